@@ -1,0 +1,110 @@
+"""ctypes binding of libomp355.so (the C ABI declared in include/omp355.h).
+
+There is NO fallback: if the shared library is missing the import fails loudly, and every op
+raises RuntimeError(omp_last_error()) on a non-zero return code.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libomp355.so')
+
+OMP_F32, OMP_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
+MAX_DEC_LAYERS = 8
+
+c_void_p, c_int, c_int32, c_int64, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
+                                              ctypes.c_int64, ctypes.c_float)
+
+
+class GemmArgs(ctypes.Structure):
+    _fields_ = [('A', c_void_p), ('lda', c_int64), ('W', c_void_p), ('ldw', c_int64),
+                ('bias', c_void_p), ('bias_row', c_void_p), ('bias_row_stride', c_int64),
+                ('residual', c_void_p), ('ldr', c_int64), ('C', c_void_p), ('ldc', c_int64),
+                ('M', c_int64), ('N', c_int32), ('K', c_int32), ('dtype', c_int32),
+                ('out_dtype', c_int32), ('act', c_int32), ('trans_out', c_int32),
+                ('trans_rows', c_int64), ('trans_ld', c_int64)]
+
+
+class SampleCfg(ctypes.Structure):
+    _fields_ = [('kind', c_int32), ('num_bins', c_int32), ('pt_eos', c_int32), ('poly_eos', c_int32),
+                ('rec_eos', c_int32), ('vocab', c_int32), ('vie_categories', c_int32),
+                ('infer_vie', c_int32), ('suppress_eos', c_int32), ('step0', c_int32)]
+
+
+class DecLayer(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        'sa_in_w', 'sa_bias_tab', 'sa_out_w', 'sa_out_b', 'ca_q_w', 'ca_qbias_tab', 'ca_out_w',
+        'ca_out_b', 'ff1_w', 'ff1_b', 'ff2_w', 'ff2_b', 'n1_g', 'n1_b', 'n2_g', 'n2_b', 'n3_g', 'n3_b',
+        'kcache', 'vcache', 'crossK', 'crossVt')]
+
+
+class DecoderPlan(ctypes.Structure):
+    _fields_ = ([(n, c_int32) for n in ('dtype', 'n_layers', 'd_model', 'n_heads', 'd_ff', 'vocab',
+                                        'pre_norm', 'R', 'Lmax', 'M', 'n_tiles', 'n_split', 'n_prompt')]
+                + [('eps', c_float), ('layers', DecLayer * MAX_DEC_LAYERS)]
+                + [(n, c_void_p) for n in ('word_emb', 'pos_tab', 'emb_g', 'emb_b', 'fn_g', 'fn_b',
+                                           'h0_w', 'h1_w', 'h2_w', 'h0_b', 'h1_b', 'h2_b')]
+                + [(n, c_int64) for n in ('ldk', 'k_batch_stride', 'ldvt', 'vt_batch_stride')]
+                + [('key_mask', c_void_p), ('tiles', c_void_p), ('seq', c_void_p), ('seq_ld', c_int32),
+                   ('d_pos', c_void_p), ('probs', c_void_p), ('finished', c_void_p), ('lengths', c_void_p)]
+                + [(n, c_void_p) for n in ('x', 'x2', 'y', 'qkv', 'att', 'q', 'ffh', 'hh0', 'hh1',
+                                           'partial', 'logits')]
+                + [('sample', SampleCfg)])
+
+
+_SIGS = {
+    'omp_abi_version': (c_int, []),
+    'omp_layernorm': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64,
+                              c_int, c_float, c_void_p]),
+    'omp_gemm_bias_act': (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
+    'omp_patch_embed_ln': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p]),
+    'omp_swin_window_attn': (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
+    'omp_patch_merge_gather_ln': (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_void_p]),
+    'omp_fpn_fuse': (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p]),
+    'omp_sine_posembed': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    'omp_dec_embed_ln': (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_void_p]),
+    'omp_dec_self_attn_step': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    'omp_dec_cross_attn_step': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                        c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                        c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    'omp_head_softmax_mask_argmax': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(SampleCfg), c_void_p,
+                                             c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'omp_decoder_run': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_int, c_int, c_void_p]),
+    'omp_decoder_graph_reset': (c_int, [c_int]),
+    'omp_decoder_step_logits': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_void_p]),
+    'omp_debug_force_gemm_kernel': (c_int, [c_int]),
+    'omp_prof_enable': (c_int, [c_int]),
+    'omp_prof_read': (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
+}
+EXPORTS = sorted(list(_SIGS) + ['omp_last_error'])
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libomp355.so not found at %s -- build it with `python -m advancedliteratemachinery_amd.build` '
+                '(there is no CPU/PyTorch fallback for the OmniParser hot path)' % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        h.omp_last_error.restype = ctypes.c_char_p
+        h.omp_last_error.argtypes = []
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        if h.omp_abi_version() != 1:
+            raise RuntimeError('libomp355.so ABI version mismatch')
+        _lib = h
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (what or 'libomp355', rc,
+                                                   lib().omp_last_error().decode('utf-8', 'replace')))

@@ -1,0 +1,65 @@
+"""Build libomp355.so (hand-written HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m advancedliteratemachinery_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so is written next to this file (git-ignored, but it
+travels with the tree to the GPU box).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, 'build')
+LIB = os.path.join(HERE, 'libomp355.so')
+SOURCES = ['api.hip', 'gemm.hip', 'norm.hip', 'swin_attn.hip', 'fpn.hip', 'decoder.hip']
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(os.path.dirname(HERE), 'include', 'omp355.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return 'hipcc'
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS):
+            jobs.append([hipcc] + FLAGS + ['-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed:\n%s\n%s' % (' '.join(cmd), r.stderr))
+        return r
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,148 @@
+// Shared device/host helpers for libomp355 (gfx950 / CDNA4 only).
+//
+// Conventions used by every kernel in this directory:
+//   * wave = 64 lanes, hard-coded.
+//   * activations are token-major (rows = tokens, channels contiguous), dtype T in {float, bf16};
+//     biases / LayerNorm affine / tables are always fp32; accumulation is always fp32.
+//   * a "fragment" is the 16 bytes one lane feeds to the matrix core per k-step:
+//       bf16 : 8 elements -> one v_mfma_f32_16x16x32_bf16
+//       f32  : 4 elements -> four v_mfma_f32_16x16x4_f32 (element j of every lane forms k-slice j)
+//     In both cases lane l supplies row (l & 15) and the k-chunk (l >> 4); the k permutation is
+//     the same for both operands, so the dot product is unaffected.
+//   * D layout of the 16x16 MFMA: acc[r] <-> (i = (l >> 4) * 4 + r, j = l & 15).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/omp355.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define OMP_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// host-side error plumbing
+// ---------------------------------------------------------------------------------------------
+void omp_set_error(const char* fmt, ...);
+#define OMP_CHECK_ARG(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      omp_set_error(__VA_ARGS__);       \
+      return OMP_ERR_INVALID;           \
+    }                                   \
+  } while (0)
+#define OMP_CHECK_LAUNCH(name)                                                   \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      omp_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return OMP_ERR_LAUNCH;                                                     \
+    }                                                                            \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// scalar conversions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // RNE
+
+// 16-byte vector of T
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+  typedef f32x4 type;
+  static constexpr int N = 4;
+};
+template <>
+struct Vec16<bf16_t> {
+  typedef bf16x8 type;
+  static constexpr int N = 8;
+};
+
+template <typename T>
+__device__ __forceinline__ typename Vec16<T>::type ld16(const T* p) {
+  return *reinterpret_cast<const typename Vec16<T>::type*>(p);
+}
+template <typename T>
+__device__ __forceinline__ void st16(T* p, typename Vec16<T>::type v) {
+  *reinterpret_cast<typename Vec16<T>::type*>(p) = v;
+}
+
+// unpack a 16-byte vector into floats
+__device__ __forceinline__ void unpack16(f32x4 v, float* o) {
+  o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+__device__ __forceinline__ void unpack16(bf16x8 v, float* o) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+__device__ __forceinline__ void pack16(const float* o, f32x4& v) {
+  v[0] = o[0]; v[1] = o[1]; v[2] = o[2]; v[3] = o[3];
+}
+__device__ __forceinline__ void pack16(const float* o, bf16x8& v) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (bf16_t)o[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// matrix-core fragment traits
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct Mma;
+template <>
+struct Mma<bf16_t> {
+  typedef bf16x8 frag;
+  static constexpr int KPL = 8;    // k elements per lane per step
+  static constexpr int KSTEP = 32; // k elements per wave per step
+  __device__ static __forceinline__ void mma(f32x4& acc, frag a, frag b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<float> {
+  typedef f32x4 frag;
+  static constexpr int KPL = 4;
+  static constexpr int KSTEP = 16;
+  __device__ static __forceinline__ void mma(f32x4& acc, frag a, frag b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave-level reductions (64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// reduce over groups of `W` consecutive lanes (W power of two <= 64)
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

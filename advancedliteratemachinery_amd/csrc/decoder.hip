@@ -1,0 +1,674 @@
+// Point-conditioned autoregressive decoders: KV-cached greedy decoding on gfx950.
+//
+// The reference re-runs the whole prefix through 4 layers at every greedy step and physically
+// replicates the image memory once per text instance (transformer.py:74-100).  Algebraically the
+// same computation is done here incrementally:
+//   * self-attention K/V of past positions live in a cache (the causal mask makes them immutable);
+//   * cross-attention K = (memory+pos) Wk^T + bk and V = memory Wv^T + bv are computed ONCE per
+//     image and shared by every query row of that image (rows are grouped in tiles of <= 16
+//     consecutive rows of one image);
+//   * (y + qpos) Wq^T == y Wq^T + (qpos Wq^T): the position term is a per-position bias table;
+//   * the 3-layer head runs on the newest position only.
+// All rows of a phase sit at the same sequence position, kept in device memory (*d_pos) so the
+// step is position-independent on the host side and can be replayed as a hipGraph.
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int DH = 64;  // decoder head_dim (512 / 8)
+
+// ---------------------------------------------------------------------------------------------
+// embedding + LayerNorm  (one wave per row)
+// ---------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void dec_embed_ln_kernel(const int32_t* __restrict__ seq, int seq_ld,
+                                                           const int32_t* __restrict__ d_pos,
+                                                           const float* __restrict__ word,
+                                                           const float* __restrict__ postab,
+                                                           const float* __restrict__ g,
+                                                           const float* __restrict__ be, float* __restrict__ x,
+                                                           TO* __restrict__ y, int R, int d, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const int p = *d_pos;
+  const int tok = seq[(int64_t)r * seq_ld + p];
+  const float* we = word + (int64_t)tok * d;
+  const float* pe = postab + (int64_t)p * d;
+  float v[4][4];
+  float s = 0.f;
+  const int nch = d / 4;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = lane + it * 64;
+    if (c < nch) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(we + c * 4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(pe + c * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[it][i] = a[i] + b[i]; s += v[it][i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[it][i] = 0.f;
+    }
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    if (lane + it * 64 < nch) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const float t = v[it][i] - mean; q += t * t; }
+    }
+  }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q / (float)d + eps);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = lane + it * 64;
+    if (c < nch) {
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c * 4);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(be + c * 4);
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (v[it][i] - mean) * rstd * gg[i] + bb[i];
+      if (x != nullptr) *reinterpret_cast<f32x4*>(x + (int64_t)r * d + c * 4) = f32x4{o[0], o[1], o[2], o[3]};
+      if (y != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[(int64_t)r * d + c * 4 + i] = from_f32<TO>(o[i]);
+      }
+    }
+  }
+}
+
+// load 8 consecutive elements as floats
+__device__ __forceinline__ void load8(const float* p, float* o) {
+  unpack16(ld16<float>(p), o);
+  unpack16(ld16<float>(p + 4), o + 4);
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float* o) { unpack16(ld16<bf16_t>(p), o); }
+__device__ __forceinline__ void store8(float* p, const float* v) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float* v) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// causal self-attention step with KV cache: one wave per (row, head).
+// lane = (js = lane>>3 : key slot, dc = lane&7 : 8-dim chunk); 8 keys per iteration, each key row
+// (64 dims) read as 8 x 16 B (bf16) -- full 128-byte lines.  Online softmax per key slot, merged
+// across the 8 slots at the end.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc,
+                                                           T* __restrict__ vc, T* __restrict__ out,
+                                                           const int32_t* __restrict__ d_pos, int R, int nH,
+                                                           int d, int Lmax) {
+  const int r = blockIdx.x, h = blockIdx.y;
+  const int lane = threadIdx.x, js = lane >> 3, dc = lane & 7;
+  const int p = *d_pos;
+  const T* row = qkv + (int64_t)r * 3 * d + h * DH + dc * 8;
+  float q[8], kn[8], vn[8];
+  load8(row, q);
+  load8(row + d, kn);
+  load8(row + 2 * d, vn);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] *= 0.125f;  // 1/sqrt(64), applied to q like nn.MultiheadAttention
+  T* kbase = kc + ((int64_t)r * Lmax) * d + h * DH + dc * 8;
+  T* vbase = vc + ((int64_t)r * Lmax) * d + h * DH + dc * 8;
+  if (js == 0) {
+    store8(kbase + (int64_t)p * d, kn);
+    store8(vbase + (int64_t)p * d, vn);
+  }
+  float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = 0.f;
+  for (int j0 = 0; j0 <= p; j0 += 8) {
+    const int j = j0 + js;
+    const bool valid = j <= p;
+    float kk[8], vv[8];
+    if (valid && j < p) {
+      load8(kbase + (int64_t)j * d, kk);
+      load8(vbase + (int64_t)j * d, vv);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { kk[i] = kn[i]; vv[i] = vn[i]; }
+    }
+    float sdot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sdot = fmaf(q[i], kk[i], sdot);
+    sdot += __shfl_xor(sdot, 1, 64);
+    sdot += __shfl_xor(sdot, 2, 64);
+    sdot += __shfl_xor(sdot, 4, 64);
+    if (valid) {
+      const float mn = fmaxf(m, sdot);
+      const float a = expf(m - mn);  // exp(-inf) = 0 on the first key
+      const float pj = expf(sdot - mn);
+      l = l * a + pj;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = o[i] * a + pj * vv[i];
+      m = mn;
+    }
+  }
+  // merge the 8 key slots (lanes differing in bits 3..5)
+  float mall = m;
+  mall = fmaxf(mall, __shfl_xor(mall, 8, 64));
+  mall = fmaxf(mall, __shfl_xor(mall, 16, 64));
+  mall = fmaxf(mall, __shfl_xor(mall, 32, 64));
+  const float sc = (m == -INFINITY) ? 0.f : expf(m - mall);
+  l *= sc;
+  l += __shfl_xor(l, 8, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float t = o[i] * sc;
+    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+    o[i] = t / l;
+  }
+  if (js == 0) store8(out + (int64_t)r * d + h * DH + dc * 8, o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cross attention, flash-style partials on the matrix cores: one wave per (tile, head, key split)
+//   S^T[key][query] = K[key,:] . Q[query,:]        (A operand = K rows, B operand = Q rows)
+//   O^T[d][query]  += V^T[d][key] * P[key][query]   (A operand = V^T rows, B operand = P)
+// The S^T accumulator layout (lane: query = l&15, keys 4*(l>>4)+r) IS the B-operand layout of the
+// second product once the k-slots are mapped to keys {k0+4g+r} (and {k0+16+4g+r} for bf16), so the
+// probabilities never leave registers; V^T rows are read with the same key permutation.
+// ---------------------------------------------------------------------------------------------
+struct CrossP {
+  const void* q; int64_t ldq;
+  const void* K; int64_t ldk, kbs;
+  const void* Vt; int64_t ldvt, vbs;
+  const uint8_t* kmask;
+  const int32_t* tiles;
+  float* partial;
+  int M, nH, n_split, keys_per_split;
+};
+
+template <typename T>
+struct CrossTraits;
+template <>
+struct CrossTraits<bf16_t> {
+  static constexpr int KB = 32;   // keys per iteration
+  static constexpr int NSB = 2;   // 16-key score blocks per iteration
+  static constexpr int DSTEPS = 2;  // 64 dims / 32
+  __device__ static __forceinline__ bf16x8 pfrag(const float* p) {
+    bf16x8 f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (bf16_t)p[i];
+    return f;
+  }
+  // V^T row fragment: keys {k0+4g..+3} and {k0+16+4g..+3}
+  __device__ static __forceinline__ bf16x8 vfrag(const bf16_t* vrow, int k0, int g) {
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(vrow + k0 + 4 * g);
+    const bf16x4 b = *reinterpret_cast<const bf16x4*>(vrow + k0 + 16 + 4 * g);
+    bf16x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return f;
+  }
+};
+template <>
+struct CrossTraits<float> {
+  static constexpr int KB = 16;
+  static constexpr int NSB = 1;
+  static constexpr int DSTEPS = 4;  // 64 dims / 16
+  __device__ static __forceinline__ f32x4 pfrag(const float* p) { return f32x4{p[0], p[1], p[2], p[3]}; }
+  __device__ static __forceinline__ f32x4 vfrag(const float* vrow, int k0, int g) {
+    return *reinterpret_cast<const f32x4*>(vrow + k0 + 4 * g);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void dec_cross_attn_kernel(CrossP p) {
+  typedef Mma<T> MM;
+  typedef CrossTraits<T> CT;
+  typedef typename MM::frag frag;
+  const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+  const int t = blockIdx.x, h = blockIdx.y, sp = blockIdx.z;
+  const int row0 = p.tiles[t * 3], nrows = p.tiles[t * 3 + 1], img = p.tiles[t * 3 + 2];
+  const int kbeg = sp * p.keys_per_split;
+  int kend = kbeg + p.keys_per_split;
+  if (kend > p.M) kend = p.M;
+
+  // Q fragments (B operand): query li (clamped), dims s*KSTEP + g*KPL ..
+  const int qrow = row0 + (li < nrows ? li : nrows - 1);
+  const T* qp = reinterpret_cast<const T*>(p.q) + (int64_t)qrow * p.ldq + h * DH + g * MM::KPL;
+  frag qf[CT::DSTEPS];
+#pragma unroll
+  for (int s = 0; s < CT::DSTEPS; ++s) {
+    float tmp[MM::KPL];
+    unpack16(ld16<T>(qp + s * MM::KSTEP), tmp);
+#pragma unroll
+    for (int i = 0; i < MM::KPL; ++i) tmp[i] *= 0.125f;
+    pack16(tmp, qf[s]);
+  }
+  const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)img * p.kbs + h * DH + g * MM::KPL;
+  const T* Vb = reinterpret_cast<const T*>(p.Vt) + (int64_t)img * p.vbs + (int64_t)(h * DH) * p.ldvt;
+  const uint8_t* km = p.kmask ? p.kmask + (int64_t)img * p.M : nullptr;
+
+  float m = -INFINITY, lpart = 0.f;
+  f32x4 ot[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = kbeg; k0 < kend; k0 += CT::KB) {
+    float sc[CT::NSB * 4];
+    float bmax = -INFINITY;
+#pragma unroll
+    for (int sb = 0; sb < CT::NSB; ++sb) {
+      int key = k0 + sb * 16 + li;            // A operand row = key
+      if (key > p.M - 1) key = p.M - 1;       // clamp: value is masked below
+      const T* kr = Kb + (int64_t)key * p.ldk;
+      f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < CT::DSTEPS; ++s) MM::mma(st, ld16<T>(kr + s * MM::KSTEP), qf[s]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = k0 + sb * 16 + g * 4 + r;  // this lane's key for acc[r]
+        float v = st[r];
+        if (kk >= kend || (km != nullptr && km[kk])) v = -INFINITY;
+        sc[sb * 4 + r] = v;
+        bmax = fmaxf(bmax, v);
+      }
+    }
+    bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
+    bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+    const float mn = fmaxf(m, bmax);
+    // no branch here: MFMAs below must run with a full EXEC mask.  If every key seen so far is
+    // masked (mn = -inf) use 0 as the reference so exp(-inf - 0) = 0 instead of NaN.
+    const float mref = (mn == -INFINITY) ? 0.f : mn;
+    const float alpha = expf(m - mref);
+    float ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < CT::NSB * 4; ++i) { sc[i] = expf(sc[i] - mref); ps += sc[i]; }
+    lpart = lpart * alpha + ps;
+    m = mn;
+    const frag pf = CT::pfrag(sc);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const T* vrow = Vb + (int64_t)(dt * 16 + li) * p.ldvt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
+      MM::mma(ot[dt], CT::vfrag(vrow, k0, g), pf);
+    }
+  }
+  float l = lpart;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (li < nrows) {
+    float* dst = p.partial + (((int64_t)(row0 + li) * p.nH + h) * p.n_split + sp) * 66;
+    if (g == 0) { dst[0] = m; dst[1] = l; }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<f32x4*>(dst + 2 + dt * 16 + g * 4) = ot[dt];
+  }
+}
+
+template <typename T>
+__global__ void dec_cross_combine_kernel(const float* __restrict__ partial, T* __restrict__ out, int64_t ldo,
+                                         int nH, int n_split) {
+  const int r = blockIdx.x;
+  for (int idx = threadIdx.x; idx < nH * DH; idx += blockDim.x) {
+    const int h = idx / DH, dd = idx % DH;
+    const float* base = partial + (((int64_t)r * nH + h) * n_split) * 66;
+    float mall = -INFINITY;
+    for (int s = 0; s < n_split; ++s) mall = fmaxf(mall, base[s * 66]);
+    float L = 0.f, o = 0.f;
+    for (int s = 0; s < n_split; ++s) {
+      const float ms = base[s * 66];
+      const float w = (ms == -INFINITY) ? 0.f : expf(ms - mall);
+      L += base[s * 66 + 1] * w;
+      o += base[s * 66 + 2 + dd] * w;
+    }
+    out[(int64_t)r * ldo + h * DH + dd] = from_f32<T>(o / L);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// greedy sampling: softmax over the support, candidate filter, argmax, probability. wave per row.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_candidate(const omp_sample_cfg& c, int tok, int i) {
+  if (c.kind == OMP_DEC_PT) {
+    const int period = c.infer_vie ? 3 : 2;
+    const int r = i % period;
+    if (r == 0) return tok < c.num_bins || (tok == c.pt_eos && !c.suppress_eos);
+    if (r == 1) return tok < c.num_bins;
+    return tok >= c.vocab - c.vie_categories;
+  }
+  if (c.kind == OMP_DEC_POLY) return tok < c.num_bins;
+  return tok >= c.num_bins && tok <= c.rec_eos && tok != c.pt_eos && tok != c.poly_eos;
+}
+
+__global__ __launch_bounds__(256) void dec_sample_kernel(const float* __restrict__ logits, int ld, int R,
+                                                         omp_sample_cfg c, int32_t* __restrict__ seq,
+                                                         float* __restrict__ probs, int seq_ld,
+                                                         int32_t* __restrict__ finished,
+                                                         int32_t* __restrict__ lengths,
+                                                         const int32_t* __restrict__ d_pos) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const int p = *d_pos;
+  const int i = p + 1 - c.step0;
+  if (i < 0) return;
+  const bool slice = c.infer_vie && c.kind != OMP_DEC_PT;
+  const int Vs = c.vocab - (slice ? c.vie_categories : 0);
+  const float* lg = logits + (int64_t)r * ld;
+  float mx = -INFINITY, best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int t = lane; t < Vs; t += 64) {
+    const float v = lg[t];
+    mx = fmaxf(mx, v);
+    if (is_candidate(c, t, i) && v > best) { best = v; bi = t; }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int t = lane; t < Vs; t += 64) sum += expf(lg[t] - mx);
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) {
+    seq[(int64_t)r * seq_ld + p + 1] = bi;
+    probs[(int64_t)r * seq_ld + p + 1] = expf(best - mx) / sum;
+    if (c.kind == OMP_DEC_PT && finished != nullptr) {
+      // reference stops at the first EOS (transformer.py:126); later tokens of a finished row are ignored
+      if (!finished[r] && bi == c.pt_eos) { finished[r] = 1; lengths[r] = p + 1; }
+    }
+  }
+}
+
+__global__ void advance_pos_kernel(int32_t* d_pos) { *d_pos += 1; }
+
+// ---------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ---------------------------------------------------------------------------------------------
+// optional hipEvent bracketing of the cross-attention kernel (bench.py's roofline measurement)
+bool g_prof = false, g_capturing = false;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
+size_t g_prof_used = 0;
+
+int launch_cross(const CrossP& cp, int n_tiles, int dtype, void* out, int64_t ldo, int R, hipStream_t st) {
+  dim3 grid(n_tiles, cp.nH, cp.n_split);
+  const bool prof = g_prof && !g_capturing;
+  if (prof) {
+    if (g_prof_used == g_prof_ev.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { omp_set_error("hipEventCreate failed"); return OMP_ERR_LAUNCH; }
+      g_prof_ev.emplace_back(a, b);
+    }
+    (void)hipEventRecord(g_prof_ev[g_prof_used].first, st);
+  }
+  if (dtype == OMP_F32) hipLaunchKernelGGL((dec_cross_attn_kernel<float>), grid, dim3(64), 0, st, cp);
+  else hipLaunchKernelGGL((dec_cross_attn_kernel<bf16_t>), grid, dim3(64), 0, st, cp);
+  if (prof) (void)hipEventRecord(g_prof_ev[g_prof_used++].second, st);
+  OMP_CHECK_LAUNCH("omp_dec_cross_attn_step");
+  if (dtype == OMP_F32)
+    hipLaunchKernelGGL((dec_cross_combine_kernel<float>), dim3(R), dim3(256), 0, st, cp.partial, (float*)out, ldo, cp.nH, cp.n_split);
+  else
+    hipLaunchKernelGGL((dec_cross_combine_kernel<bf16_t>), dim3(R), dim3(256), 0, st, cp.partial, (bf16_t*)out, ldo, cp.nH, cp.n_split);
+  OMP_CHECK_LAUNCH("omp_dec_cross_attn_step(combine)");
+  return OMP_OK;
+}
+
+int keys_per_split(int M, int n_split, int dtype) {
+  const int kb = dtype == OMP_F32 ? 16 : 32;
+  int per = (M + n_split - 1) / n_split;
+  per = ((per + kb - 1) / kb) * kb;
+  return per;
+}
+
+}  // namespace
+
+extern "C" int omp_dec_embed_ln(const int32_t* seq, int seq_ld, const int32_t* d_pos, const float* word_emb,
+                                const float* pos_tab, const float* gamma, const float* beta, float* x,
+                                void* y, int y_dtype, int R, int d, float eps, omp_stream_t s) {
+  OMP_CHECK_ARG(seq && d_pos && word_emb && pos_tab && gamma && beta && (x || y), "omp_dec_embed_ln: null pointer");
+  OMP_CHECK_ARG(R > 0 && d > 0 && d % 4 == 0 && d <= 1024, "omp_dec_embed_ln: bad shape R=%d d=%d", R, d);
+  dim3 grid((R + 3) / 4);
+  if (y_dtype == OMP_BF16 && y != nullptr)
+    hipLaunchKernelGGL((dec_embed_ln_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, seq, seq_ld, d_pos,
+                       word_emb, pos_tab, gamma, beta, x, (bf16_t*)y, R, d, eps);
+  else
+    hipLaunchKernelGGL((dec_embed_ln_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, seq, seq_ld, d_pos,
+                       word_emb, pos_tab, gamma, beta, x, (float*)y, R, d, eps);
+  OMP_CHECK_LAUNCH("omp_dec_embed_ln");
+  return OMP_OK;
+}
+
+extern "C" int omp_dec_self_attn_step(const void* qkv, void* kcache, void* vcache, void* out,
+                                      const int32_t* d_pos, int dtype, int R, int nH, int d, int Lmax,
+                                      omp_stream_t s) {
+  OMP_CHECK_ARG(qkv && kcache && vcache && out && d_pos, "omp_dec_self_attn_step: null pointer");
+  OMP_CHECK_ARG(d == nH * DH, "omp_dec_self_attn_step: head_dim must be 64 (d=%d nH=%d)", d, nH);
+  dim3 grid(R, nH);
+  if (dtype == OMP_F32)
+    hipLaunchKernelGGL((dec_self_attn_kernel<float>), grid, dim3(64), 0, (hipStream_t)s, (const float*)qkv,
+                       (float*)kcache, (float*)vcache, (float*)out, d_pos, R, nH, d, Lmax);
+  else if (dtype == OMP_BF16)
+    hipLaunchKernelGGL((dec_self_attn_kernel<bf16_t>), grid, dim3(64), 0, (hipStream_t)s, (const bf16_t*)qkv,
+                       (bf16_t*)kcache, (bf16_t*)vcache, (bf16_t*)out, d_pos, R, nH, d, Lmax);
+  else { omp_set_error("omp_dec_self_attn_step: bad dtype"); return OMP_ERR_INVALID; }
+  OMP_CHECK_LAUNCH("omp_dec_self_attn_step");
+  return OMP_OK;
+}
+
+extern "C" int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K, int64_t ldk,
+                                       int64_t k_batch_stride, const void* Vt, int64_t ldvt,
+                                       int64_t vt_batch_stride, const uint8_t* key_mask,
+                                       const int32_t* tiles, int n_tiles, int R, float* partial, void* out,
+                                       int64_t ldo, int dtype, int M, int nH, int n_split, omp_stream_t s) {
+  OMP_CHECK_ARG(q && K && Vt && tiles && partial && out, "omp_dec_cross_attn_step: null pointer");
+  OMP_CHECK_ARG(dtype == OMP_F32 || dtype == OMP_BF16, "omp_dec_cross_attn_step: bad dtype");
+  OMP_CHECK_ARG(n_tiles > 0 && n_split > 0 && M > 0 && R > 0, "omp_dec_cross_attn_step: bad sizes");
+  OMP_CHECK_ARG(ldvt % 8 == 0, "omp_dec_cross_attn_step: ldvt must be a multiple of 8 (got %lld)", (long long)ldvt);
+  CrossP cp;
+  cp.q = q; cp.ldq = ldq; cp.K = K; cp.ldk = ldk; cp.kbs = k_batch_stride;
+  cp.Vt = Vt; cp.ldvt = ldvt; cp.vbs = vt_batch_stride; cp.kmask = key_mask; cp.tiles = tiles;
+  cp.partial = partial; cp.M = M; cp.nH = nH; cp.n_split = n_split;
+  cp.keys_per_split = keys_per_split(M, n_split, dtype);
+  return launch_cross(cp, n_tiles, dtype, out, ldo, R, (hipStream_t)s);
+}
+
+extern "C" int omp_head_softmax_mask_argmax(const float* logits, int ld, int R, const omp_sample_cfg* cfg,
+                                            int32_t* seq, float* probs, int seq_ld, int32_t* finished,
+                                            int32_t* lengths, int32_t* d_pos, int advance, omp_stream_t s) {
+  OMP_CHECK_ARG(logits && cfg && seq && probs && d_pos, "omp_head_softmax_mask_argmax: null pointer");
+  OMP_CHECK_ARG(R > 0 && cfg->vocab > 0 && cfg->vocab <= ld, "omp_head_softmax_mask_argmax: bad shape");
+  hipLaunchKernelGGL(dec_sample_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, ld, R, *cfg,
+                     seq, probs, seq_ld, finished, lengths, d_pos);
+  OMP_CHECK_LAUNCH("omp_head_softmax_mask_argmax");
+  if (advance) {
+    hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, d_pos);
+    OMP_CHECK_LAUNCH("omp_head_softmax_mask_argmax(advance)");
+  }
+  return OMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one full decoder step, launched from the host (eager or under stream capture)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+#define RUN(expr)                 \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != OMP_OK) return rc__; \
+  } while (0)
+
+int gemm(const omp_decoder_plan* P, const void* A, int64_t lda, const void* W, int K, int N, const float* bias,
+         const int32_t* bias_row, int64_t bias_stride, const void* res, void* C, int out_dtype, int act,
+         hipStream_t st) {
+  omp_gemm_args a{};
+  a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.bias_row = bias_row; a.bias_row_stride = bias_stride;
+  a.residual = res; a.ldr = N; a.C = C; a.ldc = N; a.M = P->R; a.N = N; a.K = K;
+  a.dtype = P->dtype; a.out_dtype = out_dtype; a.act = act; a.trans_out = 0; a.trans_rows = 0; a.trans_ld = 0;
+  return omp_gemm_bias_act(&a, st);
+}
+
+int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
+  const int d = P->d_model, R = P->R, T = P->dtype;
+  // embedding: pre-norm needs only the fp32 stream; post-norm also the T copy
+  RUN(omp_dec_embed_ln(P->seq, P->seq_ld, P->d_pos, P->word_emb, P->pos_tab, P->emb_g, P->emb_b, P->x,
+                       P->pre_norm ? nullptr : P->y, T, R, d, P->eps, st));
+  CrossP cp;
+  cp.q = P->q; cp.ldq = d; cp.ldk = P->ldk; cp.kbs = P->k_batch_stride; cp.ldvt = P->ldvt;
+  cp.vbs = P->vt_batch_stride; cp.kmask = P->key_mask; cp.tiles = P->tiles; cp.partial = P->partial;
+  cp.M = P->M; cp.nH = P->n_heads; cp.n_split = P->n_split;
+  cp.keys_per_split = keys_per_split(P->M, P->n_split, T);
+  for (int li = 0; li < P->n_layers; ++li) {
+    const omp_dec_layer& L = P->layers[li];
+    cp.K = L.crossK; cp.Vt = L.crossVt;
+    if (P->pre_norm) {
+      RUN(omp_layernorm(P->x, OMP_F32, L.n1_g, L.n1_b, P->y, T, nullptr, R, d, P->eps, st));
+      RUN(gemm(P, P->y, d, L.sa_in_w, d, 3 * d, L.sa_bias_tab, P->d_pos, 3 * d, nullptr, P->qkv, T, OMP_ACT_NONE, st));
+      RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, T, R, P->n_heads, d, P->Lmax, st));
+      RUN(gemm(P, P->att, d, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
+      RUN(omp_layernorm(P->x, OMP_F32, L.n2_g, L.n2_b, P->y, T, nullptr, R, d, P->eps, st));
+      RUN(gemm(P, P->y, d, L.ca_q_w, d, d, L.ca_qbias_tab, P->d_pos, d, nullptr, P->q, T, OMP_ACT_NONE, st));
+      RUN(launch_cross(cp, P->n_tiles, T, P->att, d, R, st));
+      RUN(gemm(P, P->att, d, L.ca_out_w, d, d, L.ca_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
+      RUN(omp_layernorm(P->x, OMP_F32, L.n3_g, L.n3_b, P->y, T, nullptr, R, d, P->eps, st));
+      RUN(gemm(P, P->y, d, L.ff1_w, d, P->d_ff, L.ff1_b, nullptr, 0, nullptr, P->ffh, T, OMP_ACT_RELU, st));
+      RUN(gemm(P, P->ffh, P->d_ff, L.ff2_w, P->d_ff, d, L.ff2_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
+    } else {
+      RUN(gemm(P, P->y, d, L.sa_in_w, d, 3 * d, L.sa_bias_tab, P->d_pos, 3 * d, nullptr, P->qkv, T, OMP_ACT_NONE, st));
+      RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, T, R, P->n_heads, d, P->Lmax, st));
+      RUN(gemm(P, P->att, d, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x2, OMP_F32, OMP_ACT_NONE, st));
+      RUN(omp_layernorm(P->x2, OMP_F32, L.n1_g, L.n1_b, P->y, T, P->x, R, d, P->eps, st));
+      RUN(gemm(P, P->y, d, L.ca_q_w, d, d, L.ca_qbias_tab, P->d_pos, d, nullptr, P->q, T, OMP_ACT_NONE, st));
+      RUN(launch_cross(cp, P->n_tiles, T, P->att, d, R, st));
+      RUN(gemm(P, P->att, d, L.ca_out_w, d, d, L.ca_out_b, nullptr, 0, P->x, P->x2, OMP_F32, OMP_ACT_NONE, st));
+      RUN(omp_layernorm(P->x2, OMP_F32, L.n2_g, L.n2_b, P->y, T, P->x, R, d, P->eps, st));
+      RUN(gemm(P, P->y, d, L.ff1_w, d, P->d_ff, L.ff1_b, nullptr, 0, nullptr, P->ffh, T, OMP_ACT_RELU, st));
+      RUN(gemm(P, P->ffh, P->d_ff, L.ff2_w, P->d_ff, d, L.ff2_b, nullptr, 0, P->x, P->x2, OMP_F32, OMP_ACT_NONE, st));
+      RUN(omp_layernorm(P->x2, OMP_F32, L.n3_g, L.n3_b, P->y, T, P->x, R, d, P->eps, st));
+    }
+  }
+  if (do_head) {
+    RUN(omp_layernorm(P->x, OMP_F32, P->fn_g, P->fn_b, P->y, T, nullptr, R, d, P->eps, st));
+    RUN(gemm(P, P->y, d, P->h0_w, d, d, P->h0_b, nullptr, 0, nullptr, P->hh0, T, OMP_ACT_RELU, st));
+    RUN(gemm(P, P->hh0, d, P->h1_w, d, d, P->h1_b, nullptr, 0, nullptr, P->hh1, T, OMP_ACT_RELU, st));
+    RUN(gemm(P, P->hh1, d, P->h2_w, d, P->vocab, P->h2_b, nullptr, 0, nullptr, P->logits, OMP_F32, OMP_ACT_NONE, st));
+  }
+  return OMP_OK;
+}
+
+int check_plan(const omp_decoder_plan* P) {
+  OMP_CHECK_ARG(P != nullptr, "omp_decoder_run: null plan");
+  OMP_CHECK_ARG(P->dtype == OMP_F32 || P->dtype == OMP_BF16, "omp_decoder_run: bad dtype");
+  OMP_CHECK_ARG(P->n_layers > 0 && P->n_layers <= OMP_MAX_DEC_LAYERS, "omp_decoder_run: bad n_layers %d", P->n_layers);
+  OMP_CHECK_ARG(P->d_model == P->n_heads * DH, "omp_decoder_run: head_dim must be 64");
+  OMP_CHECK_ARG(P->R > 0 && P->Lmax > 0 && P->M > 0 && P->n_tiles > 0 && P->n_split > 0, "omp_decoder_run: bad sizes");
+  OMP_CHECK_ARG(P->seq && P->d_pos && P->probs && P->x && P->y && P->qkv && P->att && P->q && P->ffh && P->hh0 &&
+                    P->hh1 && P->partial && P->logits && P->tiles,
+                "omp_decoder_run: null buffer in plan");
+  OMP_CHECK_ARG(P->pre_norm || P->x2, "omp_decoder_run: post-norm needs x2");
+  return OMP_OK;
+}
+
+struct GraphSlot {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+std::vector<GraphSlot> g_slots;
+
+int sample_and_advance(const omp_decoder_plan* P, hipStream_t st) {
+  return omp_head_softmax_mask_argmax(P->logits, P->vocab, P->R, &P->sample, P->seq, P->probs, P->seq_ld,
+                                      P->finished, P->lengths, P->d_pos, 1, st);
+}
+
+}  // namespace
+
+/* bench instrumentation: bracket every (non-captured) cross-attention launch with hipEvents on the
+ * launch stream; omp_prof_read synchronises those events and returns total ms / launch count. */
+extern "C" int omp_prof_enable(int on) {
+  g_prof = on != 0;
+  g_prof_used = 0;
+  return OMP_OK;
+}
+extern "C" int omp_prof_read(double* total_ms, int64_t* count) {
+  double tot = 0.0;
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof_ev[i].second) != hipSuccess ||
+        hipEventElapsedTime(&ms, g_prof_ev[i].first, g_prof_ev[i].second) != hipSuccess) {
+      omp_set_error("omp_prof_read: event query failed");
+      return OMP_ERR_LAUNCH;
+    }
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (count) *count = (int64_t)g_prof_used;
+  return OMP_OK;
+}
+
+extern "C" int omp_decoder_graph_reset(int slot) {
+  if (slot >= 0 && slot < (int)g_slots.size()) {
+    if (g_slots[slot].exec) (void)hipGraphExecDestroy(g_slots[slot].exec);
+    if (g_slots[slot].graph) (void)hipGraphDestroy(g_slots[slot].graph);
+    g_slots[slot] = GraphSlot();
+  }
+  return OMP_OK;
+}
+
+extern "C" int omp_decoder_run(const omp_decoder_plan* P, int first_pos, int n_steps, int graph_slot,
+                               omp_stream_t s) {
+  RUN(check_plan(P));
+  OMP_CHECK_ARG(first_pos >= 0 && first_pos + n_steps <= P->Lmax, "omp_decoder_run: positions %d..%d exceed Lmax %d",
+                first_pos, first_pos + n_steps, P->Lmax);
+  OMP_CHECK_ARG(first_pos + n_steps + 1 <= P->seq_ld, "omp_decoder_run: seq_ld %d too small", P->seq_ld);
+  hipStream_t st = (hipStream_t)s;
+  for (int i = 0; i < n_steps; ++i) {
+    const int pos = first_pos + i;
+    const bool do_head = pos >= P->n_prompt - 1;
+    if (!do_head) {
+      RUN(step_launch(P, false, st));
+      hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, st, P->d_pos);
+      OMP_CHECK_LAUNCH("omp_decoder_run(advance)");
+      continue;
+    }
+    if (graph_slot < 0) {
+      RUN(step_launch(P, true, st));
+      RUN(sample_and_advance(P, st));
+      continue;
+    }
+    if ((int)g_slots.size() <= graph_slot) g_slots.resize(graph_slot + 1);
+    GraphSlot& gs = g_slots[graph_slot];
+    if (gs.exec == nullptr) {
+      hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+      if (e != hipSuccess) { omp_set_error("omp_decoder_run: begin capture: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
+      g_capturing = true;
+      int rc = step_launch(P, true, st);
+      if (rc == OMP_OK) rc = sample_and_advance(P, st);
+      g_capturing = false;
+      e = hipStreamEndCapture(st, &gs.graph);
+      if (rc != OMP_OK) return rc;
+      if (e != hipSuccess) { omp_set_error("omp_decoder_run: end capture: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
+      e = hipGraphInstantiate(&gs.exec, gs.graph, nullptr, nullptr, 0);
+      if (e != hipSuccess) { omp_set_error("omp_decoder_run: instantiate: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
+    }
+    hipError_t e = hipGraphLaunch(gs.exec, st);
+    if (e != hipSuccess) { omp_set_error("omp_decoder_run: graph launch: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
+  }
+  return OMP_OK;
+}
+
+extern "C" int omp_decoder_step_logits(const omp_decoder_plan* P, int pos, omp_stream_t s) {
+  RUN(check_plan(P));
+  (void)pos;
+  hipStream_t st = (hipStream_t)s;
+  RUN(step_launch(P, true, st));
+  hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, st, P->d_pos);
+  OMP_CHECK_LAUNCH("omp_decoder_step_logits(advance)");
+  return OMP_OK;
+}

@@ -1,0 +1,312 @@
+// GEMM with fused epilogue for gfx950:  C = act(A @ W^T + bias) + residual
+//
+// Two kernels, both on the 16x16 MFMA (bf16: v_mfma_f32_16x16x32_bf16, f32: v_mfma_f32_16x16x4_f32):
+//
+//  gemm_tiled<T,TOut,BM,BN>  LDS-tiled, 4 waves (2x2), register-staged double buffer, one barrier
+//                            per 128-byte K tile, XOR-swizzled LDS rows (conflict-free
+//                            ds_read_b128), XCD-aware tile order.  Used for the big Swin / FPN /
+//                            KV-projection GEMMs (M = tokens).
+//  gemm_rows<T,TOut>         no LDS; each wave streams a 16-row slab of W straight into MFMA
+//                            fragments.  Used for the decoder's small-M (8..64 rows) weight-
+//                            streaming GEMMs where nothing is reused inside a workgroup.
+//
+// Operand orientation: the matrix core computes D[i][j] with i = output feature n (A operand =
+// rows of W) and j = token m (B operand = rows of A).  A lane then owns 4 CONSECUTIVE output
+// features of one token (acc[r] <-> n = 4*(lane>>4)+r, m = lane&15), so bias loads and C stores
+// are 8/16-byte vectors instead of 4 scalar stores.
+#include "common.h"
+
+namespace {
+
+int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows (debug/testing)
+
+struct GemmP {
+  const void* A; int64_t lda;
+  const void* W; int64_t ldw;
+  const float* bias; const int32_t* bias_row; int64_t bias_row_stride;
+  const void* residual; int64_t ldr;
+  void* C; int64_t ldc;
+  int64_t M; int N; int K;
+  int act; int trans_out; int64_t trans_rows, trans_ld;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == OMP_ACT_GELU) return gelu_erf(v);
+  if (act == OMP_ACT_RELU) return fmaxf(v, 0.0f);
+  return v;
+}
+
+// Store the 4 consecutive-n values a lane holds for token m.
+template <typename TOut>
+__device__ __forceinline__ void epilogue_store(const GemmP& p, const float* bias, int64_t m, int n,
+                                               f32x4 acc) {
+  if (m >= p.M || n >= p.N) return;
+  const TOut* res = reinterpret_cast<const TOut*>(p.residual);
+  TOut* C = reinterpret_cast<TOut*>(p.C);
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float b = (bias != nullptr && n + r < p.N) ? bias[n + r] : 0.0f;
+    v[r] = apply_act(acc[r] + b, p.act);
+  }
+  if (p.trans_out) {
+    int64_t bidx = m / p.trans_rows, mi = m % p.trans_rows;
+    TOut* base = C + bidx * (int64_t)p.N * p.trans_ld + mi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < p.N) base[(int64_t)(n + r) * p.trans_ld] = from_f32<TOut>(v[r]);
+    return;
+  }
+  const bool full = (n + 3 < p.N) && ((p.ldc & 3) == 0) && (res == nullptr || (p.ldr & 3) == 0);
+  if (full) {
+    if (res != nullptr) {
+      if constexpr (sizeof(TOut) == 4) {
+        f32x4 rv = *reinterpret_cast<const f32x4*>(res + m * p.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+      } else {
+        bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + m * p.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+      }
+    }
+    if constexpr (sizeof(TOut) == 4) {
+      f32x4 o = {v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(C + m * p.ldc + n) = o;
+    } else {
+      bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4*>(C + m * p.ldc + n) = o;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n + r < p.N) {
+        float o = v[r];
+        if (res != nullptr) o += to_f32(res[m * p.ldr + n + r]);
+        C[m * p.ldc + n + r] = from_f32<TOut>(o);
+      }
+    }
+  }
+}
+
+// bijective XCD remap: consecutive logical tile ids land on the same XCD (block b runs on XCD b%8)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
+
+template <typename T, typename TOut, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_tiled(GemmP p) {
+  typedef Mma<T> MM;
+  typedef typename MM::frag frag;
+  constexpr int ROWB = 128;                       // bytes of K per LDS row
+  constexpr int KT = ROWB / (int)sizeof(T);       // k elements per tile
+  constexpr int STEPS = KT / MM::KSTEP;           // 2
+  constexpr int EPC = 16 / (int)sizeof(T);        // elements per 16-byte chunk
+  constexpr int ACH = BM * 8 / 256;               // chunks per thread for the A tile
+  constexpr int WCH = BN * 8 / 256;
+  constexpr int FM = BM / 32, FN = BN / 32;       // frags per wave (wave tile = BM/2 x BN/2)
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * ROWB];
+  constexpr int BUF = (BM + BN) * ROWB;  // one stage: A tile then W tile
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int n0 = tn * BN;
+
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* W = reinterpret_cast<const T*>(p.W);
+
+  // per-thread staging coordinates
+  const T* a_src[ACH]; int a_dst[ACH];
+  const T* w_src[WCH]; int w_dst[WCH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    int id = tid + 256 * i, row = id >> 3, c = id & 7;
+    int64_t gm = m0 + row; if (gm > p.M - 1) gm = p.M - 1;
+    a_src[i] = A + gm * p.lda + c * EPC;
+    a_dst[i] = row * ROWB + ((c ^ (row & 7)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) {
+    int id = tid + 256 * i, row = id >> 3, c = id & 7;
+    int gn = n0 + row; if (gn > p.N - 1) gn = p.N - 1;
+    w_src[i] = W + (int64_t)gn * p.ldw + c * EPC;
+    w_dst[i] = row * ROWB + ((c ^ (row & 7)) << 4);
+  }
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  frag ra[ACH], rw[WCH];
+  const int nk = p.K / KT;
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) ra[i] = ld16<T>(a_src[i]);
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) rw[i] = ld16<T>(w_src[i]);
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) *reinterpret_cast<frag*>(smem + a_dst[i]) = ra[i];
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) *reinterpret_cast<frag*>(smem + BM * ROWB + w_dst[i]) = rw[i];
+  __syncthreads();
+
+  const int lrow = lane & 15, lg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      const int koff = (kt + 1) * KT;
+#pragma unroll
+      for (int i = 0; i < ACH; ++i) ra[i] = ld16<T>(a_src[i] + koff);
+#pragma unroll
+      for (int i = 0; i < WCH; ++i) rw[i] = ld16<T>(w_src[i] + koff);
+    }
+    const char* as = smem + cur * BUF + (wm * (BM / 2)) * ROWB;
+    const char* ws = smem + cur * BUF + BM * ROWB + (wn * (BN / 2)) * ROWB;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      frag fw[FN], fx[FM];
+      const int c = s * 4 + lg;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        int row = i * 16 + lrow;   // (row & 7) == (lrow & 7) because tiles are 16-row aligned
+        fw[i] = *reinterpret_cast<const frag*>(ws + row * ROWB + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        int row = j * 16 + lrow;
+        fx[j] = *reinterpret_cast<const frag*>(as + row * ROWB + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) MM::mma(acc[i][j], fw[i], fx[j]);
+    }
+    if (kt + 1 < nk) {
+      const int nxt = cur ^ 1;
+#pragma unroll
+      for (int i = 0; i < ACH; ++i) *reinterpret_cast<frag*>(smem + nxt * BUF + a_dst[i]) = ra[i];
+#pragma unroll
+      for (int i = 0; i < WCH; ++i) *reinterpret_cast<frag*>(smem + nxt * BUF + BM * ROWB + w_dst[i]) = rw[i];
+    }
+    __syncthreads();
+  }
+
+  const float* bias = p.bias;
+  if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int n = n0 + wn * (BN / 2) + i * 16 + lg * 4;
+      const int64_t m = m0 + wm * (BM / 2) + j * 16 + lrow;
+      epilogue_store<TOut>(p, bias, m, n, acc[i][j]);
+    }
+}
+
+// Small-M path: grid (ceil(N/64), ceil(M/16)), 4 waves, wave w owns output features
+// [bx*64 + 16w, +16) for tokens [by*16, +16).  No LDS, fragments come straight from global.
+template <typename T, typename TOut>
+__global__ __launch_bounds__(256) void gemm_rows(GemmP p) {
+  typedef Mma<T> MM;
+  typedef typename MM::frag frag;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lrow = lane & 15, lg = lane >> 4;
+  const int nb = blockIdx.x * 64 + wave * 16;
+  const int64_t mb = (int64_t)blockIdx.y * 16;
+  if (nb >= p.N) return;
+  int gn = nb + lrow; if (gn > p.N - 1) gn = p.N - 1;
+  int64_t gm = mb + lrow; if (gm > p.M - 1) gm = p.M - 1;
+  const T* wp = reinterpret_cast<const T*>(p.W) + (int64_t)gn * p.ldw + lg * MM::KPL;
+  const T* xp = reinterpret_cast<const T*>(p.A) + gm * p.lda + lg * MM::KPL;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int nsteps = p.K / MM::KSTEP;
+  int s = 0;
+  for (; s + 8 <= nsteps; s += 8) {
+    frag fw[8], fx[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      fw[u] = ld16<T>(wp + (s + u) * MM::KSTEP);
+      fx[u] = ld16<T>(xp + (s + u) * MM::KSTEP);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      MM::mma(acc0, fw[u], fx[u]);
+      MM::mma(acc1, fw[u + 1], fx[u + 1]);
+    }
+  }
+  for (; s < nsteps; ++s) MM::mma(acc0, ld16<T>(wp + s * MM::KSTEP), ld16<T>(xp + s * MM::KSTEP));
+  f32x4 acc = acc0 + acc1;
+  const float* bias = p.bias;
+  if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
+  epilogue_store<TOut>(p, bias, mb + lrow, nb + lg * 4, acc);
+}
+
+template <typename T, typename TOut>
+int launch_gemm(const GemmP& p0, hipStream_t st) {
+  GemmP p = p0;
+  int which = g_force_kernel;
+  if (which == 0) {
+    if (p.M <= 64) which = 3;
+    else if (ceil_div64(p.M, 128) * ceil_div64(p.N, 128) < 512) which = 2;
+    else which = 1;
+  }
+  if (which == 3) {
+    dim3 grid((unsigned)ceil_div64(p.N, 64), (unsigned)ceil_div64(p.M, 16));
+    hipLaunchKernelGGL((gemm_rows<T, TOut>), grid, dim3(256), 0, st, p);
+  } else if (which == 2) {
+    p.tiles_m = (int)ceil_div64(p.M, 64); p.tiles_n = (int)ceil_div64(p.N, 64);
+    hipLaunchKernelGGL((gemm_tiled<T, TOut, 64, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  } else {
+    p.tiles_m = (int)ceil_div64(p.M, 128); p.tiles_n = (int)ceil_div64(p.N, 128);
+    hipLaunchKernelGGL((gemm_tiled<T, TOut, 128, 128>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  }
+  OMP_CHECK_LAUNCH("omp_gemm_bias_act");
+  return OMP_OK;
+}
+
+}  // namespace
+
+extern "C" int omp_debug_force_gemm_kernel(int which) {
+  g_force_kernel = which;
+  return OMP_OK;
+}
+
+extern "C" int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s) {
+  OMP_CHECK_ARG(a != nullptr, "omp_gemm_bias_act: null args");
+  OMP_CHECK_ARG(a->A && a->W && a->C, "omp_gemm_bias_act: null A/W/C");
+  OMP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "omp_gemm_bias_act: bad shape M=%lld N=%d K=%d",
+                (long long)a->M, a->N, a->K);
+  OMP_CHECK_ARG(a->dtype == OMP_F32 || a->dtype == OMP_BF16, "omp_gemm_bias_act: bad dtype %d", a->dtype);
+  OMP_CHECK_ARG(a->out_dtype == a->dtype || a->out_dtype == OMP_F32,
+                "omp_gemm_bias_act: out_dtype must equal dtype or be f32");
+  const int esz = a->dtype == OMP_F32 ? 4 : 2;
+  const int ktile = 128 / esz;
+  OMP_CHECK_ARG(a->K % ktile == 0, "omp_gemm_bias_act: K=%d must be a multiple of %d", a->K, ktile);
+  OMP_CHECK_ARG((a->lda * esz) % 16 == 0 && (a->ldw * esz) % 16 == 0,
+                "omp_gemm_bias_act: lda/ldw rows must be 16-byte aligned");
+  OMP_CHECK_ARG(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->W % 16) == 0 && ((uintptr_t)a->C % 16) == 0,
+                "omp_gemm_bias_act: A/W/C must be 16-byte aligned");
+  OMP_CHECK_ARG(!a->trans_out || (a->trans_rows > 0 && a->trans_ld >= a->trans_rows),
+                "omp_gemm_bias_act: trans_rows must be > 0 and trans_ld >= trans_rows");
+  OMP_CHECK_ARG(a->M < (1ll << 31), "omp_gemm_bias_act: M too large");
+  GemmP p;
+  p.A = a->A; p.lda = a->lda; p.W = a->W; p.ldw = a->ldw;
+  p.bias = a->bias; p.bias_row = a->bias_row; p.bias_row_stride = a->bias_row_stride;
+  p.residual = a->residual; p.ldr = a->ldr; p.C = a->C; p.ldc = a->ldc;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act;
+  p.trans_out = a->trans_out; p.trans_rows = a->trans_rows; p.trans_ld = a->trans_ld; p.tiles_m = p.tiles_n = 0;
+  hipStream_t st = (hipStream_t)s;
+  if (a->dtype == OMP_F32) return launch_gemm<float, float>(p, st);
+  if (a->out_dtype == OMP_F32) return launch_gemm<bf16_t, float>(p, st);
+  return launch_gemm<bf16_t, bf16_t>(p, st);
+}

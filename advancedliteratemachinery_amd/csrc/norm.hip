@@ -1,0 +1,255 @@
+// LayerNorm family (HBM-bound): plain LN, PatchMerging gather+LN, PatchEmbed conv4x4+LN.
+//
+// Layout: a row of C channels is covered by LPR = 2^k <= 64 lanes, each lane owning IT 16-byte
+// chunks (chunk c = sub + it*LPR), so a wave processes 64/LPR rows at once and every global access
+// is a full 16-byte vector.  Row statistics are two-pass in registers (mean, then centred
+// variance -- same numerics as ATen's LayerNorm), reduced with xor-shuffles inside the LPR group.
+#include "common.h"
+
+namespace {
+
+template <typename TO, int NV>
+__device__ __forceinline__ void store_vals(TO* p, const float* v) {
+  if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+    for (int i = 0; i < NV; i += 4) {
+      f32x4 o = {v[i], v[i + 1], v[i + 2], v[i + 3]};
+      *reinterpret_cast<f32x4*>(p + i) = o;
+    }
+  } else {
+    if constexpr (NV == 8) {
+      bf16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+      *reinterpret_cast<bf16x8*>(p) = o;
+    } else {
+      bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4*>(p) = o;
+    }
+  }
+}
+
+struct LnP {
+  const void* x; const float* g; const float* b; void* y; float* yf;
+  int64_t rows; int C; int lpr_log2; float eps;
+  // gather mode (PatchMerging): x is [B,H,W,Cin], row = (b, y2, x2), C = 4*Cin
+  int gather; int H, W, Cin, H2, W2;
+};
+
+template <typename TI, typename TO, int IT>
+__global__ __launch_bounds__(256) void ln_kernel(LnP p) {
+  constexpr int NV = Vec16<TI>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int LPR = 1 << p.lpr_log2;
+  const int rpw = 64 >> p.lpr_log2;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * rpw + (lane >> p.lpr_log2);
+  const int sub = lane & (LPR - 1);
+  const bool rvalid = row < p.rows;
+  const int nchunks = p.C / NV;
+  const TI* X = reinterpret_cast<const TI*>(p.x);
+
+  // gather bookkeeping
+  int gb = 0, gy = 0, gx = 0, cpp = 1;
+  if (p.gather) {
+    int64_t r = rvalid ? row : 0;
+    gx = (int)(r % p.W2); r /= p.W2;
+    gy = (int)(r % p.H2); gb = (int)(r / p.H2);
+    cpp = p.Cin / NV;  // chunks per part
+  }
+
+  float v[IT][NV];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int c = sub + it * LPR;
+    bool ok = rvalid && c < nchunks;
+    const TI* src = nullptr;
+    if (ok) {
+      if (p.gather) {
+        const int part = c / cpp, cc = c - part * cpp;
+        const int yy = 2 * gy + (part & 1), xx = 2 * gx + (part >> 1);
+        if (yy < p.H && xx < p.W)
+          src = X + (((int64_t)gb * p.H + yy) * p.W + xx) * p.Cin + cc * NV;
+        else
+          ok = false;  // zero padding (F.pad), still counted in the statistics
+      } else {
+        src = X + row * p.C + c * NV;
+      }
+    }
+    if (ok) {
+      unpack16(ld16<TI>(src), v[it]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[it][i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[it][i];
+  }
+  for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)p.C;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int c = sub + it * LPR;
+    if (c < nchunks) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { float d = v[it][i] - mean; q += d * d; }
+    }
+  }
+  for (int o = LPR >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.0f / sqrtf(q / (float)p.C + p.eps);
+  if (!rvalid) return;
+  TO* Y = reinterpret_cast<TO*>(p.y);
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int c = sub + it * LPR;
+    if (c < nchunks) {
+      float o[NV];
+#pragma unroll
+      for (int i = 0; i < NV; i += 4) {
+        f32x4 gg = *reinterpret_cast<const f32x4*>(p.g + c * NV + i);
+        f32x4 bb = *reinterpret_cast<const f32x4*>(p.b + c * NV + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[i + j] = (v[it][i + j] - mean) * rstd * gg[j] + bb[j];
+      }
+      if (Y != nullptr) store_vals<TO, NV>(Y + row * p.C + c * NV, o);
+      if (p.yf != nullptr) store_vals<float, NV>(p.yf + row * p.C + c * NV, o);
+    }
+  }
+}
+
+template <typename TI, typename TO>
+int launch_ln(LnP p, hipStream_t st, const char* name) {
+  constexpr int NV = Vec16<TI>::N;
+  OMP_CHECK_ARG(p.C % NV == 0 && p.C % 4 == 0, "%s: C=%d must be a multiple of %d", name, p.C, NV);
+  const int nchunks = p.C / NV;
+  int lg = 0;
+  while ((1 << lg) < nchunks && lg < 6) ++lg;
+  p.lpr_log2 = lg;
+  const int LPR = 1 << lg;
+  const int it = (nchunks + LPR - 1) / LPR;
+  const int rpw = 64 >> lg;
+  const int64_t blocks = ceil_div64(p.rows, 4 * rpw);
+  dim3 grid((unsigned)blocks), block(256);
+  if (it <= 1) hipLaunchKernelGGL((ln_kernel<TI, TO, 1>), grid, block, 0, st, p);
+  else if (it <= 2) hipLaunchKernelGGL((ln_kernel<TI, TO, 2>), grid, block, 0, st, p);
+  else if (it <= 4) hipLaunchKernelGGL((ln_kernel<TI, TO, 4>), grid, block, 0, st, p);
+  else if (it <= 8) hipLaunchKernelGGL((ln_kernel<TI, TO, 8>), grid, block, 0, st, p);
+  else if (it <= 16) hipLaunchKernelGGL((ln_kernel<TI, TO, 16>), grid, block, 0, st, p);
+  else { omp_set_error("%s: C=%d too large", name, p.C); return OMP_ERR_UNSUPPORTED; }
+  OMP_CHECK_LAUNCH(name);
+  return OMP_OK;
+}
+
+int dispatch_ln(LnP p, int x_dtype, int y_dtype, hipStream_t st, const char* name) {
+  if (x_dtype == OMP_F32 && y_dtype == OMP_F32) return launch_ln<float, float>(p, st, name);
+  if (x_dtype == OMP_F32 && y_dtype == OMP_BF16) return launch_ln<float, bf16_t>(p, st, name);
+  if (x_dtype == OMP_BF16 && y_dtype == OMP_BF16) return launch_ln<bf16_t, bf16_t>(p, st, name);
+  if (x_dtype == OMP_BF16 && y_dtype == OMP_F32) return launch_ln<bf16_t, float>(p, st, name);
+  omp_set_error("%s: bad dtypes %d -> %d", name, x_dtype, y_dtype);
+  return OMP_ERR_INVALID;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PatchEmbed: one block = TOK consecutive tokens of one token-row; thread c = output channel.
+// ---------------------------------------------------------------------------------------------
+constexpr int PE_TOK = 8;
+
+template <typename TO>
+__global__ void patch_embed_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                   const float* __restrict__ bias, const float* __restrict__ g,
+                                   const float* __restrict__ be, TO* __restrict__ out, int B, int H,
+                                   int W, int Hp, int Wp, int E, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* patch = sm;               // [PE_TOK][48]
+  float* vals = sm + PE_TOK * 48;  // [PE_TOK][E]
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int xb = blockIdx.x * PE_TOK, ty = blockIdx.y, b = blockIdx.z;
+  for (int idx = tid; idx < PE_TOK * 48; idx += nthr) {
+    const int t = idx / 48, e = idx - t * 48;
+    const int ch = e >> 4, ky = (e >> 2) & 3, kx = e & 3;
+    const int py = ty * 4 + ky, px = (xb + t) * 4 + kx;
+    float v = 0.f;
+    if (py < H && px < W && xb + t < Wp) v = img[(((int64_t)b * 3 + ch) * H + py) * W + px];
+    patch[idx] = v;
+  }
+  __syncthreads();
+  if (tid < E) {
+    float wr[48];
+#pragma unroll
+    for (int i = 0; i < 48; i += 4) {
+      f32x4 t4 = *reinterpret_cast<const f32x4*>(w + tid * 48 + i);
+      wr[i] = t4[0]; wr[i + 1] = t4[1]; wr[i + 2] = t4[2]; wr[i + 3] = t4[3];
+    }
+    const float bv = bias[tid];
+#pragma unroll
+    for (int t = 0; t < PE_TOK; ++t) {
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < 48; ++e) a = fmaf(wr[e], patch[t * 48 + e], a);
+      vals[t * E + tid] = a + bv;
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  for (int t = wave; t < PE_TOK; t += nw) {
+    if (xb + t >= Wp) continue;
+    float s = 0.f;
+    for (int c = lane; c < E; c += 64) s += vals[t * E + c];
+    s = wave_sum(s);
+    const float mean = s / (float)E;
+    float q = 0.f;
+    for (int c = lane; c < E; c += 64) { float d = vals[t * E + c] - mean; q += d * d; }
+    q = wave_sum(q);
+    const float rstd = 1.0f / sqrtf(q / (float)E + eps);
+    TO* o = out + (((int64_t)b * Hp + ty) * Wp + xb + t) * E;
+    for (int c = lane; c < E; c += 64) o[c] = from_f32<TO>((vals[t * E + c] - mean) * rstd * g[c] + be[c]);
+  }
+}
+
+}  // namespace
+
+extern "C" int omp_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
+                             int y_dtype, float* y_f32, int64_t rows, int C, float eps, omp_stream_t s) {
+  OMP_CHECK_ARG(x && gamma && beta && (y || y_f32), "omp_layernorm: null pointer");
+  OMP_CHECK_ARG(rows > 0 && C > 0, "omp_layernorm: bad shape rows=%lld C=%d", (long long)rows, C);
+  LnP p{};
+  p.x = x; p.g = gamma; p.b = beta; p.y = y; p.yf = y_f32; p.rows = rows; p.C = C; p.eps = eps;
+  p.gather = 0;
+  if (y == nullptr) y_dtype = OMP_F32;
+  return dispatch_ln(p, x_dtype, y_dtype, (hipStream_t)s, "omp_layernorm");
+}
+
+extern "C" int omp_patch_merge_gather_ln(const void* x, const float* gamma, const float* beta, void* y,
+                                         int dtype, int B, int H, int W, int C, float eps,
+                                         omp_stream_t s) {
+  OMP_CHECK_ARG(x && gamma && beta && y, "omp_patch_merge_gather_ln: null pointer");
+  OMP_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0, "omp_patch_merge_gather_ln: bad shape");
+  LnP p{};
+  p.x = x; p.g = gamma; p.b = beta; p.y = y; p.yf = nullptr; p.eps = eps;
+  p.gather = 1; p.H = H; p.W = W; p.Cin = C; p.H2 = (H + 1) / 2; p.W2 = (W + 1) / 2;
+  p.rows = (int64_t)B * p.H2 * p.W2; p.C = 4 * C;
+  const int nv = dtype == OMP_F32 ? 4 : 8;
+  OMP_CHECK_ARG(C % nv == 0, "omp_patch_merge_gather_ln: C=%d must be a multiple of %d", C, nv);
+  return dispatch_ln(p, dtype, dtype, (hipStream_t)s, "omp_patch_merge_gather_ln");
+}
+
+extern "C" int omp_patch_embed_ln(const float* img, const float* w, const float* b, const float* gamma,
+                                  const float* beta, void* out, int out_dtype, int B, int H, int W, int E,
+                                  float eps, omp_stream_t s) {
+  OMP_CHECK_ARG(img && w && b && gamma && beta && out, "omp_patch_embed_ln: null pointer");
+  OMP_CHECK_ARG(B > 0 && H > 0 && W > 0 && E > 0 && E <= 1024, "omp_patch_embed_ln: bad shape");
+  const int Hp = (H + 3) / 4, Wp = (W + 3) / 4;
+  const int nthr = ((E + 63) / 64) * 64;
+  dim3 grid((Wp + PE_TOK - 1) / PE_TOK, Hp, B);
+  const size_t smem = (PE_TOK * 48 + PE_TOK * E) * sizeof(float);
+  if (out_dtype == OMP_F32)
+    hipLaunchKernelGGL((patch_embed_kernel<float>), grid, dim3(nthr), smem, (hipStream_t)s, img, w, b,
+                       gamma, beta, (float*)out, B, H, W, Hp, Wp, E, eps);
+  else if (out_dtype == OMP_BF16)
+    hipLaunchKernelGGL((patch_embed_kernel<bf16_t>), grid, dim3(nthr), smem, (hipStream_t)s, img, w, b,
+                       gamma, beta, (bf16_t*)out, B, H, W, Hp, Wp, E, eps);
+  else { omp_set_error("omp_patch_embed_ln: bad dtype %d", out_dtype); return OMP_ERR_INVALID; }
+  OMP_CHECK_LAUNCH("omp_patch_embed_ln");
+  return OMP_OK;
+}

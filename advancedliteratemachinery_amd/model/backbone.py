@@ -1,0 +1,144 @@
+"""Swin-B backbone + FPN + input projection on libomp355 (the `encode` half of the hot path).
+
+Host-side driver only: every tensor op is a libomp355 kernel (ops.py); the launches are large
+(token-level GEMMs, fused window attention, LayerNorm) so Python-side sequencing stays far ahead
+of the GPU.  Mirrors, stage by stage, SwinTransformer.forward (reference
+model/backbone/swin_transformer.py:597-625), Joiner/PositionEmbeddingSine
+(backbone/joiner.py:10-18, position_embedding.py:24-44), FPN.forward (model/fpn.py:21-45) and the
+input_proj call of OmniParser.forward (model/omniparser.py:19-31).
+
+Layout: activations stay token-major [B*H*W, C] in the engine dtype for the whole backbone -- the
+reference's NCHW permutes, window partition/reverse copies, rolls and pads never materialise.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+
+LN_EPS = 1e-5
+
+
+class _Block(object):
+    __slots__ = ('n1g', 'n1b', 'qkv_w', 'qkv_b', 'table', 'proj_w', 'proj_b', 'n2g', 'n2b', 'fc1_w',
+                 'fc1_b', 'fc2_w', 'fc2_b', 'shift')
+
+
+class _Stage(object):
+    __slots__ = ('C', 'nH', 'blocks', 'down_g', 'down_b', 'down_w', 'out_g', 'out_b')
+
+
+class Encoder(object):
+    """Packs the backbone/FPN/input_proj weights once (matrices -> engine dtype, vectors stay fp32)
+    and runs images -> (memory, memory+pos, key padding mask)."""
+
+    def __init__(self, sd, args, swin_cfg, dtype):
+        self.dtype = dtype
+        self.args = args
+        self.window = swin_cfg['window']
+        self.embed_dim = swin_cfg['embed_dim']
+        f32 = lambda k: sd[k].detach().float().contiguous()          # noqa: E731
+        mat = lambda k: sd[k].detach().to(dtype).contiguous()        # noqa: E731
+        bb = 'backbone.0.'
+        self.pe_w = f32(bb + 'patch_embed.proj.weight').reshape(self.embed_dim, 48).contiguous()
+        self.pe_b = f32(bb + 'patch_embed.proj.bias')
+        self.pe_g = f32(bb + 'patch_embed.norm.weight')
+        self.pe_bt = f32(bb + 'patch_embed.norm.bias')
+        self.stages = []
+        depths, heads = swin_cfg['depths'], swin_cfg['num_heads']
+        for s, (dep, nh) in enumerate(zip(depths, heads)):
+            st = _Stage()
+            st.C, st.nH, st.blocks = self.embed_dim << s, nh, []
+            if st.C != nh * 32:
+                raise ValueError('libomp355 window attention is built for head_dim 32 (C=%d, heads=%d)' % (st.C, nh))
+            for b in range(dep):
+                p = '%slayers.%d.blocks.%d.' % (bb, s, b)
+                blk = _Block()
+                blk.n1g, blk.n1b = f32(p + 'norm1.weight'), f32(p + 'norm1.bias')
+                blk.qkv_w, blk.qkv_b = mat(p + 'attn.qkv.weight'), f32(p + 'attn.qkv.bias')
+                blk.table = f32(p + 'attn.relative_position_bias_table')
+                blk.proj_w, blk.proj_b = mat(p + 'attn.proj.weight'), f32(p + 'attn.proj.bias')
+                blk.n2g, blk.n2b = f32(p + 'norm2.weight'), f32(p + 'norm2.bias')
+                blk.fc1_w, blk.fc1_b = mat(p + 'mlp.fc1.weight'), f32(p + 'mlp.fc1.bias')
+                blk.fc2_w, blk.fc2_b = mat(p + 'mlp.fc2.weight'), f32(p + 'mlp.fc2.bias')
+                blk.shift = 0 if b % 2 == 0 else self.window // 2
+                st.blocks.append(blk)
+            if s + 1 < len(depths):
+                p = '%slayers.%d.downsample.' % (bb, s)
+                st.down_g, st.down_b = f32(p + 'norm.weight'), f32(p + 'norm.bias')
+                st.down_w = mat(p + 'reduction.weight')
+            else:
+                st.down_g = st.down_b = st.down_w = None
+            st.out_g, st.out_b = f32('%snorm%d.weight' % (bb, s)), f32('%snorm%d.bias' % (bb, s))
+            self.stages.append(st)
+        self.use_fpn = bool(args.use_fpn)
+        if self.use_fpn:
+            if len(self.stages) != 4:
+                raise ValueError('FPN needs 4 backbone stages')
+            # fpn_in[0] consumes c5 ... fpn_in[3] consumes c2 (reference fpn.py:18-19)
+            self.fpn_w = [mat('fpn.fpn_in.%d.weight' % i).reshape(256, -1).contiguous() for i in range(4)]
+        self.proj_w = mat('input_proj.weight').reshape(args.tfm_hidden_dim, -1).contiguous()
+        self.proj_b = f32('input_proj.bias')
+
+    # -- Swin ---------------------------------------------------------------------------------
+    def backbone(self, img):
+        """img [B,3,H,W] fp32 -> list of (normed map [B*h*w, C], h, w) per stage."""
+        B = img.shape[0]
+        x, H, W = ops.patch_embed_ln(img, self.pe_w, self.pe_b, self.pe_g, self.pe_bt, self.dtype, LN_EPS)
+        x = x.view(B * H * W, self.embed_dim)
+        outs = []
+        for si, st in enumerate(self.stages):
+            C = st.C
+            for blk in st.blocks:
+                y = ops.layernorm(x, blk.n1g, blk.n1b, eps=LN_EPS)
+                qkv = ops.gemm(y, blk.qkv_w, blk.qkv_b)
+                att = ops.swin_window_attn(qkv, blk.qkv_b, blk.table, B, H, W, C, st.nH, blk.shift, out=y,
+                                           window=self.window)
+                ops.gemm(att, blk.proj_w, blk.proj_b, residual=x, out=x)
+                y = ops.layernorm(x, blk.n2g, blk.n2b, out=y, eps=LN_EPS)
+                h = ops.gemm(y, blk.fc1_w, blk.fc1_b, act=ops.ACT_GELU)
+                ops.gemm(h, blk.fc2_w, blk.fc2_b, residual=x, out=x)
+            outs.append((ops.layernorm(x, st.out_g, st.out_b, eps=LN_EPS), H, W))
+            if st.down_w is not None:
+                y, H2, W2 = ops.patch_merge_gather_ln(x, st.down_g, st.down_b, B, H, W, C, LN_EPS)
+                x = ops.gemm(y, st.down_w)
+                H, W = H2, W2
+        return outs
+
+    @staticmethod
+    def level_mask(mask, h, w):
+        """Padding mask at a feature level: nearest resize exactly as swin_transformer.py:621."""
+        return F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]
+
+    # -- full encode ----------------------------------------------------------------------------
+    def encode(self, img, mask, want_intermediates=False):
+        """-> dict(memory [B*M,d], mem_pos [B*M,d], key_mask uint8 [B,M] or None, M, hw)."""
+        B = img.shape[0]
+        feats = self.backbone(img)
+        if self.use_fpn:
+            (c2, h2, w2), (c3, h3, w3), (c4, h4, w4), (c5, h5, w5) = feats
+            l5 = ops.gemm(c5, self.fpn_w[0])
+            l4 = ops.gemm(c4, self.fpn_w[1])
+            l3 = ops.gemm(c3, self.fpn_w[2])
+            l2 = ops.gemm(c2, self.fpn_w[3])
+            sizes = ((h2, w2), (h3, w3), (h4, w4), (h5, w5))
+            src, ho, wo = ops.fpn_fuse(l2, l3, l4, l5, B, sizes, 2)
+            lvl = (h4, w4)
+            if (ho, wo) != lvl:
+                raise RuntimeError('stride-2 projection grid %s != stage-2 grid %s' % ((ho, wo), lvl))
+        else:
+            src, ho, wo = feats[-1]
+            lvl = (ho, wo)
+        lm = self.level_mask(mask, *lvl)
+        pos = ops.sine_posembed(lm.to(torch.uint8).contiguous(), self.args.tfm_hidden_dim // 2, self.dtype)
+        M = ho * wo
+        pos = pos.view(B * M, -1)
+        memory = ops.gemm(src, self.proj_w, self.proj_b)
+        mem_pos = ops.gemm(src, self.proj_w, self.proj_b, residual=pos)
+        out = dict(memory=memory, mem_pos=mem_pos, M=M, hw=(ho, wo), pos=pos,
+                   key_mask=lm.reshape(B, M).to(torch.uint8).contiguous())
+        if want_intermediates:
+            out['feats'] = feats
+            out['src'] = src
+            if self.use_fpn:
+                out['src_full'] = ops.fpn_fuse(l2, l3, l4, l5, B, sizes, 1)[0]
+        return out

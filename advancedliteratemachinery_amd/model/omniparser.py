@@ -1,0 +1,188 @@
+"""OmniParser: drop-in for the reference model class on the inference path.
+
+Same constructor-by-args, same state-dict layout, same `forward(samples, sequence)` contract as
+OCR/OmniParser/model/omniparser.py:7-32 (eval mode), with the computation executed by
+libomp355 (hand-written gfx950 kernels).  Additions over the reference:
+  * batches of B > 1 images (the reference asserts B == 1, engine/val.py:22): every image is
+    decoded exactly as if it had been submitted alone; `forward` then returns a list of B results;
+  * `forced_instances`: fixed-length decoding for throughput measurement with random weights.
+
+Return value per image (reference transformer.py:240-246,286):
+  text spotting : ([pt (1,2N), poly (1,32N), rec (1,N,rec_length)] int64, [probs (N,rec_length)])
+  KIE           : list of (text, class_name, prob, [rects])
+  no points     : None
+"""
+import torch
+import torch.nn as nn
+
+from ..utils.nested_tensor import NestedTensor
+from . import params
+from .backbone import Encoder
+from .transformer import Decoder, index2class
+
+_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32, torch.bfloat16: torch.bfloat16,
+           torch.float32: torch.float32}
+
+
+def _image_sizes(sizes, B):
+    """orig_size of seqs[3] (engine/val.py:33): a (2,) tensor, a (B,2) tensor or a list of B of them."""
+    if isinstance(sizes, (list, tuple)) and len(sizes) == B and not isinstance(sizes[0], (int, float)):
+        t = torch.stack([torch.as_tensor(s).reshape(2) for s in sizes])
+    else:
+        t = torch.as_tensor(sizes).reshape(-1, 2)
+    if t.shape[0] == 1 and B > 1:
+        t = t.expand(B, 2)
+    return t.cpu()
+
+
+class OmniParser(nn.Module):
+    def __init__(self, args, swin_cfg=None, engine_dtype=None):
+        super().__init__()
+        self.args = args
+        self.swin_cfg = dict(params.SWIN_B)
+        self.swin_cfg.update(swin_cfg or {})
+        self.use_fpn = bool(args.use_fpn)
+        self.engine_dtype = _DTYPES[engine_dtype or getattr(args, 'engine_dtype', 'bf16')]
+        spec = params.expected_state_dict(args, self.swin_cfg)
+        shared = [['transformer.%s_decoder.norm.%s' % (k, leaf) for k in ('pt', 'poly', 'rec')]
+                  for leaf in ('weight', 'bias')]
+        params.attach_parameters(self, spec, shared)
+        self._engine = None
+        self._engine_key = None
+        self.use_graph = False
+        self.eval()
+
+    # -- engine lifecycle -------------------------------------------------------------------------
+    def _key(self):
+        ps = list(self.parameters())
+        return (ps[0].device, self.engine_dtype, sum(p._version for p in ps), id(ps[0]))
+
+    def engine(self):
+        """(Encoder, Decoder) packed from the CURRENT parameters; rebuilt after load_state_dict/.to()."""
+        key = self._key()
+        if self._engine is None or key != self._engine_key:
+            dev = key[0]
+            if dev.type != 'cuda':
+                raise RuntimeError('OmniParser runs on MI355X only: move the model to a cuda (HIP) device; '
+                                   'there is no CPU fallback')
+            sd = {k: v for k, v in self.state_dict().items()}
+            with torch.cuda.device(dev):
+                enc = Encoder(sd, self.args, self.swin_cfg, self.engine_dtype)
+                dec = Decoder(sd, self.args, self.engine_dtype, dev)
+            self._engine, self._engine_key = (enc, dec), key
+        self._engine[1].use_graph = self.use_graph
+        return self._engine
+
+    def set_engine_dtype(self, dtype):
+        self.engine_dtype = _DTYPES[dtype]
+        self._engine = None
+
+    # -- reference-compatible forward -------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, samples, sequence, forced_instances=None):
+        if self.training:
+            raise NotImplementedError('training is out of scope for the MI355X inference engine')
+        if not isinstance(samples, NestedTensor) and hasattr(samples, 'tensors'):
+            samples = NestedTensor(samples.tensors, samples.mask)
+        img, mask = samples.tensors, samples.mask
+        if mask is None:
+            mask = torch.zeros(img.shape[0], img.shape[2], img.shape[3], dtype=torch.bool, device=img.device)
+        results = self.infer(img, mask, sequence, forced_instances=forced_instances)
+        return results[0] if img.shape[0] == 1 else results
+
+    # -- batched inference ------------------------------------------------------------------------
+    @torch.no_grad()
+    def infer(self, img, mask, sequence, forced_instances=None, has_padding=None):
+        enc, dec = self.engine()
+        a = self.args
+        dev = img.device
+        B = img.shape[0]
+        with torch.cuda.device(dev):
+            img = img.float().contiguous()
+            if has_padding is None:
+                has_padding = bool(mask.any())
+            e = enc.encode(img, mask)
+            kv = dec.project_memory(e['memory'], e['mem_pos'], B, e['M'], e['key_mask'] if has_padding else None)
+            prompt = [int(t) for t in sequence[0].reshape(-1).tolist()]
+            poly_sos = int(sequence[1].reshape(-1)[0])
+            rec_sos = int(sequence[2].reshape(-1)[0])
+            pts = dec.decode_points(kv, prompt, forced_instances=forced_instances)
+            if a.infer_vie:
+                sizes = sequence[3]
+                return self._kie(dec, kv, pts, poly_sos, rec_sos, sizes, B)
+            counts = [int(ids.numel()) // 2 for ids, _ in pts]
+            R = sum(counts)
+            if R == 0:
+                return [None] * B
+            points = torch.cat([ids.reshape(-1, 2) for ids, _ in pts], 0).to(dev, torch.int32)
+            poly, _ = dec.decode_instances('poly', kv, points, counts, poly_sos, 32)
+            rec, rprob = dec.decode_instances('rec', kv, points, counts, rec_sos, a.rec_length)
+            poly, rec, rprob = poly.long(), rec.long(), rprob.clone()
+            out, r0 = [], 0
+            for b in range(B):
+                n = counts[b]
+                if n == 0:
+                    out.append(None)
+                    continue
+                sl = slice(r0, r0 + n)
+                out.append(([points[sl].long().reshape(1, -1), poly[sl].reshape(1, -1), rec[sl].unsqueeze(0)],
+                            [rprob[sl]]))
+                r0 += n
+            return out
+
+    # -- KIE assembly (reference transformer.py:143-217) --------------------------------------------------
+    def _kie(self, dec, kv, pts, poly_sos, rec_sos, sizes, B):
+        a = self.args
+        nb = a.num_bins
+        events, words, counts = [], [], []
+        for b in range(B):
+            ids = pts[b][0].tolist()
+            ev, n, i, cnt = [], len(ids), 0, 0
+            while i < n:
+                if ids[i] < nb:
+                    if i + 1 <= n - 1 and ids[i + 1] < nb:
+                        ev.append(('word', len(words)))
+                        words.append((ids[i], ids[i + 1]))
+                        cnt += 1
+                        i += 2
+                    else:
+                        i += 1
+                else:
+                    ev.append(('class', i))
+                    i += 1
+            events.append(ev)
+            counts.append(cnt)
+        poly = rec = None
+        if words:
+            points = torch.tensor(words, dtype=torch.int32, device=kv['K'].device)
+            poly, _ = dec.decode_instances('poly', kv, points, counts, poly_sos, 32, infer_vie=True)
+            rec, _ = dec.decode_instances('rec', kv, points, counts, rec_sos, a.rec_length, infer_vie=True)
+            poly, rec = poly.cpu(), rec.cpu()
+        i2c = index2class(a)
+        sizes = _image_sizes(sizes, B)
+        out = []
+        for b in range(B):
+            ids, probs = pts[b][0].tolist(), pts[b][1].tolist()
+            if len(ids) == 0:
+                out.append(None)
+                continue
+            ih, iw = sizes[b][0].item(), sizes[b][1].item()
+            res, cur_words, cur_rects = [], [], []
+            for kind, v in events[b]:
+                if kind == 'word':
+                    pp = poly[v].reshape(-1, 2)
+                    cur_rects.append([iw * pp[:, 0].min().item() / nb, ih * pp[:, 1].min().item() / nb,
+                                      iw * pp[:, 0].max().item() / nb, ih * pp[:, 1].max().item() / nb])
+                    chars = []
+                    for t in rec[v].tolist():
+                        if t == a.recog_pad_index or t == a.rec_eos_index:
+                            break
+                        if t == a.recog_pad_index - 1:
+                            continue
+                        chars.append(a.chars[t - nb])
+                    cur_words.append(''.join(chars))
+                else:
+                    res.append((' '.join(cur_words), i2c[ids[v]], probs[v], cur_rects))
+                    cur_words, cur_rects = [], []
+            out.append(res)
+        return out

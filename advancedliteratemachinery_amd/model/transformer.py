@@ -1,0 +1,284 @@
+"""Point-conditioned autoregressive decoders on libomp355 (the `decode` half of the hot path).
+
+Host-side mirror of the reference's Transformer (OCR/OmniParser/model/transformer.py):
+  * `decode_points`     <-> decode_pt_seq            (:102-141)
+  * `decode_instances`  <-> the poly / rec loops     (:252-284) and the per-word loops of
+                            decode_vie_pt_poly_rec_seq (:150-183)
+  * `assemble_kie`      <-> the walk over (x, y, class) triplets (:143-217)
+with the per-step math executed by omp_decoder_run (csrc/decoder.hip): KV-cached, memory K/V
+computed once per image and shared by all of its text instances, all images of a batch and all
+instances decoded in lock-step.  The host touches the device once per `poll` steps (EOS flags of
+the point decoder) and once per phase (results).
+"""
+import ctypes
+
+import torch
+
+from .. import _lib, ops
+
+KINDS = ('pt', 'poly', 'rec')
+KIND_ID = {'pt': _lib.DEC_PT, 'poly': _lib.DEC_POLY, 'rec': _lib.DEC_REC}
+LN_EPS = 1e-5
+
+CORD_CLASSES = ['menu.cnt', 'menu.discountprice', 'menu.etc', 'menu.itemsubtotal', 'menu.nm',
+                'menu.num', 'menu.price', 'menu.sub.cnt', 'menu.sub.nm', 'menu.sub.price',
+                'menu.sub.unitprice', 'menu.unitprice', 'menu.vatyn', 'sub_total.discount_price',
+                'sub_total.etc', 'sub_total.othersvc_price', 'sub_total.service_price',
+                'sub_total.subtotal_price', 'sub_total.tax_price', 'total.cashprice',
+                'total.changeprice', 'total.creditcardprice', 'total.emoneyprice',
+                'total.menuqty_cnt', 'total.menutype_cnt', 'total.total_etc', 'total.total_price',
+                'void_menu.nm', 'void_menu.price']
+SROIE_CLASSES = ['company', 'address', 'date', 'total']
+
+
+def index2class(args):
+    """Class-token -> name table of the reference (transformer.py:49-67, utils/misc.py:6-43)."""
+    names = None
+    if args.val_dataset:
+        if 'cord' in args.val_dataset[0]:
+            names = CORD_CLASSES
+        elif 'sroie' in args.val_dataset[0]:
+            names = SROIE_CLASSES
+    return {} if names is None else {args.padding_index + 1 + i: n for i, n in enumerate(names)}
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class _Phase(object):
+    """Device state + ctypes plan of one decoder kind for R rows (buffers are reused across calls
+    so that pointers stay stable and captured graphs remain valid)."""
+
+    def __init__(self, dec, kind, R, Lmax, seq_ld, n_split):
+        dev, T, d, ff, V, nH, L = dec.device, dec.dtype, dec.d, dec.ff, dec.V, dec.nH, dec.L
+        self.kind, self.R, self.Lmax, self.seq_ld, self.n_split = kind, R, Lmax, seq_ld, n_split
+        z = lambda *s, dtype=torch.int32: torch.zeros(s, dtype=dtype, device=dev)  # noqa: E731
+        e = lambda *s, dtype=T: torch.empty(s, dtype=dtype, device=dev)             # noqa: E731
+        self.seq, self.probs = z(R, seq_ld), z(R, seq_ld, dtype=torch.float32)
+        self.finished, self.lengths, self.d_pos = z(R), z(R), z(1)
+        self.tiles = z(R + 64, 3)
+        self.x, self.x2 = e(R, d, dtype=torch.float32), e(R, d, dtype=torch.float32)
+        self.y, self.att, self.q, self.hh0, self.hh1 = e(R, d), e(R, d), e(R, d), e(R, d), e(R, d)
+        self.qkv, self.ffh = e(R, 3 * d), e(R, ff)
+        self.logits = e(R, V, dtype=torch.float32)
+        self.partial = e(R, nH, n_split, 66, dtype=torch.float32)
+        self.kc = [e(R, Lmax, d) for _ in range(L)]
+        self.vc = [e(R, Lmax, d) for _ in range(L)]
+        self.plan = _lib.DecoderPlan()
+        self.n_tiles = 0
+
+
+class Decoder(object):
+    def __init__(self, sd, args, dtype, device):
+        self.args, self.dtype, self.device = args, dtype, device
+        self.d, self.nH, self.L = args.tfm_hidden_dim, args.tfm_nheads, args.tfm_dec_layers
+        self.ff, self.V = args.tfm_dim_feedforward, args.num_classes
+        if self.d != self.nH * 64:
+            raise ValueError('libomp355 decoder kernels are built for head_dim 64')
+        if self.L > _lib.MAX_DEC_LAYERS:
+            raise ValueError('too many decoder layers')
+        self.use_graph = False
+        self._graph_slots = {}
+        self._phases = {}
+        self._kv = {}
+        d = self.d
+        f32 = lambda k: sd[k].detach().float().contiguous()      # noqa: E731
+        mat = lambda t: t.detach().to(dtype).contiguous()        # noqa: E731
+        tr = 'transformer.'
+        self.word = f32(tr + 'embedding.word_embeddings.weight')
+        self.emb_g, self.emb_b = f32(tr + 'embedding.LayerNorm.weight'), f32(tr + 'embedding.LayerNorm.bias')
+        self.pos_tab, self.layers, self.fn, self.head = {}, {}, {}, {}
+        wk, bk, wv, bv = [], [], [], []
+        for kind in KINDS:
+            pos = f32('%sembedding.%s_position_embeddings.weight' % (tr, kind))
+            self.pos_tab[kind] = pos
+            layers = []
+            for l in range(self.L):
+                p = '%s%s_decoder.layers.%d.' % (tr, kind, l)
+                w = {}
+                in_w, in_b = f32(p + 'self_attn.in_proj_weight'), f32(p + 'self_attn.in_proj_bias')
+                w['sa_in_w'] = mat(in_w)
+                # (y + qpos) Wq^T + bq == y Wq^T + (qpos Wq^T + bq): fold the position term into a
+                # per-position bias table (fp32 GEMM on the fp32 master weights); v takes no qpos.
+                qk = ops.gemm(pos, in_w[:2 * d].contiguous(), in_b[:2 * d].contiguous())
+                w['sa_bias_tab'] = torch.cat([qk, in_b[2 * d:].expand(pos.shape[0], d)], dim=1).contiguous()
+                w['sa_out_w'], w['sa_out_b'] = mat(f32(p + 'self_attn.out_proj.weight')), f32(p + 'self_attn.out_proj.bias')
+                cw, cb = f32(p + 'multihead_attn.in_proj_weight'), f32(p + 'multihead_attn.in_proj_bias')
+                w['ca_q_w'] = mat(cw[:d])
+                w['ca_qbias_tab'] = ops.gemm(pos, cw[:d].contiguous(), cb[:d].contiguous())
+                wk.append(cw[d:2 * d]); bk.append(cb[d:2 * d]); wv.append(cw[2 * d:]); bv.append(cb[2 * d:])
+                w['ca_out_w'], w['ca_out_b'] = mat(f32(p + 'multihead_attn.out_proj.weight')), f32(p + 'multihead_attn.out_proj.bias')
+                w['ff1_w'], w['ff1_b'] = mat(f32(p + 'linear1.weight')), f32(p + 'linear1.bias')
+                w['ff2_w'], w['ff2_b'] = mat(f32(p + 'linear2.weight')), f32(p + 'linear2.bias')
+                for n in ('1', '2', '3'):
+                    w['n%s_g' % n], w['n%s_b' % n] = f32(p + 'norm%s.weight' % n), f32(p + 'norm%s.bias' % n)
+                layers.append(w)
+            self.layers[kind] = layers
+            self.fn[kind] = (f32('%s%s_decoder.norm.weight' % (tr, kind)), f32('%s%s_decoder.norm.bias' % (tr, kind)))
+            hp = '%s%s_pred_layer.layers.' % (tr, kind)
+            self.head[kind] = [(mat(f32(hp + '%d.weight' % i)), f32(hp + '%d.bias' % i)) for i in range(3)]
+        # one stacked projection for the memory K and V of all (decoder, layer) pairs
+        self.Wk_all, self.bk_all = mat(torch.cat(wk, 0)), torch.cat(bk, 0).contiguous()
+        self.Wv_all, self.bv_all = mat(torch.cat(wv, 0)), torch.cat(bv, 0).contiguous()
+        self.NL = len(KINDS) * self.L
+
+    # -- memory K/V: once per batch ---------------------------------------------------------------
+    def project_memory(self, memory, mem_pos, B, M, key_mask):
+        """K = (memory+pos) Wk^T + bk  [B*M, NL*d];  V^T = (memory Wv^T + bv)^T  [B, NL*d, Mpad]."""
+        Mpad = _round_up(M, 32)  # a 32-key block never runs past a V^T row
+        key = (B, M)
+        if key not in self._kv:
+            nld = self.NL * self.d
+            self._kv[key] = (torch.empty(B * M, nld, dtype=self.dtype, device=self.device),
+                             torch.zeros(B, nld, Mpad, dtype=self.dtype, device=self.device))
+        K_all, Vt_all = self._kv[key]
+        ops.gemm(mem_pos, self.Wk_all, self.bk_all, out=K_all)
+        ops.gemm(memory, self.Wv_all, self.bv_all, out=Vt_all, trans_rows=M, trans_ld=Mpad, ldc=Mpad)
+        return dict(K=K_all, Vt=Vt_all, B=B, M=M, Mpad=Mpad, key_mask=key_mask)
+
+    # -- plans --------------------------------------------------------------------------------------
+    def _phase(self, kind, R, Lmax, seq_ld, n_split):
+        key = (kind, R, Lmax, seq_ld, n_split)
+        if key not in self._phases:
+            self._phases[key] = _Phase(self, kind, R, Lmax, seq_ld, n_split)
+        return self._phases[key]
+
+    @staticmethod
+    def make_tiles(counts):
+        """rows sorted by image; tiles of <=16 consecutive rows of ONE image: (row0, nrows, image)."""
+        tiles, r0 = [], 0
+        for img, n in enumerate(counts):
+            for o in range(0, n, 16):
+                tiles.append((r0 + o, min(16, n - o), img))
+            r0 += n
+        return tiles
+
+    def _bind(self, ph, kv, tiles, n_prompt, suppress_eos, infer_vie):
+        P, a, d = ph.plan, self.args, self.d
+        esz = 4 if self.dtype == torch.float32 else 2
+        P.dtype, P.n_layers, P.d_model, P.n_heads, P.d_ff, P.vocab = ops.dt(self.dtype), self.L, d, self.nH, self.ff, self.V
+        P.pre_norm = 1 if a.tfm_pre_norm else 0
+        P.R, P.Lmax, P.M, P.n_tiles, P.n_split, P.n_prompt = ph.R, ph.Lmax, kv['M'], len(tiles), ph.n_split, n_prompt
+        P.eps = LN_EPS
+        t = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 3)
+        ph.tiles[:t.shape[0]].copy_(t.to(self.device, non_blocking=False))
+        ph.n_tiles = t.shape[0]
+        kidx = KINDS.index(ph.kind)
+        nld = self.NL * d
+        for l, w in enumerate(self.layers[ph.kind]):
+            Lc = P.layers[l]
+            for name in ('sa_in_w', 'sa_bias_tab', 'sa_out_w', 'sa_out_b', 'ca_q_w', 'ca_qbias_tab', 'ca_out_w',
+                         'ca_out_b', 'ff1_w', 'ff1_b', 'ff2_w', 'ff2_b', 'n1_g', 'n1_b', 'n2_g', 'n2_b', 'n3_g', 'n3_b'):
+                setattr(Lc, name, w[name].data_ptr())
+            Lc.kcache, Lc.vcache = ph.kc[l].data_ptr(), ph.vc[l].data_ptr()
+            off = (kidx * self.L + l) * d
+            Lc.crossK = kv['K'].data_ptr() + off * esz
+            Lc.crossVt = kv['Vt'].data_ptr() + off * kv['Mpad'] * esz
+        P.word_emb, P.pos_tab = self.word.data_ptr(), self.pos_tab[ph.kind].data_ptr()
+        P.emb_g, P.emb_b = self.emb_g.data_ptr(), self.emb_b.data_ptr()
+        P.fn_g, P.fn_b = self.fn[ph.kind][0].data_ptr(), self.fn[ph.kind][1].data_ptr()
+        (P.h0_w, P.h0_b), (P.h1_w, P.h1_b), (P.h2_w, P.h2_b) = [(w.data_ptr(), b.data_ptr()) for w, b in self.head[ph.kind]]
+        P.ldk, P.k_batch_stride = nld, kv['M'] * nld
+        P.ldvt, P.vt_batch_stride = kv['Mpad'], nld * kv['Mpad']
+        P.key_mask = kv['key_mask'].data_ptr() if kv['key_mask'] is not None else None
+        P.tiles = ph.tiles.data_ptr()
+        P.seq, P.seq_ld, P.d_pos, P.probs = ph.seq.data_ptr(), ph.seq_ld, ph.d_pos.data_ptr(), ph.probs.data_ptr()
+        P.finished, P.lengths = ph.finished.data_ptr(), ph.lengths.data_ptr()
+        for n in ('x', 'x2', 'y', 'qkv', 'att', 'q', 'ffh', 'hh0', 'hh1', 'partial', 'logits'):
+            setattr(P, n, getattr(ph, n).data_ptr())
+        s = P.sample
+        s.kind, s.num_bins, s.pt_eos, s.poly_eos, s.rec_eos = KIND_ID[ph.kind], a.num_bins, a.pt_eos_index, a.poly_eos_index, a.rec_eos_index
+        s.vocab, s.vie_categories, s.infer_vie = self.V, a.vie_categories, 1 if infer_vie else 0
+        s.suppress_eos, s.step0 = 1 if suppress_eos else 0, n_prompt
+        ph._keepalive = (kv['K'], kv['Vt'], kv['key_mask'])
+        return P
+
+    def _slot(self, plan):
+        if not self.use_graph:
+            return -1
+        key = bytes(plan)
+        if key not in self._graph_slots:
+            self._graph_slots[key] = len(self._graph_slots)
+        return self._graph_slots[key]
+
+    def _run(self, ph, first_pos, n_steps):
+        if n_steps <= 0:
+            return
+        rc = _lib.lib().omp_decoder_run(ctypes.byref(ph.plan), first_pos, n_steps, self._slot(ph.plan), ops.stream())
+        _lib.check(rc, 'omp_decoder_run')
+
+    def _n_split(self, n_tiles, M):
+        want = max(1, 1024 // max(1, n_tiles * self.nH))
+        kb = 16 if self.dtype == torch.float32 else 32
+        return max(1, min(want, (M + kb - 1) // kb, 64))
+
+    # -- greedy drivers ---------------------------------------------------------------------------
+    def decode_points(self, kv, prompt, max_new=None, forced_instances=None, poll=16):
+        """Point decoder for B images in lock-step.  Returns per image (ids list, probs list) after
+        prompt strip and the reference's tail trim (transformer.py:131-141)."""
+        a, B = self.args, kv['B']
+        n_prompt = len(prompt)
+        limit = 1024 - n_prompt + 1  # beyond this the reference indexes past its position table
+        S = min(a.pt_seq_length if max_new is None else max_new, limit)
+        suppress = forced_instances is not None
+        if suppress:
+            S = min((3 if a.infer_vie else 2) * forced_instances, limit)
+        tiles = self.make_tiles([1] * B)
+        ph = self._phase('pt', B, n_prompt - 1 + S, n_prompt + S + 1, self._n_split(len(tiles), kv['M']))
+        self._bind(ph, kv, tiles, n_prompt, suppress, a.infer_vie)
+        ph.seq.zero_(); ph.probs.zero_(); ph.finished.zero_(); ph.lengths.zero_(); ph.d_pos.zero_()
+        ph.seq[:, :n_prompt] = torch.tensor(prompt, dtype=torch.int32, device=self.device)
+        total = n_prompt - 1 + S
+        done, fin = 0, [0] * B
+        if suppress:
+            self._run(ph, 0, total)
+            done = total
+        else:
+            while done < total:
+                n = min(total - done, (n_prompt - 1 if done == 0 else 0) + poll)
+                self._run(ph, done, n)
+                done += n
+                fin = ph.finished.tolist()   # the only host sync of the point phase
+                if all(fin):
+                    break
+        seq, probs, lens = ph.seq.cpu(), ph.probs.cpu(), ph.lengths.tolist()
+        sampled = done - (n_prompt - 1)      # sampling steps executed
+        out = []
+        for b in range(B):
+            # finished rows: tokens before the EOS (reference breaks before appending it, :126-127)
+            end = lens[b] if fin[b] else n_prompt + sampled
+            ids, pr = seq[b, n_prompt:end], probs[b, n_prompt:end]
+            if ids.numel() % 2 != 0:          # reference :138-139
+                ids = ids[:-1]
+            out.append((ids, pr))
+        return out
+
+    def decode_instances(self, kind, kv, points, counts, sos, n_new, infer_vie=False):
+        """poly / rec decoding of R = sum(counts) instances (rows sorted by image).
+        points: int32 [R,2] (device).  Returns (ids [R,n_new] int32, probs [R,n_new] fp32) on device."""
+        R = int(points.shape[0])
+        tiles = self.make_tiles(counts)
+        ph = self._phase(kind, R, 2 + n_new, 3 + n_new + 1, self._n_split(len(tiles), kv['M']))
+        self._bind(ph, kv, tiles, 3, False, infer_vie)
+        ph.d_pos.zero_()
+        ph.seq[:, 0:2] = points
+        ph.seq[:, 2] = sos
+        self._run(ph, 0, 2 + n_new)
+        return ph.seq[:, 3:3 + n_new], ph.probs[:, 3:3 + n_new]
+
+    def teacher_forced_logits(self, kind, kv, seqs, counts, n_prompt, infer_vie=False):
+        """Parity helper: logits [R, L, V] of decoder `kind` fed the given token sequences."""
+        seqs = seqs.to(self.device, torch.int32)
+        R, Ls = seqs.shape
+        tiles = self.make_tiles(counts)
+        ph = self._phase(kind, R, Ls, Ls + 1, self._n_split(len(tiles), kv['M']))
+        self._bind(ph, kv, tiles, n_prompt, False, infer_vie)
+        ph.d_pos.zero_()
+        ph.seq[:, :Ls] = seqs
+        outs = []
+        for p in range(Ls):
+            rc = _lib.lib().omp_decoder_step_logits(ctypes.byref(ph.plan), p, ops.stream())
+            _lib.check(rc, 'omp_decoder_step_logits')
+            outs.append(ph.logits.clone())
+        return torch.stack(outs, dim=1)

@@ -1,0 +1,168 @@
+"""Thin tensor -> pointer wrappers over the C ABI (include/omp355.h).
+
+PyTorch is used for device memory and streams only; every computation below happens inside
+libomp355.so.  All wrappers launch on torch's CURRENT stream and never synchronise.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, OMP_BF16, OMP_F32  # noqa: F401
+
+_DT = {torch.float32: OMP_F32, torch.bfloat16: OMP_BF16}
+
+
+def dt(t):
+    try:
+        return _DT[t if isinstance(t, torch.dtype) else t.dtype]
+    except KeyError:
+        raise TypeError('libomp355 supports float32/bfloat16 tensors only, got %s' % (t,))
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('libomp355 ops need device tensors (got a CPU tensor); there is no CPU fallback')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _c(t, name):
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous' % name)
+    return t
+
+
+def layernorm(x, gamma, beta, out_dtype=None, out=None, out_f32=None, eps=1e-5, want_out=True):
+    """x [rows, C] -> LN in `out_dtype` (default x.dtype) and/or fp32 copy."""
+    _c(x, 'x')
+    rows, C = x.numel() // x.shape[-1], x.shape[-1]
+    out_dtype = out_dtype or x.dtype
+    if out is None and want_out:
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    rc = _lib.lib().omp_layernorm(ptr(x), dt(x), ptr(gamma), ptr(beta), ptr(out),
+                                  dt(out) if out is not None else OMP_F32, ptr(out_f32), rows, C,
+                                  float(eps), stream())
+    _lib.check(rc, 'omp_layernorm')
+    return out
+
+
+def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None, M=None, lda=None,
+         ldw=None, ldc=None, N=None, K=None, bias_row=None, bias_row_stride=0, trans_rows=0, trans_ld=0):
+    """out[M,N] = act(A[M,K] @ W[N,K]^T + bias) + residual.  A/W may be strided row views (lda/ldw)."""
+    K = K or A.shape[-1]
+    N = N or W.shape[0]
+    M = M or A.numel() // A.shape[-1]
+    lda = lda or A.stride(-2) if A.dim() > 1 else K
+    ldw = ldw or W.stride(0)
+    out_dtype = out_dtype or A.dtype
+    if out is None:
+        if trans_rows:
+            raise ValueError('trans_out needs a preallocated (zeroed) output')
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    ldc = ldc or (out.stride(-2) if out.dim() > 1 else N)
+    a = _lib.GemmArgs()
+    a.A, a.lda, a.W, a.ldw = ptr(A), lda, ptr(W), ldw
+    a.bias, a.bias_row, a.bias_row_stride = ptr(bias), ptr(bias_row), bias_row_stride
+    a.residual, a.ldr = ptr(residual), (residual.stride(-2) if residual is not None else 0)
+    a.C, a.ldc = ptr(out), ldc
+    a.M, a.N, a.K = M, N, K
+    a.dtype, a.out_dtype, a.act = dt(A), dt(out), act
+    a.trans_out, a.trans_rows, a.trans_ld = (1 if trans_rows else 0), trans_rows, trans_ld
+    rc = _lib.lib().omp_gemm_bias_act(ctypes.byref(a), stream())
+    _lib.check(rc, 'omp_gemm_bias_act')
+    return out
+
+
+def patch_embed_ln(img, w, b, gamma, beta, out_dtype, eps=1e-5):
+    _c(img, 'img')
+    B, _, H, W = img.shape
+    E = w.shape[0]
+    Hp, Wp = (H + 3) // 4, (W + 3) // 4
+    out = torch.empty((B, Hp * Wp, E), dtype=out_dtype, device=img.device)
+    rc = _lib.lib().omp_patch_embed_ln(ptr(img), ptr(w), ptr(b), ptr(gamma), ptr(beta), ptr(out), dt(out),
+                                       B, H, W, E, float(eps), stream())
+    _lib.check(rc, 'omp_patch_embed_ln')
+    return out, Hp, Wp
+
+
+def swin_window_attn(qkv, qkv_bias, table, B, H, W, C, nH, shift, out=None, window=7):
+    _c(qkv, 'qkv')
+    if out is None:
+        out = torch.empty((B * H * W, C), dtype=qkv.dtype, device=qkv.device)
+    rc = _lib.lib().omp_swin_window_attn(ptr(qkv), ptr(qkv_bias), ptr(table), ptr(out), dt(qkv), B, H, W, C,
+                                         nH, window, shift, stream())
+    _lib.check(rc, 'omp_swin_window_attn')
+    return out
+
+
+def patch_merge_gather_ln(x, gamma, beta, B, H, W, C, eps=1e-5):
+    _c(x, 'x')
+    H2, W2 = (H + 1) // 2, (W + 1) // 2
+    out = torch.empty((B * H2 * W2, 4 * C), dtype=x.dtype, device=x.device)
+    rc = _lib.lib().omp_patch_merge_gather_ln(ptr(x), ptr(gamma), ptr(beta), ptr(out), dt(x), B, H, W, C,
+                                              float(eps), stream())
+    _lib.check(rc, 'omp_patch_merge_gather_ln')
+    return out, H2, W2
+
+
+def fpn_fuse(l2, l3, l4, l5, B, sizes, stride):
+    (h2, w2), (h3, w3), (h4, w4), (h5, w5) = sizes
+    ho, wo = (h3 + stride - 1) // stride, (w3 + stride - 1) // stride
+    out = torch.empty((B * ho * wo, 1024), dtype=l2.dtype, device=l2.device)
+    rc = _lib.lib().omp_fpn_fuse(ptr(l2), ptr(l3), ptr(l4), ptr(l5), ptr(out), dt(l2), B, h2, w2, h3, w3,
+                                 h4, w4, h5, w5, stride, stream())
+    _lib.check(rc, 'omp_fpn_fuse')
+    return out, ho, wo
+
+
+def sine_posembed(mask_u8, npf, out_dtype, temperature=10000.0):
+    _c(mask_u8, 'mask')
+    B, h, w = mask_u8.shape
+    out = torch.empty((B, h * w, 2 * npf), dtype=out_dtype, device=mask_u8.device)
+    rc = _lib.lib().omp_sine_posembed(ptr(mask_u8), ptr(out), dt(out), B, h, w, npf, float(temperature),
+                                      stream())
+    _lib.check(rc, 'omp_sine_posembed')
+    return out
+
+
+def dec_embed_ln(seq, d_pos, word, postab, gamma, beta, x=None, y=None, eps=1e-5):
+    R, d = seq.shape[0], word.shape[1]
+    rc = _lib.lib().omp_dec_embed_ln(ptr(seq), seq.stride(0), ptr(d_pos), ptr(word), ptr(postab), ptr(gamma),
+                                     ptr(beta), ptr(x), ptr(y), dt(y) if y is not None else OMP_F32, R, d,
+                                     float(eps), stream())
+    _lib.check(rc, 'omp_dec_embed_ln')
+
+
+def dec_self_attn_step(qkv, kcache, vcache, out, d_pos, nH):
+    R, d3 = qkv.shape
+    d = d3 // 3
+    rc = _lib.lib().omp_dec_self_attn_step(ptr(qkv), ptr(kcache), ptr(vcache), ptr(out), ptr(d_pos), dt(qkv),
+                                           R, nH, d, kcache.shape[1], stream())
+    _lib.check(rc, 'omp_dec_self_attn_step')
+
+
+def dec_cross_attn_step(q, K, ldk, kbs, Vt, ldvt, vbs, key_mask, tiles, n_tiles, partial, out, M, nH, n_split):
+    R = q.shape[0]
+    rc = _lib.lib().omp_dec_cross_attn_step(ptr(q), q.stride(0), ptr(K), ldk, kbs, ptr(Vt), ldvt, vbs,
+                                            ptr(key_mask), ptr(tiles), n_tiles, R, ptr(partial), ptr(out),
+                                            out.stride(0), dt(q), M, nH, n_split, stream())
+    _lib.check(rc, 'omp_dec_cross_attn_step')
+
+
+def head_sample(logits, cfg, seq, probs, finished, lengths, d_pos, advance=True):
+    R = logits.shape[0]
+    rc = _lib.lib().omp_head_softmax_mask_argmax(ptr(logits), logits.stride(0), R, ctypes.byref(cfg), ptr(seq),
+                                                 ptr(probs), seq.stride(0), ptr(finished), ptr(lengths),
+                                                 ptr(d_pos), 1 if advance else 0, stream())
+    _lib.check(rc, 'omp_head_softmax_mask_argmax')
+
+
+def force_gemm_kernel(which):
+    """debug/testing: 0 auto, 1 tiled 128x128, 2 tiled 64x64, 3 row-streaming."""
+    _lib.check(_lib.lib().omp_debug_force_gemm_kernel(which), 'omp_debug_force_gemm_kernel')

@@ -1,0 +1,243 @@
+/* libomp355 -- MI355X (gfx950) kernels for the OmniParser inference hot path.
+ *
+ * C ABI.  The reference (AlibabaResearch/AdvancedLiterateMachinery, OCR/OmniParser) has no
+ * FFI/plugin layer: its hot path is plain nn.Module composition on ATen ops.  Each entry point
+ * below therefore names the reference *function* it replaces (paths relative to
+ * OCR/OmniParser/).  INTEGRATION.md shows the ctypes stub a maintainer would drop into the
+ * reference for each of them.
+ *
+ * Rules of the ABI
+ *   - every function returns 0 on success or a negative errno-style code; omp_last_error()
+ *     returns a thread-local description of the last failure;
+ *   - the CALLER owns every buffer (device pointers); the library never allocates device
+ *     memory, never synchronises the device and launches only on the given stream
+ *     (hipStream_t passed as void*; NULL = the null stream);
+ *   - matrices are row-major; activations are token-major [rows, channels];
+ *     weights keep the reference's nn.Linear layout [out_features, in_features];
+ *   - dtype enum: OMP_F32 / OMP_BF16 for activations+weights; biases, LayerNorm affine
+ *     parameters, embedding and bias tables are always fp32; accumulation is fp32.
+ */
+#ifndef OMP355_H
+#define OMP355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMP_ABI_VERSION 1
+#define OMP_MAX_DEC_LAYERS 8
+
+enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
+enum { OMP_F32 = 0, OMP_BF16 = 1 };
+enum { OMP_ACT_NONE = 0, OMP_ACT_GELU = 1, OMP_ACT_RELU = 2 };
+/* decoder kinds (reference: model/transformer.py:26-33 pt/poly/rec decoders) */
+enum { OMP_DEC_PT = 0, OMP_DEC_POLY = 1, OMP_DEC_REC = 2 };
+
+typedef void* omp_stream_t; /* hipStream_t */
+
+const char* omp_last_error(void);
+int omp_abi_version(void);
+
+/* ---- LayerNorm ---------------------------------------------------------------------------
+ * y = (x - mean) / sqrt(var + eps) * gamma + beta over the last dim (biased variance).
+ * Replaces nn.LayerNorm call sites: swin_transformer.py:208,250,288,441,616 and
+ * transformer.py:326,374,437,441,450.  Writes y (dtype y_dtype, may be NULL) and/or y_f32. */
+int omp_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
+                  int y_dtype, float* y_f32, int64_t rows, int C, float eps, omp_stream_t s);
+
+/* ---- GEMM with fused epilogue ---------------------------------------------------------------
+ * C[m,n] = act(sum_k A[m,k] * W[n,k] + bias[n]) + residual[m,n]
+ * Replaces nn.Linear / 1x1 nn.Conv2d call sites: swin_transformer.py:127,148 (qkv, proj),
+ * :31-34 (Mlp fc1+GELU, fc2), :294 (PatchMerging.reduction), fpn.py:24-36 (fpn_in 1x1 convs),
+ * omniparser.py:31 (input_proj), transformer.py:448 (linear1/2) and the in/out projections of
+ * nn.MultiheadAttention (transformer.py:386-387), block/mlp.py:11-13 (prediction heads).
+ * bias_row (device int32, optional) selects row *bias_row of a [rows, bias_row_stride] bias table
+ * (used for the per-position query/key bias of the decoders).
+ * trans_out: store C transposed per batch of `trans_rows` consecutive rows:
+ *   C[(m / trans_rows) * N * trans_ld + n * trans_ld + (m % trans_rows)]   (ldc ignored). */
+typedef struct {
+  const void* A;
+  int64_t lda;
+  const void* W;
+  int64_t ldw;
+  const float* bias;
+  const int32_t* bias_row;
+  int64_t bias_row_stride;
+  const void* residual;
+  int64_t ldr;
+  void* C;
+  int64_t ldc;
+  int64_t M;
+  int32_t N;
+  int32_t K;
+  int32_t dtype;     /* of A and W */
+  int32_t out_dtype; /* of C and residual: dtype or OMP_F32 */
+  int32_t act;
+  int32_t trans_out;
+  int64_t trans_rows; /* rows (tokens) per batch item */
+  int64_t trans_ld;   /* pitch of a transposed row, >= trans_rows */
+} omp_gemm_args;
+int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s);
+
+/* ---- Swin patch embedding: zero-pad to x4, 4x4/4 conv (as K=48 dot products), LayerNorm -----
+ * Replaces PatchEmbed.forward, swin_transformer.py:427-443.  img is NCHW fp32 (as the reference
+ * feeds it); w is the conv weight [E,3,4,4] fp32; out is [B, ceil(H/4)*ceil(W/4), E]. */
+int omp_patch_embed_ln(const float* img, const float* w, const float* b, const float* gamma,
+                       const float* beta, void* out, int out_dtype, int B, int H, int W, int E,
+                       float eps, omp_stream_t s);
+
+/* ---- Fused (shifted-)window attention core -------------------------------------------------------
+ * Replaces everything between the qkv and proj Linears of one SwinTransformerBlock:
+ * F.pad to x7 (after norm1 => padded tokens carry bias-only q/k/v), torch.roll, window_partition,
+ * q*scale, q@k^T + relative_position_bias (+ SW-MSA mask, -100), softmax, @v, window_reverse,
+ * roll back, crop.  swin_transformer.py:209-244 + :129-147 + mask construction :369-387.
+ * qkv: [B*H*W, 3C] (q|k|v, heads contiguous, head_dim 32); qkv_bias fp32 [3C];
+ * rel_bias_table fp32 [(2*7-1)^2, nH]; out: [B*H*W, C].  shift = 0 or 3. */
+int omp_swin_window_attn(const void* qkv, const float* qkv_bias, const float* rel_bias_table,
+                         void* out, int dtype, int B, int H, int W, int C, int nH, int window,
+                         int shift, omp_stream_t s);
+
+/* ---- PatchMerging gather + LayerNorm(4C) ------------------------------------------------------------
+ * Replaces swin_transformer.py:281-293 (pad to even, 2x2 gather in order (0,0),(1,0),(0,1),(1,1),
+ * LN).  x: [B,H,W,C] -> y: [B, ceil(H/2)*ceil(W/2), 4C]; the 4C->2C reduction is a GEMM. */
+int omp_patch_merge_gather_ln(const void* x, const float* gamma, const float* beta, void* y,
+                              int dtype, int B, int H, int W, int C, float eps, omp_stream_t s);
+
+/* ---- FPN top-down + resample + concat, evaluated only where input_proj samples it -------------
+ * Replaces fpn.py:25-44 (nearest top-down adds, bilinear resample of p2/p4/p5 to c3's grid,
+ * concat) fused with the stride-`stride` sampling of omniparser.py:15,31.  l2..l5 are the four
+ * lateral 1x1-conv outputs (token-major, 256 channels); out: [B, ceil(h3/stride)*ceil(w3/stride),
+ * 1024] ordered (p2,p3,p4,p5). */
+int omp_fpn_fuse(const void* l2, const void* l3, const void* l4, const void* l5, void* out,
+                 int dtype, int B, int h2, int w2, int h3, int w3, int h4, int w4, int h5, int w5,
+                 int stride, omp_stream_t s);
+
+/* ---- Sine position embedding ---------------------------------------------------------------------
+ * Replaces PositionEmbeddingSine.forward (normalize=True), backbone/position_embedding.py:24-44.
+ * mask: [B,h,w] uint8 (1 = padding); pos: [B, h*w, 2*npf] token-major, (y feats | x feats). */
+int omp_sine_posembed(const uint8_t* mask, void* pos, int dtype, int B, int h, int w, int npf,
+                      float temperature, omp_stream_t s);
+
+/* ---- Decoder step pieces (KV-cached restatement of transformer.py:74-100,430-454) -----------------
+ * All rows of a phase sit at the same sequence position *d_pos (device int32). */
+
+/* x = LN(word_emb[seq[r, *d_pos]] + pos_tab[*d_pos]); writes fp32 x and/or y (dtype).
+ * Replaces DecoderEmbeddings.forward, transformer.py:302-328. */
+int omp_dec_embed_ln(const int32_t* seq, int seq_ld, const int32_t* d_pos, const float* word_emb,
+                     const float* pos_tab, const float* gamma, const float* beta, float* x, void* y,
+                     int y_dtype, int R, int d, float eps, omp_stream_t s);
+
+/* Append this step's k,v (from qkv [R,3d]) to the caches [R,Lmax,d] at *d_pos and attend the new
+ * query over positions 0..*d_pos (causal self-attention with KV cache; head_dim = d/nH = 64).
+ * Replaces self_attn of transformer.py:412-414/:438-440 + generate_square_subsequent_mask. */
+int omp_dec_self_attn_step(const void* qkv, void* kcache, void* vcache, void* out,
+                           const int32_t* d_pos, int dtype, int R, int nH, int d, int Lmax,
+                           omp_stream_t s);
+
+/* Cross attention of R query rows over per-image memory K [B][M][ldk] / V^T [B][d][M]; rows are
+ * grouped in tiles of <=16 consecutive rows of one image: tiles[t] = {row0, nrows, image}.
+ * Keys are split in n_split chunks (flash-style partials in `partial`, fp32
+ * [R][nH][n_split][66], R = total rows) and combined.  All queries of an image share its K/V: the memory
+ * is never replicated.  Replaces multihead_attn of transformer.py:416-420/:442-446 with
+ * memory.repeat (transformer.py:88-96). */
+int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K, int64_t ldk,
+                            int64_t k_batch_stride, const void* Vt, int64_t ldvt,
+                            int64_t vt_batch_stride, const uint8_t* key_mask, const int32_t* tiles,
+                            int n_tiles, int R, float* partial, void* out, int64_t ldo, int dtype,
+                            int M, int nH, int n_split, omp_stream_t s);
+
+/* Greedy sampling of one step from logits [R, ld] fp32: softmax over the support, candidate
+ * filtering, argmax, probability; appends the token at seq[r, *d_pos + 1], the probability at
+ * probs[r, *d_pos + 1], maintains finished/lengths for the point decoder, then (if advance)
+ * increments *d_pos.  Replaces transformer.py:106-129 (pt), :258-263 (poly), :272-282 (rec) and
+ * the KIE variants :154-183.  `step0` = sequence position of the first generated token. */
+typedef struct {
+  int32_t kind;        /* OMP_DEC_* */
+  int32_t num_bins, pt_eos, poly_eos, rec_eos, vocab;
+  int32_t vie_categories, infer_vie; /* infer_vie: period-3 pt pattern; poly/rec slice class logits */
+  int32_t suppress_eos;              /* forced-length benchmarking: EOS is never selectable */
+  int32_t step0;
+} omp_sample_cfg;
+int omp_head_softmax_mask_argmax(const float* logits, int ld, int R, const omp_sample_cfg* cfg,
+                                 int32_t* seq, float* probs, int seq_ld, int32_t* finished,
+                                 int32_t* lengths, int32_t* d_pos, int advance, omp_stream_t s);
+
+/* ---- One decoder, many steps (the launch-bound inner loop runs from C++, optionally as a
+ *      hipGraph replay).  Replaces Transformer.decode driven by decode_pt_seq / the poly and rec
+ *      loops, transformer.py:74-141,252-284. */
+typedef struct {
+  const void* sa_in_w;         /* [3d,d] */
+  const float* sa_bias_tab;    /* [Pmax,3d]: in_proj_bias + pos_tab @ [Wq;Wk;0]^T */
+  const void* sa_out_w;
+  const float* sa_out_b;
+  const void* ca_q_w;          /* [d,d] */
+  const float* ca_qbias_tab;   /* [Pmax,d] */
+  const void* ca_out_w;
+  const float* ca_out_b;
+  const void* ff1_w;
+  const float* ff1_b;
+  const void* ff2_w;
+  const float* ff2_b;
+  const float *n1_g, *n1_b, *n2_g, *n2_b, *n3_g, *n3_b;
+  void* kcache;                /* [R,Lmax,d] */
+  void* vcache;
+  const void* crossK;          /* [B][M][ldk] slice of this layer */
+  const void* crossVt;         /* [B][d][M] slice of this layer */
+} omp_dec_layer;
+
+typedef struct {
+  int32_t dtype, n_layers, d_model, n_heads, d_ff, vocab, pre_norm;
+  int32_t R, Lmax, M, n_tiles, n_split, n_prompt;
+  float eps;
+  omp_dec_layer layers[OMP_MAX_DEC_LAYERS];
+  const float *word_emb, *pos_tab, *emb_g, *emb_b, *fn_g, *fn_b;
+  const void *h0_w, *h1_w, *h2_w;
+  const float *h0_b, *h1_b, *h2_b;
+  int64_t ldk, k_batch_stride, ldvt, vt_batch_stride;
+  const uint8_t* key_mask;
+  const int32_t* tiles;
+  /* state */
+  int32_t* seq;
+  int32_t seq_ld;
+  int32_t* d_pos;
+  float* probs;
+  int32_t* finished;
+  int32_t* lengths;
+  /* scratch */
+  float* x;      /* [R,d] fp32 residual stream */
+  float* x2;     /* [R,d] fp32 (post-norm temp) */
+  void* y;       /* [R,d] */
+  void* qkv;     /* [R,3d] */
+  void* att;     /* [R,d] */
+  void* q;       /* [R,d] */
+  void* ffh;     /* [R,d_ff] */
+  void* hh0;     /* [R,d] */
+  void* hh1;     /* [R,d] */
+  float* partial;
+  float* logits; /* [R,vocab] */
+  omp_sample_cfg sample;
+} omp_decoder_plan;
+
+/* Runs steps for input positions first_pos .. first_pos+n_steps-1 (host-side counter must match
+ * *d_pos).  Positions < n_prompt-1 are prompt prefill (no head / sampling).  graph_slot >= 0
+ * caches a hipGraph of the sampling step under that slot (call omp_decoder_graph_reset when the
+ * plan's pointers or shapes change); graph_slot < 0 launches eagerly. */
+int omp_decoder_run(const omp_decoder_plan* plan, int first_pos, int n_steps, int graph_slot,
+                    omp_stream_t s);
+int omp_decoder_graph_reset(int graph_slot);
+
+/* Measurement hooks (bench.py roofline leg): hipEvent-bracket every eagerly launched decoder
+ * cross-attention kernel on its launch stream; read back total milliseconds and launch count. */
+int omp_prof_enable(int on);
+int omp_prof_read(double* total_ms, int64_t* count);
+int omp_debug_force_gemm_kernel(int which);
+
+/* Single teacher-forced step that also leaves logits in plan->logits (parity tests). */
+int omp_decoder_step_logits(const omp_decoder_plan* plan, int pos, omp_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMP355_H */

@@ -1,0 +1,34 @@
+"""GPU parity tests of the individual libomp355 entry points (through the C ABI) vs the oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_all(records):
+    bad = [r for r in records if not r['ok']]
+    assert not bad, '\n'.join('%s: err=%.3e tol=%.1e %s' % (r['name'], r['err'], r['tol'], r['note']) for r in bad)
+
+
+@pytest.fixture(scope='module')
+def C():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from tests import gpu_checks
+    return gpu_checks
+
+
+@pytest.mark.parametrize('name', ['check_layernorm', 'check_gemm', 'check_patch_embed', 'check_window_attn',
+                                  'check_patch_merge', 'check_fpn', 'check_posembed', 'check_sampling'])
+def test_op(C, name):
+    _assert_all(getattr(C, name)())
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('pre_norm', [True, False])
+def test_decoder_teacher_forced(C, dtype, pre_norm):
+    _assert_all(C.check_decoder(dtype, pre_norm, with_mask=True))
+
+
+def test_decoder_no_mask(C):
+    _assert_all(C.check_decoder('fp32', True, with_mask=False))
