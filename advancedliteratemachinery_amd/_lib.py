@@ -24,7 +24,8 @@ class GemmArgs(ctypes.Structure):
                 ('residual', c_void_p), ('ldr', c_int64), ('C', c_void_p), ('ldc', c_int64),
                 ('M', c_int64), ('N', c_int32), ('K', c_int32), ('dtype', c_int32),
                 ('out_dtype', c_int32), ('act', c_int32), ('trans_out', c_int32),
-                ('trans_rows', c_int64), ('trans_ld', c_int64)]
+                ('trans_rows', c_int64), ('trans_ld', c_int64), ('ln_gamma', c_void_p), ('ln_beta', c_void_p),
+                ('ln_eps', c_float), ('small_m_splitk', c_int32)]
 
 
 class SampleCfg(ctypes.Structure):

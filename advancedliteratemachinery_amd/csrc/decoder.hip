@@ -188,8 +188,8 @@ struct CrossP {
   const void* Vt; int64_t ldvt, vbs;
   const uint8_t* kmask;
   const int32_t* tiles;
-  float* partial;
-  int M, nH, n_split, keys_per_split;
+  void* out; int64_t ldo;
+  int M, nH;
 };
 
 template <typename T>
@@ -224,16 +224,22 @@ struct CrossTraits<float> {
   }
 };
 
-template <typename T>
-__global__ __launch_bounds__(64) void dec_cross_attn_kernel(CrossP p) {
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
   typedef Mma<T> MM;
   typedef CrossTraits<T> CT;
   typedef typename MM::frag frag;
-  const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
-  const int t = blockIdx.x, h = blockIdx.y, sp = blockIdx.z;
+  constexpr int NKF = CT::NSB * CT::DSTEPS;
+  constexpr int PSTR = 68;                                       // m, l, pad, pad, o[64]
+  extern __shared__ __attribute__((aligned(16))) float part[];   // [NW][16 queries][PSTR]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int t = blockIdx.x, h = blockIdx.y;
   const int row0 = p.tiles[t * 3], nrows = p.tiles[t * 3 + 1], img = p.tiles[t * 3 + 2];
-  const int kbeg = sp * p.keys_per_split;
-  int kend = kbeg + p.keys_per_split;
+  // the NW waves of the workgroup split the keys; every wave keeps flash-style running (m, l, o)
+  int kpw = (p.M + NW - 1) / NW;
+  kpw = ((kpw + CT::KB - 1) / CT::KB) * CT::KB;
+  const int kbeg = wave * kpw;
+  int kend = kbeg + kpw;
   if (kend > p.M) kend = p.M;
 
   // Q fragments (B operand): query li (clamped), dims s*KSTEP + g*KPL ..
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(64) void dec_cross_attn_kernel(CrossP p) {
     pack16(tmp, qf[s]);
   }
   const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)img * p.kbs + h * DH + g * MM::KPL;
-  const T* Vb = reinterpret_cast<const T*>(p.Vt) + (int64_t)img * p.vbs + (int64_t)(h * DH) * p.ldvt;
+  const T* Vb = reinterpret_cast<const T*>(p.Vt) + (int64_t)img * p.vbs + (int64_t)(h * DH + li) * p.ldvt;
   const uint8_t* km = p.kmask ? p.kmask + (int64_t)img * p.M : nullptr;
 
   float m = -INFINITY, lpart = 0.f;
@@ -257,17 +263,30 @@ __global__ __launch_bounds__(64) void dec_cross_attn_kernel(CrossP p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  frag kc[NKF], vc[4], kn[NKF], vn[4];
+  auto load_block = [&](int k0, frag* kf, frag* vf) {
+#pragma unroll
+    for (int sb = 0; sb < CT::NSB; ++sb) {
+      int key = k0 + sb * 16 + li;           // A operand row = key (clamped; masked below)
+      if (key > p.M - 1) key = p.M - 1;
+      const T* kr = Kb + (int64_t)key * p.ldk;
+#pragma unroll
+      for (int s = 0; s < CT::DSTEPS; ++s) kf[sb * CT::DSTEPS + s] = ld16<T>(kr + s * MM::KSTEP);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vf[dt] = CT::vfrag(Vb + (int64_t)(dt * 16) * p.ldvt, k0, g);
+  };
+  if (kbeg < kend) load_block(kbeg, kc, vc);
   for (int k0 = kbeg; k0 < kend; k0 += CT::KB) {
+    const bool more = k0 + CT::KB < kend;
+    if (more) load_block(k0 + CT::KB, kn, vn);   // next block's loads fly under this block's math
     float sc[CT::NSB * 4];
     float bmax = -INFINITY;
 #pragma unroll
     for (int sb = 0; sb < CT::NSB; ++sb) {
-      int key = k0 + sb * 16 + li;            // A operand row = key
-      if (key > p.M - 1) key = p.M - 1;       // clamp: value is masked below
-      const T* kr = Kb + (int64_t)key * p.ldk;
       f32x4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < CT::DSTEPS; ++s) MM::mma(st, ld16<T>(kr + s * MM::KSTEP), qf[s]);
+      for (int s = 0; s < CT::DSTEPS; ++s) MM::mma(st, kc[sb * CT::DSTEPS + s], qf[s]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kk = k0 + sb * 16 + g * 4 + r;  // this lane's key for acc[r]
@@ -292,41 +311,40 @@ __global__ __launch_bounds__(64) void dec_cross_attn_kernel(CrossP p) {
     const frag pf = CT::pfrag(sc);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      const T* vrow = Vb + (int64_t)(dt * 16 + li) * p.ldvt;
 #pragma unroll
       for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
-      MM::mma(ot[dt], CT::vfrag(vrow, k0, g), pf);
+      MM::mma(ot[dt], vc[dt], pf);
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NKF; ++i) kc[i] = kn[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vc[i] = vn[i];
     }
   }
   float l = lpart;
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
-  if (li < nrows) {
-    float* dst = p.partial + (((int64_t)(row0 + li) * p.nH + h) * p.n_split + sp) * 66;
-    if (g == 0) { dst[0] = m; dst[1] = l; }
+  // merge the NW key slices of this (tile, head) in LDS -- no partial buffer, no combine launch
+  float* mine = part + (wave * 16 + li) * PSTR;
+  if (g == 0) { mine[0] = m; mine[1] = l; }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<f32x4*>(dst + 2 + dt * 16 + g * 4) = ot[dt];
-  }
-}
-
-template <typename T>
-__global__ void dec_cross_combine_kernel(const float* __restrict__ partial, T* __restrict__ out, int64_t ldo,
-                                         int nH, int n_split) {
-  const int r = blockIdx.x;
-  for (int idx = threadIdx.x; idx < nH * DH; idx += blockDim.x) {
-    const int h = idx / DH, dd = idx % DH;
-    const float* base = partial + (((int64_t)r * nH + h) * n_split) * 66;
+  for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(mine + 4 + dt * 16 + g * 4) = ot[dt];
+  __syncthreads();
+  T* out = reinterpret_cast<T*>(p.out);
+  for (int qi = wave; qi < nrows; qi += NW) {
     float mall = -INFINITY;
-    for (int s = 0; s < n_split; ++s) mall = fmaxf(mall, base[s * 66]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mall = fmaxf(mall, part[(w * 16 + qi) * PSTR]);
     float L = 0.f, o = 0.f;
-    for (int s = 0; s < n_split; ++s) {
-      const float ms = base[s * 66];
-      const float w = (ms == -INFINITY) ? 0.f : expf(ms - mall);
-      L += base[s * 66 + 1] * w;
-      o += base[s * 66 + 2 + dd] * w;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float* pw = part + (w * 16 + qi) * PSTR;
+      const float wt = (pw[0] == -INFINITY) ? 0.f : expf(pw[0] - mall);
+      L += pw[1] * wt;
+      o += pw[4 + lane] * wt;
     }
-    out[(int64_t)r * ldo + h * DH + dd] = from_f32<T>(o / L);
+    out[(int64_t)(row0 + qi) * p.ldo + h * DH + lane] = from_f32<T>(o / L);
   }
 }
 
@@ -397,8 +415,26 @@ bool g_prof = false, g_capturing = false;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
 size_t g_prof_used = 0;
 
-int launch_cross(const CrossP& cp, int n_tiles, int dtype, void* out, int64_t ldo, int R, hipStream_t st) {
-  dim3 grid(n_tiles, cp.nH, cp.n_split);
+template <typename T, int NW>
+int launch_cross_t(const CrossP& cp, int n_tiles, hipStream_t st) {
+  const size_t smem = (size_t)NW * 16 * 68 * sizeof(float);
+  auto kern = dec_cross_attn_kernel<T, NW>;
+  if (smem > 48 * 1024) {
+    static bool done = false;
+    if (!done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+        omp_set_error("omp_dec_cross_attn_step: cannot raise dynamic LDS limit");
+        return OMP_ERR_LAUNCH;
+      }
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(n_tiles, cp.nH), dim3(NW * 64), smem, st, cp);
+  return OMP_OK;
+}
+
+// n_waves: key slices per (tile, head) workgroup, rounded down to a power of two in [1, 16]
+int launch_cross(const CrossP& cp, int n_tiles, int dtype, int n_waves, hipStream_t st) {
   const bool prof = g_prof && !g_capturing;
   if (prof) {
     if (g_prof_used == g_prof_ev.size()) {
@@ -408,23 +444,17 @@ int launch_cross(const CrossP& cp, int n_tiles, int dtype, void* out, int64_t ld
     }
     (void)hipEventRecord(g_prof_ev[g_prof_used].first, st);
   }
-  if (dtype == OMP_F32) hipLaunchKernelGGL((dec_cross_attn_kernel<float>), grid, dim3(64), 0, st, cp);
-  else hipLaunchKernelGGL((dec_cross_attn_kernel<bf16_t>), grid, dim3(64), 0, st, cp);
+  int rc;
+  const bool f = dtype == OMP_F32;
+  if (n_waves >= 16) rc = f ? launch_cross_t<float, 16>(cp, n_tiles, st) : launch_cross_t<bf16_t, 16>(cp, n_tiles, st);
+  else if (n_waves >= 8) rc = f ? launch_cross_t<float, 8>(cp, n_tiles, st) : launch_cross_t<bf16_t, 8>(cp, n_tiles, st);
+  else if (n_waves >= 4) rc = f ? launch_cross_t<float, 4>(cp, n_tiles, st) : launch_cross_t<bf16_t, 4>(cp, n_tiles, st);
+  else if (n_waves >= 2) rc = f ? launch_cross_t<float, 2>(cp, n_tiles, st) : launch_cross_t<bf16_t, 2>(cp, n_tiles, st);
+  else rc = f ? launch_cross_t<float, 1>(cp, n_tiles, st) : launch_cross_t<bf16_t, 1>(cp, n_tiles, st);
+  if (rc != OMP_OK) return rc;
   if (prof) (void)hipEventRecord(g_prof_ev[g_prof_used++].second, st);
   OMP_CHECK_LAUNCH("omp_dec_cross_attn_step");
-  if (dtype == OMP_F32)
-    hipLaunchKernelGGL((dec_cross_combine_kernel<float>), dim3(R), dim3(256), 0, st, cp.partial, (float*)out, ldo, cp.nH, cp.n_split);
-  else
-    hipLaunchKernelGGL((dec_cross_combine_kernel<bf16_t>), dim3(R), dim3(256), 0, st, cp.partial, (bf16_t*)out, ldo, cp.nH, cp.n_split);
-  OMP_CHECK_LAUNCH("omp_dec_cross_attn_step(combine)");
   return OMP_OK;
-}
-
-int keys_per_split(int M, int n_split, int dtype) {
-  const int kb = dtype == OMP_F32 ? 16 : 32;
-  int per = (M + n_split - 1) / n_split;
-  per = ((per + kb - 1) / kb) * kb;
-  return per;
 }
 
 }  // namespace
@@ -467,16 +497,16 @@ extern "C" int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K
                                        int64_t vt_batch_stride, const uint8_t* key_mask,
                                        const int32_t* tiles, int n_tiles, int R, float* partial, void* out,
                                        int64_t ldo, int dtype, int M, int nH, int n_split, omp_stream_t s) {
-  OMP_CHECK_ARG(q && K && Vt && tiles && partial && out, "omp_dec_cross_attn_step: null pointer");
+  (void)partial; (void)R;
+  OMP_CHECK_ARG(q && K && Vt && tiles && out, "omp_dec_cross_attn_step: null pointer");
   OMP_CHECK_ARG(dtype == OMP_F32 || dtype == OMP_BF16, "omp_dec_cross_attn_step: bad dtype");
-  OMP_CHECK_ARG(n_tiles > 0 && n_split > 0 && M > 0 && R > 0, "omp_dec_cross_attn_step: bad sizes");
-  OMP_CHECK_ARG(ldvt % 8 == 0, "omp_dec_cross_attn_step: ldvt must be a multiple of 8 (got %lld)", (long long)ldvt);
+  OMP_CHECK_ARG(n_tiles > 0 && n_split > 0 && M > 0, "omp_dec_cross_attn_step: bad sizes");
+  OMP_CHECK_ARG(ldvt % 32 == 0 && ldvt >= M, "omp_dec_cross_attn_step: ldvt must be a multiple of 32 and >= M (got %lld)", (long long)ldvt);
   CrossP cp;
   cp.q = q; cp.ldq = ldq; cp.K = K; cp.ldk = ldk; cp.kbs = k_batch_stride;
   cp.Vt = Vt; cp.ldvt = ldvt; cp.vbs = vt_batch_stride; cp.kmask = key_mask; cp.tiles = tiles;
-  cp.partial = partial; cp.M = M; cp.nH = nH; cp.n_split = n_split;
-  cp.keys_per_split = keys_per_split(M, n_split, dtype);
-  return launch_cross(cp, n_tiles, dtype, out, ldo, R, (hipStream_t)s);
+  cp.out = out; cp.ldo = ldo; cp.M = M; cp.nH = nH;
+  return launch_cross(cp, n_tiles, dtype, n_split, (hipStream_t)s);
 }
 
 extern "C" int omp_head_softmax_mask_argmax(const float* logits, int ld, int R, const omp_sample_cfg* cfg,
@@ -507,12 +537,25 @@ namespace {
 
 int gemm(const omp_decoder_plan* P, const void* A, int64_t lda, const void* W, int K, int N, const float* bias,
          const int32_t* bias_row, int64_t bias_stride, const void* res, void* C, int out_dtype, int act,
-         hipStream_t st) {
+         hipStream_t st, const float* ln_g = nullptr, const float* ln_b = nullptr) {
   omp_gemm_args a{};
   a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.bias_row = bias_row; a.bias_row_stride = bias_stride;
   a.residual = res; a.ldr = N; a.C = C; a.ldc = N; a.M = P->R; a.N = N; a.K = K;
   a.dtype = P->dtype; a.out_dtype = out_dtype; a.act = act; a.trans_out = 0; a.trans_rows = 0; a.trans_ld = 0;
+  a.ln_gamma = ln_g; a.ln_beta = ln_b; a.ln_eps = P->eps; a.small_m_splitk = 1;
   return omp_gemm_bias_act(&a, st);
+}
+
+// y = LN(x) @ W^T (+bias...): fused LayerNorm prologue when the phase has <= 64 rows (split-K small-M
+// kernel), otherwise a LayerNorm launch followed by the tiled GEMM.
+int ln_gemm(const omp_decoder_plan* P, const float* g, const float* b, const void* W, int N, const float* bias,
+            const int32_t* bias_row, int64_t bias_stride, void* C, int out_dtype, int act, hipStream_t st) {
+  const int d = P->d_model;
+  if (P->R <= 64)
+    return gemm(P, P->x, d, W, d, N, bias, bias_row, bias_stride, nullptr, C, out_dtype, act, st, g, b);
+  int rc = omp_layernorm(P->x, OMP_F32, g, b, P->y, P->dtype, nullptr, P->R, d, P->eps, st);
+  if (rc != OMP_OK) return rc;
+  return gemm(P, P->y, d, W, d, N, bias, bias_row, bias_stride, nullptr, C, out_dtype, act, st);
 }
 
 int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
@@ -522,23 +565,19 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
                        P->pre_norm ? nullptr : P->y, T, R, d, P->eps, st));
   CrossP cp;
   cp.q = P->q; cp.ldq = d; cp.ldk = P->ldk; cp.kbs = P->k_batch_stride; cp.ldvt = P->ldvt;
-  cp.vbs = P->vt_batch_stride; cp.kmask = P->key_mask; cp.tiles = P->tiles; cp.partial = P->partial;
-  cp.M = P->M; cp.nH = P->n_heads; cp.n_split = P->n_split;
-  cp.keys_per_split = keys_per_split(P->M, P->n_split, T);
+  cp.vbs = P->vt_batch_stride; cp.kmask = P->key_mask; cp.tiles = P->tiles; cp.out = P->att; cp.ldo = d;
+  cp.M = P->M; cp.nH = P->n_heads;
   for (int li = 0; li < P->n_layers; ++li) {
     const omp_dec_layer& L = P->layers[li];
     cp.K = L.crossK; cp.Vt = L.crossVt;
     if (P->pre_norm) {
-      RUN(omp_layernorm(P->x, OMP_F32, L.n1_g, L.n1_b, P->y, T, nullptr, R, d, P->eps, st));
-      RUN(gemm(P, P->y, d, L.sa_in_w, d, 3 * d, L.sa_bias_tab, P->d_pos, 3 * d, nullptr, P->qkv, T, OMP_ACT_NONE, st));
+      RUN(ln_gemm(P, L.n1_g, L.n1_b, L.sa_in_w, 3 * d, L.sa_bias_tab, P->d_pos, 3 * d, P->qkv, T, OMP_ACT_NONE, st));
       RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, T, R, P->n_heads, d, P->Lmax, st));
       RUN(gemm(P, P->att, d, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
-      RUN(omp_layernorm(P->x, OMP_F32, L.n2_g, L.n2_b, P->y, T, nullptr, R, d, P->eps, st));
-      RUN(gemm(P, P->y, d, L.ca_q_w, d, d, L.ca_qbias_tab, P->d_pos, d, nullptr, P->q, T, OMP_ACT_NONE, st));
-      RUN(launch_cross(cp, P->n_tiles, T, P->att, d, R, st));
+      RUN(ln_gemm(P, L.n2_g, L.n2_b, L.ca_q_w, d, L.ca_qbias_tab, P->d_pos, d, P->q, T, OMP_ACT_NONE, st));
+      RUN(launch_cross(cp, P->n_tiles, T, P->n_split, st));
       RUN(gemm(P, P->att, d, L.ca_out_w, d, d, L.ca_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
-      RUN(omp_layernorm(P->x, OMP_F32, L.n3_g, L.n3_b, P->y, T, nullptr, R, d, P->eps, st));
-      RUN(gemm(P, P->y, d, L.ff1_w, d, P->d_ff, L.ff1_b, nullptr, 0, nullptr, P->ffh, T, OMP_ACT_RELU, st));
+      RUN(ln_gemm(P, L.n3_g, L.n3_b, L.ff1_w, P->d_ff, L.ff1_b, nullptr, 0, P->ffh, T, OMP_ACT_RELU, st));
       RUN(gemm(P, P->ffh, P->d_ff, L.ff2_w, P->d_ff, d, L.ff2_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
     } else {
       RUN(gemm(P, P->y, d, L.sa_in_w, d, 3 * d, L.sa_bias_tab, P->d_pos, 3 * d, nullptr, P->qkv, T, OMP_ACT_NONE, st));
@@ -546,7 +585,7 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
       RUN(gemm(P, P->att, d, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x2, OMP_F32, OMP_ACT_NONE, st));
       RUN(omp_layernorm(P->x2, OMP_F32, L.n1_g, L.n1_b, P->y, T, P->x, R, d, P->eps, st));
       RUN(gemm(P, P->y, d, L.ca_q_w, d, d, L.ca_qbias_tab, P->d_pos, d, nullptr, P->q, T, OMP_ACT_NONE, st));
-      RUN(launch_cross(cp, P->n_tiles, T, P->att, d, R, st));
+      RUN(launch_cross(cp, P->n_tiles, T, P->n_split, st));
       RUN(gemm(P, P->att, d, L.ca_out_w, d, d, L.ca_out_b, nullptr, 0, P->x, P->x2, OMP_F32, OMP_ACT_NONE, st));
       RUN(omp_layernorm(P->x2, OMP_F32, L.n2_g, L.n2_b, P->y, T, P->x, R, d, P->eps, st));
       RUN(gemm(P, P->y, d, L.ff1_w, d, P->d_ff, L.ff1_b, nullptr, 0, nullptr, P->ffh, T, OMP_ACT_RELU, st));
@@ -555,8 +594,7 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
     }
   }
   if (do_head) {
-    RUN(omp_layernorm(P->x, OMP_F32, P->fn_g, P->fn_b, P->y, T, nullptr, R, d, P->eps, st));
-    RUN(gemm(P, P->y, d, P->h0_w, d, d, P->h0_b, nullptr, 0, nullptr, P->hh0, T, OMP_ACT_RELU, st));
+    RUN(ln_gemm(P, P->fn_g, P->fn_b, P->h0_w, d, P->h0_b, nullptr, 0, P->hh0, T, OMP_ACT_RELU, st));
     RUN(gemm(P, P->hh0, d, P->h1_w, d, d, P->h1_b, nullptr, 0, nullptr, P->hh1, T, OMP_ACT_RELU, st));
     RUN(gemm(P, P->hh1, d, P->h2_w, d, P->vocab, P->h2_b, nullptr, 0, nullptr, P->logits, OMP_F32, OMP_ACT_NONE, st));
   }
@@ -570,7 +608,7 @@ int check_plan(const omp_decoder_plan* P) {
   OMP_CHECK_ARG(P->d_model == P->n_heads * DH, "omp_decoder_run: head_dim must be 64");
   OMP_CHECK_ARG(P->R > 0 && P->Lmax > 0 && P->M > 0 && P->n_tiles > 0 && P->n_split > 0, "omp_decoder_run: bad sizes");
   OMP_CHECK_ARG(P->seq && P->d_pos && P->probs && P->x && P->y && P->qkv && P->att && P->q && P->ffh && P->hh0 &&
-                    P->hh1 && P->partial && P->logits && P->tiles,
+                    P->hh1 && P->logits && P->tiles,
                 "omp_decoder_run: null buffer in plan");
   OMP_CHECK_ARG(P->pre_norm || P->x2, "omp_decoder_run: post-norm needs x2");
   return OMP_OK;

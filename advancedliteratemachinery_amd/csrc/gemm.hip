@@ -18,7 +18,7 @@
 
 namespace {
 
-int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows (debug/testing)
+int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows, 4 small split-K (debug/testing)
 
 struct GemmP {
   const void* A; int64_t lda;
@@ -28,7 +28,8 @@ struct GemmP {
   void* C; int64_t ldc;
   int64_t M; int N; int K;
   int act; int trans_out; int64_t trans_rows, trans_ld;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n; int small_hint;
+  const float* ln_g; const float* ln_b; float ln_eps;   // optional LayerNorm prologue (A is fp32)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -228,7 +229,9 @@ __global__ __launch_bounds__(256) void gemm_rows(GemmP p) {
   int64_t gm = mb + lrow; if (gm > p.M - 1) gm = p.M - 1;
   const T* wp = reinterpret_cast<const T*>(p.W) + (int64_t)gn * p.ldw + lg * MM::KPL;
   const T* xp = reinterpret_cast<const T*>(p.A) + gm * p.lda + lg * MM::KPL;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  // ONE accumulator chain in ascending k: bit-identical to gemm_tiled's per-element summation order,
+  // so a row's result does not depend on which kernel (i.e. which batch size) computed it.
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int nsteps = p.K / MM::KSTEP;
   int s = 0;
   for (; s + 8 <= nsteps; s += 8) {
@@ -239,22 +242,178 @@ __global__ __launch_bounds__(256) void gemm_rows(GemmP p) {
       fx[u] = ld16<T>(xp + (s + u) * MM::KSTEP);
     }
 #pragma unroll
-    for (int u = 0; u < 8; u += 2) {
-      MM::mma(acc0, fw[u], fx[u]);
-      MM::mma(acc1, fw[u + 1], fx[u + 1]);
-    }
+    for (int u = 0; u < 8; ++u) MM::mma(acc, fw[u], fx[u]);
   }
-  for (; s < nsteps; ++s) MM::mma(acc0, ld16<T>(wp + s * MM::KSTEP), ld16<T>(xp + s * MM::KSTEP));
-  f32x4 acc = acc0 + acc1;
+  for (; s < nsteps; ++s) MM::mma(acc, ld16<T>(wp + s * MM::KSTEP), ld16<T>(xp + s * MM::KSTEP));
   const float* bias = p.bias;
   if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
   epilogue_store<TOut>(p, bias, mb + lrow, nb + lg * 4, acc);
+}
+
+
+// Small-M split-K kernel (decoder steps: M = rows of one phase <= 64, weight-streaming bound).
+// grid = ceil(N/16) workgroups of 4 waves; a workgroup owns 16 output features x ALL rows and its waves
+// split K four ways (so even N = 512 gives 32 workgroups x 4 waves, each streaming a 16 x K/4 slab of W
+// with a handful of 16-byte loads in flight); partial accumulators meet in LDS in a fixed order.
+// LN = true fuses the preceding LayerNorm: A is the fp32 residual stream, each workgroup normalises
+// the (<= 64) rows once into LDS (as T) and the MFMA B-operand is read from there.
+template <typename T, typename TOut, int MF, bool LN>
+__global__ __launch_bounds__(256) void gemm_small(GemmP p) {
+  typedef Mma<T> MM;
+  typedef typename MM::frag frag;
+  extern __shared__ __attribute__((aligned(16))) char sm_small[];
+  f32x4* red = reinterpret_cast<f32x4*>(sm_small);           // [4 waves][MF][64 lanes]
+  char* alds = sm_small + 4 * MF * 64 * sizeof(f32x4);        // [MF*16 rows][K*sizeof(T) + 16]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lrow = lane & 15, lg = lane >> 4;
+  const int nb = blockIdx.x * 16;
+  int gn = nb + lrow; if (gn > p.N - 1) gn = p.N - 1;
+  const T* wp = reinterpret_cast<const T*>(p.W) + (int64_t)gn * p.ldw + lg * MM::KPL;
+  const int KQ = p.K / 4, kbeg = wave * KQ;
+  const int astride = p.K * (int)sizeof(T) + 16;
+
+  if constexpr (LN) {
+    const float* X = reinterpret_cast<const float*>(p.A);
+    const int nch = p.K / 4;  // float4 chunks per row
+    for (int r = wave; r < MF * 16; r += 4) {
+      char* dst = alds + r * astride;
+      if (r < p.M) {
+        const float* xr = X + (int64_t)r * p.lda;
+        float v[4][4];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int c = lane + 64 * it;
+          if (c < nch) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(xr + c * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[it][i] = t[i]; s += t[i]; }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[it][i] = 0.f;
+          }
+        }
+        s = wave_sum(s);
+        const float mean = s / (float)p.K;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          if (lane + 64 * it < nch) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float d = v[it][i] - mean; q += d * d; }
+          }
+        q = wave_sum(q);
+        const float rstd = 1.0f / sqrtf(q / (float)p.K + p.ln_eps);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int c = lane + 64 * it;
+          if (c < nch) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(p.ln_g + c * 4);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + c * 4);
+            T* o = reinterpret_cast<T*>(dst) + c * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = from_f32<T>((v[it][i] - mean) * rstd * gg[i] + bb[i]);
+          }
+        }
+      } else {
+        for (int c = lane; c < nch; c += 64) {
+          T* o = reinterpret_cast<T*>(dst) + c * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(0.f);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const T* xp[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    int64_t gm = mf * 16 + lrow; if (gm > p.M - 1) gm = p.M - 1;
+    xp[mf] = reinterpret_cast<const T*>(p.A) + gm * p.lda + lg * MM::KPL;
+  }
+  f32x4 acc[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = KQ / MM::KSTEP;
+  for (int s0 = 0; s0 < nsteps; s0 += 4) {
+    frag fw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (s0 + u < nsteps) fw[u] = ld16<T>(wp + kbeg + (s0 + u) * MM::KSTEP);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (s0 + u < nsteps) {
+        const int k = kbeg + (s0 + u) * MM::KSTEP;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          frag fx;
+          if constexpr (LN) fx = *reinterpret_cast<const frag*>(alds + (mf * 16 + lrow) * astride + (k + lg * MM::KPL) * (int)sizeof(T));
+          else fx = ld16<T>(xp[mf] + k);
+          MM::mma(acc[mf], fw[u], fx);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) red[(wave * MF + mf) * 64 + lane] = acc[mf];
+  __syncthreads();
+  if (wave < MF) {
+    f32x4 a = red[(0 * MF + wave) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) a += red[(w * MF + wave) * 64 + lane];
+    const float* bias = p.bias;
+    if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
+    epilogue_store<TOut>(p, bias, (int64_t)wave * 16 + lrow, nb + lg * 4, a);
+  }
+}
+
+template <typename T, typename TOut, int MF, bool LN>
+int launch_small_t(const GemmP& p, hipStream_t st) {
+  const size_t red = 4 * MF * 64 * sizeof(f32x4);
+  const size_t ab = LN ? (size_t)MF * 16 * (p.K * sizeof(T) + 16) : 0;
+  const size_t smem = red + ab;
+  auto kern = gemm_small<T, TOut, MF, LN>;
+  if (smem > 48 * 1024) {
+    static bool done = false;   // per template instantiation
+    if (!done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        omp_set_error("omp_gemm_bias_act: cannot raise dynamic LDS limit");
+        return OMP_ERR_LAUNCH;
+      }
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div64(p.N, 16)), dim3(256), smem, st, p);
+  OMP_CHECK_LAUNCH("omp_gemm_bias_act(small)");
+  return OMP_OK;
+}
+
+template <typename T, typename TOut>
+int launch_small(const GemmP& p, hipStream_t st) {
+  const int mf = (int)ceil_div64(p.M, 16);
+  const bool ln = p.ln_g != nullptr;
+  if (mf <= 1) return ln ? launch_small_t<T, TOut, 1, true>(p, st) : launch_small_t<T, TOut, 1, false>(p, st);
+  if (mf <= 2) return ln ? launch_small_t<T, TOut, 2, true>(p, st) : launch_small_t<T, TOut, 2, false>(p, st);
+  return ln ? launch_small_t<T, TOut, 4, true>(p, st) : launch_small_t<T, TOut, 4, false>(p, st);
 }
 
 template <typename T, typename TOut>
 int launch_gemm(const GemmP& p0, hipStream_t st) {
   GemmP p = p0;
   int which = g_force_kernel;
+  const int kq = 4 * Mma<T>::KSTEP;
+  if (p.ln_g != nullptr || which == 4 || (which == 0 && p.small_hint && p.M <= 64 && p.K % kq == 0)) {
+    if (p.M > 64 || p.K % kq != 0 || p.trans_out) {
+      omp_set_error("omp_gemm_bias_act: split-K small-M kernel needs M <= 64, K %% %d == 0, no trans_out", kq);
+      return OMP_ERR_UNSUPPORTED;
+    }
+    if (p.ln_g != nullptr && p.K > 1024) {
+      omp_set_error("omp_gemm_bias_act: fused LayerNorm supports K <= 1024");
+      return OMP_ERR_UNSUPPORTED;
+    }
+    return launch_small<T, TOut>(p, st);
+  }
   if (which == 0) {
     if (p.M <= 64) which = 3;
     else if (ceil_div64(p.M, 128) * ceil_div64(p.N, 128) < 512) which = 2;
@@ -292,7 +451,7 @@ extern "C" int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s) {
   const int esz = a->dtype == OMP_F32 ? 4 : 2;
   const int ktile = 128 / esz;
   OMP_CHECK_ARG(a->K % ktile == 0, "omp_gemm_bias_act: K=%d must be a multiple of %d", a->K, ktile);
-  OMP_CHECK_ARG((a->lda * esz) % 16 == 0 && (a->ldw * esz) % 16 == 0,
+  OMP_CHECK_ARG((a->lda * (a->ln_gamma ? 4 : esz)) % 16 == 0 && (a->ldw * esz) % 16 == 0,
                 "omp_gemm_bias_act: lda/ldw rows must be 16-byte aligned");
   OMP_CHECK_ARG(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->W % 16) == 0 && ((uintptr_t)a->C % 16) == 0,
                 "omp_gemm_bias_act: A/W/C must be 16-byte aligned");
@@ -305,6 +464,8 @@ extern "C" int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s) {
   p.residual = a->residual; p.ldr = a->ldr; p.C = a->C; p.ldc = a->ldc;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act;
   p.trans_out = a->trans_out; p.trans_rows = a->trans_rows; p.trans_ld = a->trans_ld; p.tiles_m = p.tiles_n = 0;
+  p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.small_hint = a->small_m_splitk;
+  OMP_CHECK_ARG((a->ln_gamma == nullptr) == (a->ln_beta == nullptr), "omp_gemm_bias_act: ln_gamma and ln_beta go together");
   hipStream_t st = (hipStream_t)s;
   if (a->dtype == OMP_F32) return launch_gemm<float, float>(p, st);
   if (a->out_dtype == OMP_F32) return launch_gemm<bf16_t, float>(p, st);

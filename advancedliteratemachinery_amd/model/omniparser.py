@@ -49,7 +49,10 @@ class OmniParser(nn.Module):
         params.attach_parameters(self, spec, shared)
         self._engine = None
         self._engine_key = None
-        self.use_graph = False
+        self.use_graph = True          # decoder steps replay as hipGraphs when run on a non-default stream
+        self.overlap_decoders = True   # polygon || recognition decoders on two streams
+        self._streams = None
+        self.phase_events = None       # set to [] to collect (name, torch.cuda.Event) marks per infer()
         self.eval()
 
     # -- engine lifecycle -------------------------------------------------------------------------
@@ -72,6 +75,20 @@ class OmniParser(nn.Module):
             self._engine, self._engine_key = (enc, dec), key
         self._engine[1].use_graph = self.use_graph
         return self._engine
+
+    def _mark(self, name):
+        if self.phase_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.phase_events.append((name, ev))
+
+    def _side_streams(self, dev):
+        """Two extra HIP streams so the polygon and recognition decoders overlap (None -> sequential)."""
+        if not self.overlap_decoders:
+            return None
+        if self._streams is None or self._streams[0].device != dev:
+            self._streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        return self._streams
 
     def set_engine_dtype(self, dtype):
         self.engine_dtype = _DTYPES[dtype]
@@ -101,12 +118,16 @@ class OmniParser(nn.Module):
             img = img.float().contiguous()
             if has_padding is None:
                 has_padding = bool(mask.any())
+            self._mark('start')
             e = enc.encode(img, mask)
+            self._mark('encode')
             kv = dec.project_memory(e['memory'], e['mem_pos'], B, e['M'], e['key_mask'] if has_padding else None)
             prompt = [int(t) for t in sequence[0].reshape(-1).tolist()]
             poly_sos = int(sequence[1].reshape(-1)[0])
             rec_sos = int(sequence[2].reshape(-1)[0])
+            self._mark('kv_project')
             pts = dec.decode_points(kv, prompt, forced_instances=forced_instances)
+            self._mark('pt_decode')
             if a.infer_vie:
                 sizes = sequence[3]
                 return self._kie(dec, kv, pts, poly_sos, rec_sos, sizes, B)
@@ -115,9 +136,10 @@ class OmniParser(nn.Module):
             if R == 0:
                 return [None] * B
             points = torch.cat([ids.reshape(-1, 2) for ids, _ in pts], 0).to(dev, torch.int32)
-            poly, _ = dec.decode_instances('poly', kv, points, counts, poly_sos, 32)
-            rec, rprob = dec.decode_instances('rec', kv, points, counts, rec_sos, a.rec_length)
+            (poly, _), (rec, rprob) = dec.decode_poly_and_rec(kv, points, counts, poly_sos, rec_sos, a.rec_length,
+                                                              streams=self._side_streams(dev))
             poly, rec, rprob = poly.long(), rec.long(), rprob.clone()
+            self._mark('poly_rec_decode')
             out, r0 = [], 0
             for b in range(B):
                 n = counts[b]
@@ -155,8 +177,8 @@ class OmniParser(nn.Module):
         poly = rec = None
         if words:
             points = torch.tensor(words, dtype=torch.int32, device=kv['K'].device)
-            poly, _ = dec.decode_instances('poly', kv, points, counts, poly_sos, 32, infer_vie=True)
-            rec, _ = dec.decode_instances('rec', kv, points, counts, rec_sos, a.rec_length, infer_vie=True)
+            (poly, _), (rec, _) = dec.decode_poly_and_rec(kv, points, counts, poly_sos, rec_sos, a.rec_length,
+                                                          infer_vie=True, streams=self._side_streams(kv['K'].device))
             poly, rec = poly.cpu(), rec.cpu()
         i2c = index2class(a)
         sizes = _image_sizes(sizes, B)

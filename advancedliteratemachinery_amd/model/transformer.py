@@ -62,7 +62,7 @@ class _Phase(object):
         self.y, self.att, self.q, self.hh0, self.hh1 = e(R, d), e(R, d), e(R, d), e(R, d), e(R, d)
         self.qkv, self.ffh = e(R, 3 * d), e(R, ff)
         self.logits = e(R, V, dtype=torch.float32)
-        self.partial = e(R, nH, n_split, 66, dtype=torch.float32)
+        self.partial = e(16, dtype=torch.float32)   # unused since the in-workgroup LDS merge (ABI field kept)
         self.kc = [e(R, Lmax, d) for _ in range(L)]
         self.vc = [e(R, Lmax, d) for _ in range(L)]
         self.plan = _lib.DecoderPlan()
@@ -195,7 +195,9 @@ class Decoder(object):
         return P
 
     def _slot(self, plan):
-        if not self.use_graph:
+        # stream capture is illegal on the legacy null stream: graphs only when the caller runs us on a
+        # real stream (bench / predict do), eager launches otherwise
+        if not self.use_graph or torch.cuda.current_stream().cuda_stream == 0:
             return -1
         key = bytes(plan)
         if key not in self._graph_slots:
@@ -209,9 +211,11 @@ class Decoder(object):
         _lib.check(rc, 'omp_decoder_run')
 
     def _n_split(self, n_tiles, M):
-        want = max(1, 1024 // max(1, n_tiles * self.nH))
+        """Waves per (tile, head) workgroup of the cross-attention kernel = key slices merged in LDS:
+        aim for ~1024 waves in flight, power of two in [1, 16], at least one key block per wave."""
         kb = 16 if self.dtype == torch.float32 else 32
-        return max(1, min(want, (M + kb - 1) // kb, 64))
+        want = max(1, min(16, 1024 // max(1, n_tiles * self.nH), (M + kb - 1) // kb))
+        return 1 << (want.bit_length() - 1)
 
     # -- greedy drivers ---------------------------------------------------------------------------
     def decode_points(self, kv, prompt, max_new=None, forced_instances=None, poll=16):
@@ -254,9 +258,9 @@ class Decoder(object):
             out.append((ids, pr))
         return out
 
-    def decode_instances(self, kind, kv, points, counts, sos, n_new, infer_vie=False):
-        """poly / rec decoding of R = sum(counts) instances (rows sorted by image).
-        points: int32 [R,2] (device).  Returns (ids [R,n_new] int32, probs [R,n_new] fp32) on device."""
+    def begin_instances(self, kind, kv, points, counts, sos, n_new, infer_vie=False):
+        """Set up poly / rec decoding of R = sum(counts) instances (rows sorted by image).  points: int32
+        [R,2] on the device.  Returns the phase; drive it with `_run(ph, pos, n)` for 2 + n_new positions."""
         R = int(points.shape[0])
         tiles = self.make_tiles(counts)
         ph = self._phase(kind, R, 2 + n_new, 3 + n_new + 1, self._n_split(len(tiles), kv['M']))
@@ -264,8 +268,46 @@ class Decoder(object):
         ph.d_pos.zero_()
         ph.seq[:, 0:2] = points
         ph.seq[:, 2] = sos
+        ph.n_new = n_new
+        return ph
+
+    @staticmethod
+    def instances_result(ph):
+        return ph.seq[:, 3:3 + ph.n_new], ph.probs[:, 3:3 + ph.n_new]
+
+    def decode_instances(self, kind, kv, points, counts, sos, n_new, infer_vie=False):
+        """-> (ids [R,n_new] int32, probs [R,n_new] fp32) views into the phase buffers (device)."""
+        ph = self.begin_instances(kind, kv, points, counts, sos, n_new, infer_vie)
         self._run(ph, 0, 2 + n_new)
-        return ph.seq[:, 3:3 + n_new], ph.probs[:, 3:3 + n_new]
+        return self.instances_result(ph)
+
+    def decode_poly_and_rec(self, kv, points, counts, poly_sos, rec_sos, rec_length, infer_vie=False, streams=None):
+        """The polygon and recognition decoders only depend on the points: run them CONCURRENTLY on two
+        streams, enqueueing step by step so that both queues stay fed (small-kernel phases do not fill
+        256 CUs on their own)."""
+        if streams is None or torch.cuda.current_stream().cuda_stream == 0:
+            poly = self.decode_instances('poly', kv, points, counts, poly_sos, 32, infer_vie)
+            rec = self.decode_instances('rec', kv, points, counts, rec_sos, rec_length, infer_vie)
+            return poly, rec
+        cur = torch.cuda.current_stream()
+        sp, sr = streams
+        sp.wait_stream(cur)
+        sr.wait_stream(cur)
+        with torch.cuda.stream(sp):
+            php = self.begin_instances('poly', kv, points, counts, poly_sos, 32, infer_vie)
+        with torch.cuda.stream(sr):
+            phr = self.begin_instances('rec', kv, points, counts, rec_sos, rec_length, infer_vie)
+        np_, nr = 2 + 32, 2 + rec_length
+        for pos in range(max(np_, nr)):
+            if pos < np_:
+                with torch.cuda.stream(sp):
+                    self._run(php, pos, 1)
+            if pos < nr:
+                with torch.cuda.stream(sr):
+                    self._run(phr, pos, 1)
+        cur.wait_stream(sp)
+        cur.wait_stream(sr)
+        return self.instances_result(php), self.instances_result(phr)
 
     def teacher_forced_logits(self, kind, kv, seqs, counts, n_prompt, infer_vie=False):
         """Parity helper: logits [R, L, V] of decoder `kind` fed the given token sequences."""

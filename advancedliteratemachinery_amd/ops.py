@@ -53,14 +53,15 @@ def layernorm(x, gamma, beta, out_dtype=None, out=None, out_f32=None, eps=1e-5, 
 
 
 def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None, M=None, lda=None,
-         ldw=None, ldc=None, N=None, K=None, bias_row=None, bias_row_stride=0, trans_rows=0, trans_ld=0):
+         ldw=None, ldc=None, N=None, K=None, bias_row=None, bias_row_stride=0, trans_rows=0, trans_ld=0,
+         ln=None, ln_eps=1e-5, small_m=False):
     """out[M,N] = act(A[M,K] @ W[N,K]^T + bias) + residual.  A/W may be strided row views (lda/ldw)."""
     K = K or A.shape[-1]
     N = N or W.shape[0]
     M = M or A.numel() // A.shape[-1]
     lda = lda or A.stride(-2) if A.dim() > 1 else K
     ldw = ldw or W.stride(0)
-    out_dtype = out_dtype or A.dtype
+    out_dtype = out_dtype or W.dtype
     if out is None:
         if trans_rows:
             raise ValueError('trans_out needs a preallocated (zeroed) output')
@@ -72,7 +73,10 @@ def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     a.residual, a.ldr = ptr(residual), (residual.stride(-2) if residual is not None else 0)
     a.C, a.ldc = ptr(out), ldc
     a.M, a.N, a.K = M, N, K
-    a.dtype, a.out_dtype, a.act = dt(A), dt(out), act
+    a.dtype, a.out_dtype, a.act = dt(W), dt(out), act
+    if ln is not None:
+        a.ln_gamma, a.ln_beta, a.ln_eps = ptr(ln[0]), ptr(ln[1]), float(ln_eps)
+    a.small_m_splitk = 1 if small_m else 0
     a.trans_out, a.trans_rows, a.trans_ld = (1 if trans_rows else 0), trans_rows, trans_ld
     rc = _lib.lib().omp_gemm_bias_act(ctypes.byref(a), stream())
     _lib.check(rc, 'omp_gemm_bias_act')

@@ -49,6 +49,7 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--phase-times', action='store_true', help='also print a per-phase time breakdown (stderr)')
+    p.add_argument('--overlap', type=int, default=1, help='polygon || recognition decoders on two streams')
     return p.parse_args()
 
 
@@ -63,6 +64,16 @@ def build_model(dtype, graph, device):
     model = model.to(device)
     model.use_graph = bool(graph)
     return model, args, sd
+
+
+def phase_breakdown(model, one_step, stream):
+    model.phase_events = []
+    with torch.cuda.stream(stream):
+        one_step()
+        torch.cuda.synchronize()
+    ev = model.phase_events
+    model.phase_events = None
+    return {ev[i][0]: ev[i - 1][1].elapsed_time(ev[i][1]) for i in range(1, len(ev))}
 
 
 def prompts(args):
@@ -104,7 +115,7 @@ def cpu_baseline(args, sd, size, instances, pt_steps):
     g = torch.Generator().manual_seed(1234)
     img = torch.randn(1, 3, size, size, generator=g)
     mask = torch.zeros(1, size, size, dtype=torch.bool)
-    sd = {k: v.float() for k, v in sd.items()}
+    sd = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
     with torch.no_grad():
         t0 = time.time()
         enc = O.encode(sd, args, img, mask)
@@ -151,6 +162,7 @@ def main():
 
     from advancedliteratemachinery_amd import _lib
     model, args, sd = build_model(a.dtype, a.graph, device)
+    model.overlap_decoders = bool(a.overlap)
     B, N = a.batch, a.instances
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
     img = torch.randn(B, 3, a.size, a.size, generator=g).to(device)   # resident in HBM before timing
@@ -186,6 +198,9 @@ def main():
     # sanity: the forced workload really produced N instances x rec_length chars per image
     ids, _ = out
     assert ids.shape[0] == world * B and int((ids[:, :, 34:] >= args.num_bins).all()), 'decode output malformed'
+
+    if a.phase_times and rank == 0:
+        print('phase ms: %s' % json.dumps(phase_breakdown(model, one_step, stream)), file=sys.stderr, flush=True)
 
     roof = None
     if rank == 0 and not a.no_roofline:

@@ -78,6 +78,12 @@ typedef struct {
   int32_t trans_out;
   int64_t trans_rows; /* rows (tokens) per batch item */
   int64_t trans_ld;   /* pitch of a transposed row, >= trans_rows */
+  /* optional fused LayerNorm prologue (decoder steps, M <= 64): A is then the fp32 residual stream
+   * [M,K] and the GEMM consumes LN(A) * ln_gamma + ln_beta (transformer.py:437,441,450 + the Linear) */
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  int32_t small_m_splitk; /* hint: M <= 64 weight-streaming GEMM -> split-K workgroups */
 } omp_gemm_args;
 int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s);
 

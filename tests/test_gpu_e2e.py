@@ -35,5 +35,11 @@ def test_batch_equals_single(C, dtype):
     _assert_all(C.check_batch_equivalence(dtype))
 
 
+@pytest.mark.parametrize('name', ['spot_odd', 'kie_sroie'])
+def test_golden_fp32_graph_and_overlap(C, name):
+    """Same gate with decoder steps replayed as hipGraphs and poly || rec on two streams."""
+    _assert_all(C.check_e2e(name, 'fp32', graph=True))
+
+
 def test_graph_replay_matches_eager(C):
     _assert_all(C.check_graph_matches_eager('fp32'))

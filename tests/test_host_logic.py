@@ -1,0 +1,157 @@
+"""CPU tests of the host-side logic around the hot path (no GPU): C-ABI export list, state-dict layout,
+result formatting vs the reference's decode_seq, image sharding + all-gather under gloo (world 2)."""
+import os
+import sys
+import types
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from advancedliteratemachinery_amd.utils import dist as udist
+from advancedliteratemachinery_amd.utils.parser import make_args
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import re
+    from advancedliteratemachinery_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, 'include', 'omp355.h')).read()
+    declared = set(re.findall(r'\b(omp_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    if not os.path.exists(_lib.LIB_PATH):
+        from advancedliteratemachinery_amd import build
+        build.build(verbose=False)
+    h = _lib.lib()
+    for name in declared:
+        assert hasattr(h, name), 'libomp355.so does not export %s' % name
+    assert h.omp_abi_version() == 1
+
+
+def test_state_dict_layout_matches_reference_keys():
+    from advancedliteratemachinery_amd.model import OmniParser, expected_state_dict
+    from oracle import weights
+    for kw in (dict(use_fpn=True), dict(use_fpn=False), dict(use_fpn=True, vie_categories=29)):
+        args = make_args(tfm_pre_norm=True, **kw)
+        spec = expected_state_dict(args)
+        ora = weights.state_dict_spec(args)
+        assert list(spec) == list(ora)
+        assert all(tuple(spec[k][0]) == tuple(ora[k]) for k in ora)
+    args = make_args(tfm_pre_norm=True, use_fpn=True)
+    m = OmniParser(args, dict(depths=(2, 2, 2, 2)))
+    sd = weights.make_state_dict(args, depths=(2, 2, 2, 2))
+    m.load_state_dict(sd, strict=True)
+    # the three decoder-norm key pairs alias ONE tensor, like the reference's shared nn.LayerNorm
+    s = m.state_dict()
+    assert s['transformer.pt_decoder.norm.weight'].data_ptr() == s['transformer.rec_decoder.norm.weight'].data_ptr()
+    with pytest.raises(RuntimeError):
+        m.engine()  # CPU model: must fail loudly, never fall back
+
+
+def test_ops_refuse_cpu_tensors():
+    from advancedliteratemachinery_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.layernorm(torch.zeros(4, 128), torch.ones(128), torch.zeros(128))
+
+
+def _reference_decode_seq():
+    from oracle import ref_import
+    if not ref_import.available():
+        return None
+    for name in ('bezier',):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_misc', os.path.join(ref_import.REF_ROOT, 'utils', 'misc.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.decode_seq
+
+
+def test_decode_seq_matches_reference():
+    from advancedliteratemachinery_amd.utils.misc import decode_seq
+    args = make_args()
+    g = torch.Generator().manual_seed(0)
+    pt = torch.randint(0, 1000, (10,), generator=g)
+    poly = torch.randint(0, 1000, (5 * 32,), generator=g)
+    rec = torch.randint(1000, 1100, (5, 25), generator=g)
+    rec[0, 3] = args.rec_eos_index
+    rec[1, 0] = args.recog_pad_index
+    rec[2, 5] = args.recog_pad_index - 1
+    probs = torch.rand(5, 25, generator=g)
+    mine = (decode_seq(pt, args, 'pt'), decode_seq(poly, args, 'poly'), decode_seq(rec, args, 'rec', probs))
+    # known answers
+    assert mine[0][0]['point'] == ((pt[0] / 1000).item(), (pt[1] / 1000).item())
+    assert mine[2][0][0]['rec'] == ''.join(args.chars[t - 1000] for t in rec[0, :3].tolist())
+    assert mine[2][0][1]['rec'] == ''
+    ref = _reference_decode_seq()
+    if ref is None:
+        return
+    r = (ref(pt, args, 'pt', 'none'), ref(poly, args, 'poly', 'none'), ref(rec, args, 'rec', probs))
+    assert mine[0] == r[0]
+    assert all(torch.equal(a['polygon'], b['polygon']) for a, b in zip(mine[1], r[1]))
+    assert mine[2][0] == r[2][0]
+    assert all(abs(a - b) < 1e-6 for a, b in zip(mine[2][1], r[2][1]))
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 8, 32, 33):
+        for ws in (1, 2, 3, 8):
+            spans = [udist.shard_range(n, r, ws) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _fake_result(seed, n, rec_len):
+    g = torch.Generator().manual_seed(seed)
+    if n == 0:
+        return None
+    return ([torch.randint(0, 1000, (1, 2 * n), generator=g), torch.randint(0, 1000, (1, 32 * n), generator=g),
+             torch.randint(1000, 1096, (1, n, rec_len), generator=g)], [torch.rand(n, rec_len, generator=g)])
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    assert udist.init_distributed_mode(backend='gloo')
+    rec_len, nmax, total = 25, 6, 6
+    lo, hi = udist.shard_range(total, rank, world)
+    local = [_fake_result(100 + i, [3, 0, 6, 1, 2, 5][i], rec_len) for i in range(lo, hi)]
+    ids, probs, n = udist.pack_results(local, nmax, rec_len, 'cpu')
+    ids, probs, n = udist.all_gather_results(ids, probs, n)
+    res = udist.unpack_results(ids, probs, n)
+    ok = len(res) == total
+    for i, r in enumerate(res):
+        exp = _fake_result(100 + i, [3, 0, 6, 1, 2, 5][i], rec_len)
+        if exp is None:
+            ok &= r is None
+            continue
+        ok &= all(torch.equal(a, b) for a, b in zip(r[0], exp[0])) and torch.equal(r[1][0], exp[1][0])
+    q.put((rank, bool(ok)))
+    torch.distributed.destroy_process_group()
+
+
+def test_image_sharded_gather_world2_gloo():
+    """N > 1 path: every rank ends up with every image's result, in global image order."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(got) == [(0, True), (1, True)]
+
+
+def test_decode_pred_seq_record_format():
+    from advancedliteratemachinery_amd.engine.inference import build_prompts, decode_pred_seq
+    args = make_args(use_char_window_prompt=True)
+    assert build_prompts(args)[0].tolist() == [[0, 0, 999, 999, 1000, 1095, 1100]]
+    r = _fake_result(1, 2, 25)
+    recs = decode_pred_seq([t[0] for t in r[0]], r[1][0], {'file_name': 'a.jpg', 'orig_size': (480, 640)}, args)
+    assert len(recs) == 2 and set(recs[0]) == {'image_id', 'pts', 'score', 'polys', 'rec'}
+    assert len(recs[0]['polys']) == 16 and abs(recs[0]['pts'][0][0] - r[0][0][0, 0].item() / 1000 * 640) < 1e-3

@@ -40,6 +40,8 @@ def main():
         allr += run(C.check_e2e, name, 'fp32')
     for name in ('spot_224', 'spot_odd'):
         allr += run(C.check_e2e, name, 'bf16')
+    for name in ('spot_odd', 'kie_sroie'):
+        allr += run(C.check_e2e, name, 'fp32', True)
     allr += run(C.check_batch_equivalence, 'fp32')
     allr += run(C.check_batch_equivalence, 'bf16')
     allr += run(C.check_graph_matches_eager, 'fp32')
