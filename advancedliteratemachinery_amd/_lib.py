@@ -76,6 +76,7 @@ _SIGS = {
     'omp_decoder_graph_reset': (c_int, [c_int]),
     'omp_decoder_step_logits': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_void_p]),
     'omp_debug_force_gemm_kernel': (c_int, [c_int]),
+    'omp_debug_set_gemm_prefetch': (c_int, [c_int]),
     'omp_prof_enable': (c_int, [c_int]),
     'omp_prof_read': (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
 }

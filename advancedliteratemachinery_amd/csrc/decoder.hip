@@ -130,31 +130,39 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__
   float m = -INFINITY, l = 0.f, o[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] = 0.f;
-  for (int j0 = 0; j0 <= p; j0 += 8) {
-    const int j = j0 + js;
-    const bool valid = j <= p;
-    float kk[8], vv[8];
-    if (valid && j < p) {
-      load8(kbase + (int64_t)j * d, kk);
-      load8(vbase + (int64_t)j * d, vv);
-    } else {
+  // 4 key blocks (32 keys) per outer iteration: all 8 loads are issued before the dependent online-softmax
+  // updates, so one memory round trip covers 32 keys instead of 8.
+  for (int j0 = 0; j0 <= p; j0 += 32) {
+    float kk[4][8], vv[4][8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { kk[i] = kn[i]; vv[i] = vn[i]; }
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 8 + js;
+      if (j < p) {
+        load8(kbase + (int64_t)j * d, kk[u]);
+        load8(vbase + (int64_t)j * d, vv[u]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { kk[u][i] = kn[i]; vv[u][i] = vn[i]; }
+      }
     }
-    float sdot = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sdot = fmaf(q[i], kk[i], sdot);
-    sdot += __shfl_xor(sdot, 1, 64);
-    sdot += __shfl_xor(sdot, 2, 64);
-    sdot += __shfl_xor(sdot, 4, 64);
-    if (valid) {
-      const float mn = fmaxf(m, sdot);
-      const float a = expf(m - mn);  // exp(-inf) = 0 on the first key
-      const float pj = expf(sdot - mn);
-      l = l * a + pj;
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 8 + js;
+      float sdot = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = o[i] * a + pj * vv[i];
-      m = mn;
+      for (int i = 0; i < 8; ++i) sdot = fmaf(q[i], kk[u][i], sdot);
+      sdot += __shfl_xor(sdot, 1, 64);
+      sdot += __shfl_xor(sdot, 2, 64);
+      sdot += __shfl_xor(sdot, 4, 64);
+      if (j <= p) {
+        const float mn = fmaxf(m, sdot);
+        const float a = expf(m - mn);  // exp(-inf) = 0 on the first key
+        const float pj = expf(sdot - mn);
+        l = l * a + pj;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = o[i] * a + pj * vv[u][i];
+        m = mn;
+      }
     }
   }
   // merge the 8 key slots (lanes differing in bits 3..5)
@@ -189,7 +197,8 @@ struct CrossP {
   const uint8_t* kmask;
   const int32_t* tiles;
   void* out; int64_t ldo;
-  int M, nH;
+  float* partial;
+  int M, nH, R;
 };
 
 template <typename T>
@@ -235,10 +244,13 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int t = blockIdx.x, h = blockIdx.y;
   const int row0 = p.tiles[t * 3], nrows = p.tiles[t * 3 + 1], img = p.tiles[t * 3 + 2];
-  // the NW waves of the workgroup split the keys; every wave keeps flash-style running (m, l, o)
-  int kpw = (p.M + NW - 1) / NW;
+  // keys are cut in S * NW slices: S workgroups (blockIdx.z) x NW waves; every wave keeps flash-style
+  // running (m, l, o); the NW slices of a workgroup merge in LDS, the S workgroup results (if S > 1)
+  // go through a small fp32 partial buffer and dec_cross_merge_kernel.
+  const int S = gridDim.z, sp = blockIdx.z;
+  int kpw = (p.M + S * NW - 1) / (S * NW);
   kpw = ((kpw + CT::KB - 1) / CT::KB) * CT::KB;
-  const int kbeg = wave * kpw;
+  const int kbeg = (sp * NW + wave) * kpw;
   int kend = kbeg + kpw;
   if (kend > p.M) kend = p.M;
 
@@ -344,8 +356,39 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
       L += pw[1] * wt;
       o += pw[4 + lane] * wt;
     }
-    out[(int64_t)(row0 + qi) * p.ldo + h * DH + lane] = from_f32<T>(o / L);
+    if (S == 1) {
+      out[(int64_t)(row0 + qi) * p.ldo + h * DH + lane] = from_f32<T>(o / L);
+    } else {
+      float* dst = p.partial + (((int64_t)(row0 + qi) * p.nH + h) * S + sp) * PSTR;
+      if (lane == 0) { dst[0] = mall; dst[1] = L; }
+      dst[4 + lane] = o;
+    }
   }
+}
+
+// merge the S workgroup-level partials of every (row, head): one wave each, lane = output dim.
+// All loads are issued before any math (S <= 16) -- the merge is a latency-, not a bandwidth problem.
+template <typename T, int S>
+__global__ __launch_bounds__(256) void dec_cross_merge_kernel(const float* __restrict__ partial, T* __restrict__ out,
+                                                              int64_t ldo, int nH, int total) {
+  const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= total) return;
+  const int r = wid / nH, h = wid % nH;
+  const float* base = partial + (int64_t)wid * S * 68;
+  float mv[S], lv[S], ov[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) { mv[s] = base[s * 68]; lv[s] = base[s * 68 + 1]; ov[s] = base[s * 68 + 4 + lane]; }
+  float mall = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < S; ++s) mall = fmaxf(mall, mv[s]);
+  float L = 0.f, o = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const float w = (mv[s] == -INFINITY) ? 0.f : expf(mv[s] - mall);
+    L += lv[s] * w;
+    o += ov[s] * w;
+  }
+  out[(int64_t)r * ldo + h * DH + lane] = from_f32<T>(o / L);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -416,25 +459,34 @@ std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
 size_t g_prof_used = 0;
 
 template <typename T, int NW>
-int launch_cross_t(const CrossP& cp, int n_tiles, hipStream_t st) {
+int launch_cross_t(const CrossP& cp, int n_tiles, int S, hipStream_t st) {
   const size_t smem = (size_t)NW * 16 * 68 * sizeof(float);
-  auto kern = dec_cross_attn_kernel<T, NW>;
-  if (smem > 48 * 1024) {
-    static bool done = false;
-    if (!done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
-        omp_set_error("omp_dec_cross_attn_step: cannot raise dynamic LDS limit");
-        return OMP_ERR_LAUNCH;
-      }
-      done = true;
-    }
-  }
-  hipLaunchKernelGGL(kern, dim3(n_tiles, cp.nH), dim3(NW * 64), smem, st, cp);
+  hipLaunchKernelGGL((dec_cross_attn_kernel<T, NW>), dim3(n_tiles, cp.nH, S), dim3(NW * 64), smem, st, cp);
   return OMP_OK;
 }
 
-// n_waves: key slices per (tile, head) workgroup, rounded down to a power of two in [1, 16]
-int launch_cross(const CrossP& cp, int n_tiles, int dtype, int n_waves, hipStream_t st) {
+template <typename T>
+int launch_merge(const CrossP& cp, int S, hipStream_t st) {
+  const int total = cp.R * cp.nH;
+  dim3 grid((total + 3) / 4), block(256);
+  T* out = reinterpret_cast<T*>(cp.out);
+  switch (S) {
+    case 2: hipLaunchKernelGGL((dec_cross_merge_kernel<T, 2>), grid, block, 0, st, cp.partial, out, cp.ldo, cp.nH, total); break;
+    case 4: hipLaunchKernelGGL((dec_cross_merge_kernel<T, 4>), grid, block, 0, st, cp.partial, out, cp.ldo, cp.nH, total); break;
+    case 8: hipLaunchKernelGGL((dec_cross_merge_kernel<T, 8>), grid, block, 0, st, cp.partial, out, cp.ldo, cp.nH, total); break;
+    case 16: hipLaunchKernelGGL((dec_cross_merge_kernel<T, 16>), grid, block, 0, st, cp.partial, out, cp.ldo, cp.nH, total); break;
+    default: omp_set_error("omp_dec_cross_attn_step: unsupported workgroup split %d", S); return OMP_ERR_INVALID;
+  }
+  return OMP_OK;
+}
+
+// n_split = total key slices per (tile, head), a power of two in [1, 64]: NW = min(n_split, 4) waves per
+// workgroup (merged in LDS) x S = n_split / NW workgroups (merged by dec_cross_merge_kernel).
+int launch_cross(const CrossP& cp, int n_tiles, int dtype, int n_split, hipStream_t st) {
+  int ns = 1;
+  while (ns * 2 <= n_split && ns < 64) ns *= 2;
+  const int NW = ns < 4 ? ns : 4, S = ns / NW;
+  if (S > 1 && cp.partial == nullptr) { omp_set_error("omp_dec_cross_attn_step: n_split %d needs a partial buffer", n_split); return OMP_ERR_INVALID; }
   const bool prof = g_prof && !g_capturing;
   if (prof) {
     if (g_prof_used == g_prof_ev.size()) {
@@ -446,14 +498,17 @@ int launch_cross(const CrossP& cp, int n_tiles, int dtype, int n_waves, hipStrea
   }
   int rc;
   const bool f = dtype == OMP_F32;
-  if (n_waves >= 16) rc = f ? launch_cross_t<float, 16>(cp, n_tiles, st) : launch_cross_t<bf16_t, 16>(cp, n_tiles, st);
-  else if (n_waves >= 8) rc = f ? launch_cross_t<float, 8>(cp, n_tiles, st) : launch_cross_t<bf16_t, 8>(cp, n_tiles, st);
-  else if (n_waves >= 4) rc = f ? launch_cross_t<float, 4>(cp, n_tiles, st) : launch_cross_t<bf16_t, 4>(cp, n_tiles, st);
-  else if (n_waves >= 2) rc = f ? launch_cross_t<float, 2>(cp, n_tiles, st) : launch_cross_t<bf16_t, 2>(cp, n_tiles, st);
-  else rc = f ? launch_cross_t<float, 1>(cp, n_tiles, st) : launch_cross_t<bf16_t, 1>(cp, n_tiles, st);
+  if (NW == 4) rc = f ? launch_cross_t<float, 4>(cp, n_tiles, S, st) : launch_cross_t<bf16_t, 4>(cp, n_tiles, S, st);
+  else if (NW == 2) rc = f ? launch_cross_t<float, 2>(cp, n_tiles, S, st) : launch_cross_t<bf16_t, 2>(cp, n_tiles, S, st);
+  else rc = f ? launch_cross_t<float, 1>(cp, n_tiles, S, st) : launch_cross_t<bf16_t, 1>(cp, n_tiles, S, st);
   if (rc != OMP_OK) return rc;
   if (prof) (void)hipEventRecord(g_prof_ev[g_prof_used++].second, st);
   OMP_CHECK_LAUNCH("omp_dec_cross_attn_step");
+  if (S > 1) {
+    rc = f ? launch_merge<float>(cp, S, st) : launch_merge<bf16_t>(cp, S, st);
+    if (rc != OMP_OK) return rc;
+    OMP_CHECK_LAUNCH("omp_dec_cross_attn_step(merge)");
+  }
   return OMP_OK;
 }
 
@@ -497,15 +552,15 @@ extern "C" int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K
                                        int64_t vt_batch_stride, const uint8_t* key_mask,
                                        const int32_t* tiles, int n_tiles, int R, float* partial, void* out,
                                        int64_t ldo, int dtype, int M, int nH, int n_split, omp_stream_t s) {
-  (void)partial; (void)R;
   OMP_CHECK_ARG(q && K && Vt && tiles && out, "omp_dec_cross_attn_step: null pointer");
+  OMP_CHECK_ARG(R > 0, "omp_dec_cross_attn_step: bad R");
   OMP_CHECK_ARG(dtype == OMP_F32 || dtype == OMP_BF16, "omp_dec_cross_attn_step: bad dtype");
   OMP_CHECK_ARG(n_tiles > 0 && n_split > 0 && M > 0, "omp_dec_cross_attn_step: bad sizes");
   OMP_CHECK_ARG(ldvt % 32 == 0 && ldvt >= M, "omp_dec_cross_attn_step: ldvt must be a multiple of 32 and >= M (got %lld)", (long long)ldvt);
   CrossP cp;
   cp.q = q; cp.ldq = ldq; cp.K = K; cp.ldk = ldk; cp.kbs = k_batch_stride;
   cp.Vt = Vt; cp.ldvt = ldvt; cp.vbs = vt_batch_stride; cp.kmask = key_mask; cp.tiles = tiles;
-  cp.out = out; cp.ldo = ldo; cp.M = M; cp.nH = nH;
+  cp.out = out; cp.ldo = ldo; cp.partial = partial; cp.M = M; cp.nH = nH; cp.R = R;
   return launch_cross(cp, n_tiles, dtype, n_split, (hipStream_t)s);
 }
 
@@ -566,7 +621,7 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
   CrossP cp;
   cp.q = P->q; cp.ldq = d; cp.ldk = P->ldk; cp.kbs = P->k_batch_stride; cp.ldvt = P->ldvt;
   cp.vbs = P->vt_batch_stride; cp.kmask = P->key_mask; cp.tiles = P->tiles; cp.out = P->att; cp.ldo = d;
-  cp.M = P->M; cp.nH = P->n_heads;
+  cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R;
   for (int li = 0; li < P->n_layers; ++li) {
     const omp_dec_layer& L = P->layers[li];
     cp.K = L.crossK; cp.Vt = L.crossVt;

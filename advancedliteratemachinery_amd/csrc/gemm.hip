@@ -18,6 +18,7 @@
 
 namespace {
 
+int g_prefetch = 2;      // K tiles of register prefetch in gemm_tiled (1 or 2)
 int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows, 4 small split-K (debug/testing)
 
 struct GemmP {
@@ -99,7 +100,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return start + idx;
 }
 
-template <typename T, typename TOut, int BM, int BN>
+template <typename T, typename TOut, int BM, int BN, int PF>
 __global__ __launch_bounds__(256) void gemm_tiled(GemmP p) {
   typedef Mma<T> MM;
   typedef typename MM::frag frag;
@@ -149,30 +150,29 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmP p) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  frag ra[ACH], rw[WCH];
+  // Register prefetch two K tiles ahead (two alternating register sets), LDS double-buffered, ONE barrier
+  // per tile: the global loads of tile t+2 are issued before tile t is computed and are written to LDS only
+  // at the end of iteration t+1, so every load has two compute phases to land (small tiles are otherwise
+  // bound by one memory round trip per K tile).
+  frag ra0[ACH], rw0[WCH], ra1[ACH], rw1[WCH];
   const int nk = p.K / KT;
+  auto gload = [&](int kt, frag* ra, frag* rw) {
+    const int koff = kt * KT;
 #pragma unroll
-  for (int i = 0; i < ACH; ++i) ra[i] = ld16<T>(a_src[i]);
+    for (int i = 0; i < ACH; ++i) ra[i] = ld16<T>(a_src[i] + koff);
 #pragma unroll
-  for (int i = 0; i < WCH; ++i) rw[i] = ld16<T>(w_src[i]);
+    for (int i = 0; i < WCH; ++i) rw[i] = ld16<T>(w_src[i] + koff);
+  };
+  auto lwrite = [&](int buf, const frag* ra, const frag* rw) {
 #pragma unroll
-  for (int i = 0; i < ACH; ++i) *reinterpret_cast<frag*>(smem + a_dst[i]) = ra[i];
+    for (int i = 0; i < ACH; ++i) *reinterpret_cast<frag*>(smem + buf * BUF + a_dst[i]) = ra[i];
 #pragma unroll
-  for (int i = 0; i < WCH; ++i) *reinterpret_cast<frag*>(smem + BM * ROWB + w_dst[i]) = rw[i];
-  __syncthreads();
-
+    for (int i = 0; i < WCH; ++i) *reinterpret_cast<frag*>(smem + buf * BUF + BM * ROWB + w_dst[i]) = rw[i];
+  };
   const int lrow = lane & 15, lg = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      const int koff = (kt + 1) * KT;
-#pragma unroll
-      for (int i = 0; i < ACH; ++i) ra[i] = ld16<T>(a_src[i] + koff);
-#pragma unroll
-      for (int i = 0; i < WCH; ++i) rw[i] = ld16<T>(w_src[i] + koff);
-    }
-    const char* as = smem + cur * BUF + (wm * (BM / 2)) * ROWB;
-    const char* ws = smem + cur * BUF + BM * ROWB + (wn * (BN / 2)) * ROWB;
+  auto compute = [&](int buf) {
+    const char* as = smem + buf * BUF + (wm * (BM / 2)) * ROWB;
+    const char* ws = smem + buf * BUF + BM * ROWB + (wn * (BN / 2)) * ROWB;
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       frag fw[FN], fx[FM];
@@ -192,14 +192,34 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmP p) {
 #pragma unroll
         for (int j = 0; j < FM; ++j) MM::mma(acc[i][j], fw[i], fx[j]);
     }
-    if (kt + 1 < nk) {
-      const int nxt = cur ^ 1;
-#pragma unroll
-      for (int i = 0; i < ACH; ++i) *reinterpret_cast<frag*>(smem + nxt * BUF + a_dst[i]) = ra[i];
-#pragma unroll
-      for (int i = 0; i < WCH; ++i) *reinterpret_cast<frag*>(smem + nxt * BUF + BM * ROWB + w_dst[i]) = rw[i];
-    }
+  };
+  if constexpr (PF == 2) {
+    gload(0, ra0, rw0);
+    if (nk > 1) gload(1, ra1, rw1);
+    lwrite(0, ra0, rw0);
     __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 2 < nk) gload(kt + 2, ra0, rw0);
+      compute(0);
+      if (kt + 1 < nk) lwrite(1, ra1, rw1);
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      if (kt + 3 < nk) gload(kt + 3, ra1, rw1);
+      compute(1);
+      if (kt + 2 < nk) lwrite(0, ra0, rw0);
+      __syncthreads();
+    }
+  } else {
+    // one tile ahead (fewer registers -> 2 workgroups per CU for the 128x128 tile)
+    gload(0, ra0, rw0);
+    lwrite(0, ra0, rw0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) gload(kt + 1, ra0, rw0);
+      compute(kt & 1);
+      if (kt + 1 < nk) lwrite((kt + 1) & 1, ra0, rw0);
+      __syncthreads();
+    }
   }
 
   const float* bias = p.bias;
@@ -271,6 +291,14 @@ __global__ __launch_bounds__(256) void gemm_small(GemmP p) {
   const T* wp = reinterpret_cast<const T*>(p.W) + (int64_t)gn * p.ldw + lg * MM::KPL;
   const int KQ = p.K / 4, kbeg = wave * KQ;
   const int astride = p.K * (int)sizeof(T) + 16;
+  const int nsteps = KQ / MM::KSTEP;   // 4 (K=512 bf16) .. 16 (K=2048 bf16 / K=1024 f32)
+  constexpr int PF = 8;                // W fragments in flight per wave
+  // the weight stream does not depend on anything computed here: issue it first so its latency hides
+  // under the LayerNorm prologue / activation loads
+  frag fw[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+    if (u < nsteps) fw[u] = ld16<T>(wp + kbeg + u * MM::KSTEP);
 
   if constexpr (LN) {
     const float* X = reinterpret_cast<const float*>(p.A);
@@ -335,23 +363,29 @@ __global__ __launch_bounds__(256) void gemm_small(GemmP p) {
   f32x4 acc[MF];
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nsteps = KQ / MM::KSTEP;
-  for (int s0 = 0; s0 < nsteps; s0 += 4) {
-    frag fw[4];
+  for (int s0 = 0; s0 < nsteps; s0 += PF) {
+    if (s0 > 0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (s0 + u < nsteps) fw[u] = ld16<T>(wp + kbeg + (s0 + u) * MM::KSTEP);
+      for (int u = 0; u < PF; ++u)
+        if (s0 + u < nsteps) fw[u] = ld16<T>(wp + kbeg + (s0 + u) * MM::KSTEP);
+    }
+    frag fx[PF][MF];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PF; ++u) {
       if (s0 + u < nsteps) {
         const int k = kbeg + (s0 + u) * MM::KSTEP;
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
-          frag fx;
-          if constexpr (LN) fx = *reinterpret_cast<const frag*>(alds + (mf * 16 + lrow) * astride + (k + lg * MM::KPL) * (int)sizeof(T));
-          else fx = ld16<T>(xp[mf] + k);
-          MM::mma(acc[mf], fw[u], fx);
+          if constexpr (LN) fx[u][mf] = *reinterpret_cast<const frag*>(alds + (mf * 16 + lrow) * astride + (k + lg * MM::KPL) * (int)sizeof(T));
+          else fx[u][mf] = ld16<T>(xp[mf] + k);
         }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (s0 + u < nsteps) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) MM::mma(acc[mf], fw[u], fx[u][mf]);
       }
     }
   }
@@ -424,16 +458,23 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
     hipLaunchKernelGGL((gemm_rows<T, TOut>), grid, dim3(256), 0, st, p);
   } else if (which == 2) {
     p.tiles_m = (int)ceil_div64(p.M, 64); p.tiles_n = (int)ceil_div64(p.N, 64);
-    hipLaunchKernelGGL((gemm_tiled<T, TOut, 64, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    if (g_prefetch == 2) hipLaunchKernelGGL((gemm_tiled<T, TOut, 64, 64, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_tiled<T, TOut, 64, 64, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
   } else {
     p.tiles_m = (int)ceil_div64(p.M, 128); p.tiles_n = (int)ceil_div64(p.N, 128);
-    hipLaunchKernelGGL((gemm_tiled<T, TOut, 128, 128>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    if (g_prefetch == 2) hipLaunchKernelGGL((gemm_tiled<T, TOut, 128, 128, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_tiled<T, TOut, 128, 128, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
   }
   OMP_CHECK_LAUNCH("omp_gemm_bias_act");
   return OMP_OK;
 }
 
 }  // namespace
+
+extern "C" int omp_debug_set_gemm_prefetch(int tiles) {
+  g_prefetch = tiles == 1 ? 1 : 2;
+  return OMP_OK;
+}
 
 extern "C" int omp_debug_force_gemm_kernel(int which) {
   g_force_kernel = which;

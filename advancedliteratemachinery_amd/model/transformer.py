@@ -62,7 +62,7 @@ class _Phase(object):
         self.y, self.att, self.q, self.hh0, self.hh1 = e(R, d), e(R, d), e(R, d), e(R, d), e(R, d)
         self.qkv, self.ffh = e(R, 3 * d), e(R, ff)
         self.logits = e(R, V, dtype=torch.float32)
-        self.partial = e(16, dtype=torch.float32)   # unused since the in-workgroup LDS merge (ABI field kept)
+        self.partial = e(R, nH, max(1, n_split // 4), 68, dtype=torch.float32)   # workgroup-level partials
         self.kc = [e(R, Lmax, d) for _ in range(L)]
         self.vc = [e(R, Lmax, d) for _ in range(L)]
         self.plan = _lib.DecoderPlan()
@@ -194,6 +194,15 @@ class Decoder(object):
         ph._keepalive = (kv['K'], kv['Vt'], kv['key_mask'])
         return P
 
+    _next_slot = [0]   # graph slots live in the shared library: ids must be unique per PROCESS
+
+    def __del__(self):
+        try:
+            for slot in self._graph_slots.values():
+                _lib.lib().omp_decoder_graph_reset(slot)
+        except Exception:
+            pass
+
     def _slot(self, plan):
         # stream capture is illegal on the legacy null stream: graphs only when the caller runs us on a
         # real stream (bench / predict do), eager launches otherwise
@@ -201,7 +210,8 @@ class Decoder(object):
             return -1
         key = bytes(plan)
         if key not in self._graph_slots:
-            self._graph_slots[key] = len(self._graph_slots)
+            self._graph_slots[key] = Decoder._next_slot[0]
+            Decoder._next_slot[0] += 1
         return self._graph_slots[key]
 
     def _run(self, ph, first_pos, n_steps):
@@ -211,11 +221,18 @@ class Decoder(object):
         _lib.check(rc, 'omp_decoder_run')
 
     def _n_split(self, n_tiles, M):
-        """Waves per (tile, head) workgroup of the cross-attention kernel = key slices merged in LDS:
-        aim for ~1024 waves in flight, power of two in [1, 16], at least one key block per wave."""
+        """Key slices per (tile, head) of the cross-attention kernel: up to 4 waves per workgroup (merged in
+        LDS) x S workgroups (merged by a small kernel).  Aim for >= 512 workgroups so that all 256 CUs pull
+        from HBM; power of two, at least one key block per slice."""
         kb = 16 if self.dtype == torch.float32 else 32
-        want = max(1, min(16, 1024 // max(1, n_tiles * self.nH), (M + kb - 1) // kb))
-        return 1 << (want.bit_length() - 1)
+        wgs = max(1, n_tiles * self.nH)
+        S = 1
+        while wgs * S < 512 and S < 16:
+            S *= 2
+        ns = 4 * S
+        while ns > 1 and ns * kb > M:
+            ns //= 2
+        return ns
 
     # -- greedy drivers ---------------------------------------------------------------------------
     def decode_points(self, kv, prompt, max_new=None, forced_instances=None, poll=16):

@@ -239,6 +239,7 @@ int omp_decoder_graph_reset(int graph_slot);
 int omp_prof_enable(int on);
 int omp_prof_read(double* total_ms, int64_t* count);
 int omp_debug_force_gemm_kernel(int which);
+int omp_debug_set_gemm_prefetch(int tiles);
 
 /* Single teacher-forced step that also leaves logits in plan->logits (parity tests). */
 int omp_decoder_step_logits(const omp_decoder_plan* plan, int pos, omp_stream_t s);
