@@ -10,6 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16 = 0, 1
+ABI_VERSION = 2
+STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
 MAX_DEC_LAYERS = 8
@@ -25,7 +27,9 @@ class GemmArgs(ctypes.Structure):
                 ('M', c_int64), ('N', c_int32), ('K', c_int32), ('dtype', c_int32),
                 ('out_dtype', c_int32), ('act', c_int32), ('trans_out', c_int32),
                 ('trans_rows', c_int64), ('trans_ld', c_int64), ('ln_gamma', c_void_p), ('ln_beta', c_void_p),
-                ('ln_eps', c_float), ('small_m_splitk', c_int32)]
+                ('ln_eps', c_float), ('small_m_splitk', c_int32), ('store_mode', c_int32), ('bias_along_m', c_int32),
+                ('kv_images', c_int32), ('kv_tokens', c_int32), ('kv_mpad', c_int32), ('kv_heads', c_int32),
+                ('kv_key_block', c_int32)]
 
 
 class SampleCfg(ctypes.Structure):
@@ -43,11 +47,11 @@ class DecLayer(ctypes.Structure):
 
 class DecoderPlan(ctypes.Structure):
     _fields_ = ([(n, c_int32) for n in ('dtype', 'n_layers', 'd_model', 'n_heads', 'd_ff', 'vocab',
-                                        'pre_norm', 'R', 'Lmax', 'M', 'n_tiles', 'n_split', 'n_prompt')]
+                                        'pre_norm', 'R', 'Lmax', 'M', 'Mpad', 'n_tiles', 'q_tiles', 'n_split', 'n_prompt')]
                 + [('eps', c_float), ('layers', DecLayer * MAX_DEC_LAYERS)]
                 + [(n, c_void_p) for n in ('word_emb', 'pos_tab', 'emb_g', 'emb_b', 'fn_g', 'fn_b',
                                            'h0_w', 'h1_w', 'h2_w', 'h0_b', 'h1_b', 'h2_b')]
-                + [(n, c_int64) for n in ('ldk', 'k_batch_stride', 'ldvt', 'vt_batch_stride')]
+                + [('kv_img_stride', c_int64)]
                 + [('key_mask', c_void_p), ('tiles', c_void_p), ('seq', c_void_p), ('seq_ld', c_int32),
                    ('d_pos', c_void_p), ('probs', c_void_p), ('finished', c_void_p), ('lengths', c_void_p)]
                 + [(n, c_void_p) for n in ('x', 'x2', 'y', 'qkv', 'att', 'q', 'ffh', 'hh0', 'hh1',
@@ -67,9 +71,9 @@ _SIGS = {
     'omp_sine_posembed': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     'omp_dec_embed_ln': (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_void_p]),
     'omp_dec_self_attn_step': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
-    'omp_dec_cross_attn_step': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
-                                        c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
-                                        c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    'omp_dec_cross_attn_step': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                        c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                        c_int, c_void_p]),
     'omp_head_softmax_mask_argmax': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(SampleCfg), c_void_p,
                                              c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'omp_decoder_run': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_int, c_int, c_void_p]),
@@ -77,6 +81,7 @@ _SIGS = {
     'omp_decoder_step_logits': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_void_p]),
     'omp_debug_force_gemm_kernel': (c_int, [c_int]),
     'omp_debug_set_gemm_prefetch': (c_int, [c_int]),
+    'omp_debug_swin_attn_impl': (c_int, [c_int]),
     'omp_prof_enable': (c_int, [c_int]),
     'omp_prof_read': (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
 }
@@ -100,7 +105,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.omp_abi_version() != 1:
+        if h.omp_abi_version() != ABI_VERSION:
             raise RuntimeError('libomp355.so ABI version mismatch')
         _lib = h
     return _lib

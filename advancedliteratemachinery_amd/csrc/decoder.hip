@@ -183,42 +183,46 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// cross attention, flash-style partials on the matrix cores: one wave per (tile, head, key split)
+// cross attention over the image memory, flash-style on the matrix cores.
+//
+// Memory layout (written by the K/V projection GEMM epilogues, OMP_STORE_KBLK / OMP_STORE_VBLK):
+//   K   [image][head][Mpad][64]            one contiguous M x 128 B (bf16) stream per (image, head)
+//   V^T [image][head][Mpad/KB][64][KB]     the same bytes again, blocked by KB keys so that the 16-byte
+//                                          A-operand fragment of the PV product is one aligned load
+// One workgroup = (query group, head, key split z); its NW waves cut the split's keys again; every
+// wave streams its key range ONCE (16-byte loads, PD key blocks in flight in a register ring) and
+// applies it to up to QT tiles of 16 queries of that image:
 //   S^T[key][query] = K[key,:] . Q[query,:]        (A operand = K rows, B operand = Q rows)
 //   O^T[d][query]  += V^T[d][key] * P[key][query]   (A operand = V^T rows, B operand = P)
 // The S^T accumulator layout (lane: query = l&15, keys 4*(l>>4)+r) IS the B-operand layout of the
-// second product once the k-slots are mapped to keys {k0+4g+r} (and {k0+16+4g+r} for bf16), so the
-// probabilities never leave registers; V^T rows are read with the same key permutation.
+// second product once the k-slots are mapped to keys {k0+4g+r} (and {k0+16+4g+r} for bf16), which is the
+// order V^T blocks are stored in, so the probabilities never leave registers.
+// The NW key slices merge in LDS; S > 1 workgroup splits go through a small fp32 partial buffer and
+// dec_cross_merge_kernel.  All queries of an image share its K/V: the memory is never replicated
+// (reference: memory.repeat(1, N, 1), transformer.py:88-96).
 // ---------------------------------------------------------------------------------------------
 struct CrossP {
   const void* q; int64_t ldq;
-  const void* K; int64_t ldk, kbs;
-  const void* Vt; int64_t ldvt, vbs;
+  const void* K; const void* V;   // this layer's slabs
+  int64_t img_stride;             // elements between images: nH * Mpad * 64 (K and V^T alike)
   const uint8_t* kmask;
-  const int32_t* tiles;
+  const int32_t* groups;          // {row0, nrows (<= 16*QT), image}
   void* out; int64_t ldo;
   float* partial;
-  int M, nH, R;
+  int M, Mpad, nH, R, kpw;        // kpw: keys per wave, multiple of the key block
 };
 
 template <typename T>
 struct CrossTraits;
 template <>
 struct CrossTraits<bf16_t> {
-  static constexpr int KB = 32;   // keys per iteration
-  static constexpr int NSB = 2;   // 16-key score blocks per iteration
+  static constexpr int KB = 32;   // keys per block
+  static constexpr int NSB = 2;   // 16-key score blocks per key block
   static constexpr int DSTEPS = 2;  // 64 dims / 32
   __device__ static __forceinline__ bf16x8 pfrag(const float* p) {
     bf16x8 f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) f[i] = (bf16_t)p[i];
-    return f;
-  }
-  // V^T row fragment: keys {k0+4g..+3} and {k0+16+4g..+3}
-  __device__ static __forceinline__ bf16x8 vfrag(const bf16_t* vrow, int k0, int g) {
-    const bf16x4 a = *reinterpret_cast<const bf16x4*>(vrow + k0 + 4 * g);
-    const bf16x4 b = *reinterpret_cast<const bf16x4*>(vrow + k0 + 16 + 4 * g);
-    bf16x8 f = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return f;
   }
 };
@@ -228,130 +232,160 @@ struct CrossTraits<float> {
   static constexpr int NSB = 1;
   static constexpr int DSTEPS = 4;  // 64 dims / 16
   __device__ static __forceinline__ f32x4 pfrag(const float* p) { return f32x4{p[0], p[1], p[2], p[3]}; }
-  __device__ static __forceinline__ f32x4 vfrag(const float* vrow, int k0, int g) {
-    return *reinterpret_cast<const f32x4*>(vrow + k0 + 4 * g);
-  }
 };
 
-template <typename T, int NW>
+constexpr int CROSS_PSTR = 68;   // m, l, pad, pad, o[64]
+
+template <typename T, int NW, int QT, int PD>
 __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
   typedef Mma<T> MM;
   typedef CrossTraits<T> CT;
   typedef typename MM::frag frag;
+  constexpr int KB = CT::KB;
   constexpr int NKF = CT::NSB * CT::DSTEPS;
-  constexpr int PSTR = 68;                                       // m, l, pad, pad, o[64]
-  extern __shared__ __attribute__((aligned(16))) float part[];   // [NW][16 queries][PSTR]
+  constexpr int PSTR = CROSS_PSTR;
+  extern __shared__ __attribute__((aligned(16))) float part[];   // [NW][QT*16 queries][PSTR]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
-  const int t = blockIdx.x, h = blockIdx.y;
-  const int row0 = p.tiles[t * 3], nrows = p.tiles[t * 3 + 1], img = p.tiles[t * 3 + 2];
-  // keys are cut in S * NW slices: S workgroups (blockIdx.z) x NW waves; every wave keeps flash-style
-  // running (m, l, o); the NW slices of a workgroup merge in LDS, the S workgroup results (if S > 1)
-  // go through a small fp32 partial buffer and dec_cross_merge_kernel.
+  const int grp = blockIdx.x, h = blockIdx.y;
+  const int row0 = p.groups[grp * 3], nrows = p.groups[grp * 3 + 1], img = p.groups[grp * 3 + 2];
+  const int nqt = (nrows + 15) >> 4;
   const int S = gridDim.z, sp = blockIdx.z;
-  int kpw = (p.M + S * NW - 1) / (S * NW);
-  kpw = ((kpw + CT::KB - 1) / CT::KB) * CT::KB;
-  const int kbeg = (sp * NW + wave) * kpw;
-  int kend = kbeg + kpw;
+  const int kbeg = (sp * NW + wave) * p.kpw;
+  int kend = kbeg + p.kpw;
   if (kend > p.M) kend = p.M;
+  const int nblk = kbeg < kend ? (kend - kbeg + KB - 1) / KB : 0;
 
-  // Q fragments (B operand): query li (clamped), dims s*KSTEP + g*KPL ..
-  const int qrow = row0 + (li < nrows ? li : nrows - 1);
-  const T* qp = reinterpret_cast<const T*>(p.q) + (int64_t)qrow * p.ldq + h * DH + g * MM::KPL;
-  frag qf[CT::DSTEPS];
-#pragma unroll
-  for (int s = 0; s < CT::DSTEPS; ++s) {
-    float tmp[MM::KPL];
-    unpack16(ld16<T>(qp + s * MM::KSTEP), tmp);
-#pragma unroll
-    for (int i = 0; i < MM::KPL; ++i) tmp[i] *= 0.125f;
-    pack16(tmp, qf[s]);
-  }
-  const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)img * p.kbs + h * DH + g * MM::KPL;
-  const T* Vb = reinterpret_cast<const T*>(p.Vt) + (int64_t)img * p.vbs + (int64_t)(h * DH + li) * p.ldvt;
+  // K / V^T fragment addresses of this lane inside the (image, head) slabs
+  const int64_t slab = (int64_t)img * p.img_stride + (int64_t)h * p.Mpad * 64;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + slab + li * 64 + g * MM::KPL;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + slab + li * KB + g * MM::KPL;
   const uint8_t* km = p.kmask ? p.kmask + (int64_t)img * p.M : nullptr;
 
-  float m = -INFINITY, lpart = 0.f;
-  f32x4 ot[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  frag kc[NKF], vc[4], kn[NKF], vn[4];
+  frag kr[PD][NKF], vr[PD][4];
   auto load_block = [&](int k0, frag* kf, frag* vf) {
+    const T* kp = Kb + (int64_t)k0 * 64;
 #pragma unroll
-    for (int sb = 0; sb < CT::NSB; ++sb) {
-      int key = k0 + sb * 16 + li;           // A operand row = key (clamped; masked below)
-      if (key > p.M - 1) key = p.M - 1;
-      const T* kr = Kb + (int64_t)key * p.ldk;
+    for (int sb = 0; sb < CT::NSB; ++sb)
 #pragma unroll
-      for (int s = 0; s < CT::DSTEPS; ++s) kf[sb * CT::DSTEPS + s] = ld16<T>(kr + s * MM::KSTEP);
-    }
+      for (int s = 0; s < CT::DSTEPS; ++s) kf[sb * CT::DSTEPS + s] = ld16<T>(kp + sb * 16 * 64 + s * MM::KSTEP);
+    const T* vp = Vb + (int64_t)k0 * 64;   // block k0/KB starts at element (k0/KB) * 64 * KB = k0 * 64
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) vf[dt] = CT::vfrag(Vb + (int64_t)(dt * 16) * p.ldvt, k0, g);
+    for (int dt = 0; dt < 4; ++dt) vf[dt] = ld16<T>(vp + dt * 16 * KB);
   };
-  if (kbeg < kend) load_block(kbeg, kc, vc);
-  for (int k0 = kbeg; k0 < kend; k0 += CT::KB) {
-    const bool more = k0 + CT::KB < kend;
-    if (more) load_block(k0 + CT::KB, kn, vn);   // next block's loads fly under this block's math
-    float sc[CT::NSB * 4];
-    float bmax = -INFINITY;
+  // the K/V stream depends on nothing computed here: put PD key blocks in flight before touching Q
 #pragma unroll
-    for (int sb = 0; sb < CT::NSB; ++sb) {
-      f32x4 st = {0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < PD; ++u)
+    if (u < nblk) load_block(kbeg + u * KB, kr[u], vr[u]);
+
+  // Q fragments (B operand) of the QT query tiles: query li of the tile (clamped), dims s*KSTEP + g*KPL ..
+  frag qf[QT][CT::DSTEPS];
 #pragma unroll
-      for (int s = 0; s < CT::DSTEPS; ++s) MM::mma(st, kc[sb * CT::DSTEPS + s], qf[s]);
+  for (int t = 0; t < QT; ++t) {
+    int qi = t * 16 + li;
+    if (qi > nrows - 1) qi = nrows - 1;
+    const T* qp = reinterpret_cast<const T*>(p.q) + (int64_t)(row0 + qi) * p.ldq + h * DH + g * MM::KPL;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kk = k0 + sb * 16 + g * 4 + r;  // this lane's key for acc[r]
-        float v = st[r];
-        if (kk >= kend || (km != nullptr && km[kk])) v = -INFINITY;
-        sc[sb * 4 + r] = v;
-        bmax = fmaxf(bmax, v);
-      }
-    }
-    bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
-    bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
-    const float mn = fmaxf(m, bmax);
-    // no branch here: MFMAs below must run with a full EXEC mask.  If every key seen so far is
-    // masked (mn = -inf) use 0 as the reference so exp(-inf - 0) = 0 instead of NaN.
-    const float mref = (mn == -INFINITY) ? 0.f : mn;
-    const float alpha = expf(m - mref);
-    float ps = 0.f;
+    for (int s = 0; s < CT::DSTEPS; ++s) {
+      float tmp[MM::KPL];
+      unpack16(ld16<T>(qp + s * MM::KSTEP), tmp);
 #pragma unroll
-    for (int i = 0; i < CT::NSB * 4; ++i) { sc[i] = expf(sc[i] - mref); ps += sc[i]; }
-    lpart = lpart * alpha + ps;
-    m = mn;
-    const frag pf = CT::pfrag(sc);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
-      MM::mma(ot[dt], vc[dt], pf);
-    }
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < NKF; ++i) kc[i] = kn[i];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) vc[i] = vn[i];
+      for (int i = 0; i < MM::KPL; ++i) tmp[i] *= 0.125f;   // 1/sqrt(64) on q, like nn.MultiheadAttention
+      pack16(tmp, qf[t][s]);
     }
   }
-  float l = lpart;
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  // merge the NW key slices of this (tile, head) in LDS -- no partial buffer, no combine launch
-  float* mine = part + (wave * 16 + li) * PSTR;
-  if (g == 0) { mine[0] = m; mine[1] = l; }
+
+  float m[QT], lpart[QT];
+  f32x4 ot[QT][4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(mine + 4 + dt * 16 + g * 4) = ot[dt];
+  for (int t = 0; t < QT; ++t) {
+    m[t] = -INFINITY; lpart[t] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ot[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  auto compute = [&](int k0, const frag* kc, const frag* vc) {
+    // which of this lane's 4 (8) keys are masked: key padding mask + the end of the slice
+    bool dead[CT::NSB * 4];
+#pragma unroll
+    for (int sb = 0; sb < CT::NSB; ++sb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = k0 + sb * 16 + g * 4 + r;
+        dead[sb * 4 + r] = kk >= kend || (km != nullptr && km[kk < p.M ? kk : p.M - 1]);
+      }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      if (t < nqt) {   // wave-uniform: the matrix-core ops below always run with a full EXEC mask
+        float sc[CT::NSB * 4];
+        float bmax = -INFINITY;
+#pragma unroll
+        for (int sb = 0; sb < CT::NSB; ++sb) {
+          f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < CT::DSTEPS; ++s) MM::mma(st, kc[sb * CT::DSTEPS + s], qf[t][s]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = dead[sb * 4 + r] ? -INFINITY : st[r];
+            sc[sb * 4 + r] = v;
+            bmax = fmaxf(bmax, v);
+          }
+        }
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+        const float mn = fmaxf(m[t], bmax);
+        // If every key seen so far is masked (mn = -inf) use 0 as the reference so exp(-inf - 0) = 0, not NaN.
+        const float mref = (mn == -INFINITY) ? 0.f : mn;
+        const float alpha = expf(m[t] - mref);
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < CT::NSB * 4; ++i) { sc[i] = expf(sc[i] - mref); ps += sc[i]; }
+        lpart[t] = lpart[t] * alpha + ps;
+        m[t] = mn;
+        const frag pf = CT::pfrag(sc);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ot[t][dt][r] *= alpha;
+          MM::mma(ot[t][dt], vc[dt], pf);
+        }
+      }
+    }
+  };
+
+  for (int b0 = 0; b0 < nblk; b0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int blk = b0 + u;
+      if (blk < nblk) {
+        compute(kbeg + blk * KB, kr[u], vr[u]);
+        if (blk + PD < nblk) load_block(kbeg + (blk + PD) * KB, kr[u], vr[u]);
+      }
+    }
+  }
+
+  // merge the NW key slices of this (group, head) in LDS
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    if (t < nqt) {
+      float l = lpart[t];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      float* mine = part + ((wave * QT + t) * 16 + li) * PSTR;
+      if (g == 0) { mine[0] = m[t]; mine[1] = l; }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(mine + 4 + dt * 16 + g * 4) = ot[t][dt];
+    }
+  }
   __syncthreads();
   T* out = reinterpret_cast<T*>(p.out);
   for (int qi = wave; qi < nrows; qi += NW) {
     float mall = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) mall = fmaxf(mall, part[(w * 16 + qi) * PSTR]);
+    for (int w = 0; w < NW; ++w) mall = fmaxf(mall, part[(w * QT * 16 + qi) * PSTR]);
     float L = 0.f, o = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      const float* pw = part + (w * 16 + qi) * PSTR;
+      const float* pw = part + (w * QT * 16 + qi) * PSTR;
       const float wt = (pw[0] == -INFINITY) ? 0.f : expf(pw[0] - mall);
       L += pw[1] * wt;
       o += pw[4 + lane] * wt;
@@ -454,14 +488,27 @@ __global__ void advance_pos_kernel(int32_t* d_pos) { *d_pos += 1; }
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------------
 // optional hipEvent bracketing of the cross-attention kernel (bench.py's roofline measurement)
-bool g_prof = false, g_capturing = false;
+bool g_prof = false;
+thread_local bool g_capturing = false;   // one host thread per pipeline lane may be capturing
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
 size_t g_prof_used = 0;
 
-template <typename T, int NW>
-int launch_cross_t(const CrossP& cp, int n_tiles, int S, hipStream_t st) {
-  const size_t smem = (size_t)NW * 16 * 68 * sizeof(float);
-  hipLaunchKernelGGL((dec_cross_attn_kernel<T, NW>), dim3(n_tiles, cp.nH, S), dim3(NW * 64), smem, st, cp);
+template <typename T, int QT, int PD>
+int launch_cross_t(const CrossP& cp, int n_groups, int S, hipStream_t st) {
+  constexpr int NW = 4;
+  const size_t smem = (size_t)NW * QT * 16 * CROSS_PSTR * sizeof(float);
+  auto kern = dec_cross_attn_kernel<T, NW, QT, PD>;
+  if (smem > 48 * 1024) {
+    static bool done = false;   // per template instantiation
+    if (!done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        omp_set_error("omp_dec_cross_attn_step: cannot raise dynamic LDS limit");
+        return OMP_ERR_LAUNCH;
+      }
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(n_groups, cp.nH, S), dim3(NW * 64), smem, st, cp);
   return OMP_OK;
 }
 
@@ -480,13 +527,16 @@ int launch_merge(const CrossP& cp, int S, hipStream_t st) {
   return OMP_OK;
 }
 
-// n_split = total key slices per (tile, head), a power of two in [1, 64]: NW = min(n_split, 4) waves per
-// workgroup (merged in LDS) x S = n_split / NW workgroups (merged by dec_cross_merge_kernel).
-int launch_cross(const CrossP& cp, int n_tiles, int dtype, int n_split, hipStream_t st) {
-  int ns = 1;
-  while (ns * 2 <= n_split && ns < 64) ns *= 2;
-  const int NW = ns < 4 ? ns : 4, S = ns / NW;
-  if (S > 1 && cp.partial == nullptr) { omp_set_error("omp_dec_cross_attn_step: n_split %d needs a partial buffer", n_split); return OMP_ERR_INVALID; }
+// S = workgroup-level key splits (power of two <= 16); each workgroup's 4 waves split its keys again.
+// qt = query tiles (of 16 rows) per group: 1, 2 or 4.
+int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t st) {
+  if (S < 1 || S > 16 || (S & (S - 1)) != 0) { omp_set_error("omp_dec_cross_attn_step: n_split must be a power of two in [1,16] (got %d)", S); return OMP_ERR_INVALID; }
+  if (qt != 1 && qt != 2 && qt != 4) { omp_set_error("omp_dec_cross_attn_step: q_tiles must be 1, 2 or 4 (got %d)", qt); return OMP_ERR_INVALID; }
+  if (S > 1 && cp.partial == nullptr) { omp_set_error("omp_dec_cross_attn_step: n_split %d needs a partial buffer", S); return OMP_ERR_INVALID; }
+  const int KB = dtype == OMP_F32 ? 16 : 32;
+  if (cp.Mpad % KB != 0 || cp.Mpad < cp.M) { omp_set_error("omp_dec_cross_attn_step: Mpad %d must be a multiple of %d and >= M", cp.Mpad, KB); return OMP_ERR_INVALID; }
+  const int slices = S * 4;
+  cp.kpw = (((cp.M + slices - 1) / slices + KB - 1) / KB) * KB;
   const bool prof = g_prof && !g_capturing;
   if (prof) {
     if (g_prof_used == g_prof_ev.size()) {
@@ -498,9 +548,10 @@ int launch_cross(const CrossP& cp, int n_tiles, int dtype, int n_split, hipStrea
   }
   int rc;
   const bool f = dtype == OMP_F32;
-  if (NW == 4) rc = f ? launch_cross_t<float, 4>(cp, n_tiles, S, st) : launch_cross_t<bf16_t, 4>(cp, n_tiles, S, st);
-  else if (NW == 2) rc = f ? launch_cross_t<float, 2>(cp, n_tiles, S, st) : launch_cross_t<bf16_t, 2>(cp, n_tiles, S, st);
-  else rc = f ? launch_cross_t<float, 1>(cp, n_tiles, S, st) : launch_cross_t<bf16_t, 1>(cp, n_tiles, S, st);
+  // PD key blocks in flight per wave: with one query tile a wave's whole slice is usually 4 blocks -> all of it
+  if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st);
+  else if (qt == 2) rc = f ? launch_cross_t<float, 2, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 2, 2>(cp, n_groups, S, st);
+  else rc = f ? launch_cross_t<float, 4, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 4, 2>(cp, n_groups, S, st);
   if (rc != OMP_OK) return rc;
   if (prof) (void)hipEventRecord(g_prof_ev[g_prof_used++].second, st);
   OMP_CHECK_LAUNCH("omp_dec_cross_attn_step");
@@ -547,21 +598,18 @@ extern "C" int omp_dec_self_attn_step(const void* qkv, void* kcache, void* vcach
   return OMP_OK;
 }
 
-extern "C" int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K, int64_t ldk,
-                                       int64_t k_batch_stride, const void* Vt, int64_t ldvt,
-                                       int64_t vt_batch_stride, const uint8_t* key_mask,
-                                       const int32_t* tiles, int n_tiles, int R, float* partial, void* out,
-                                       int64_t ldo, int dtype, int M, int nH, int n_split, omp_stream_t s) {
-  OMP_CHECK_ARG(q && K && Vt && tiles && out, "omp_dec_cross_attn_step: null pointer");
+extern "C" int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K, const void* Vt, int64_t img_stride,
+                                       int Mpad, const uint8_t* key_mask, const int32_t* groups, int n_groups,
+                                       int q_tiles, int R, float* partial, void* out, int64_t ldo, int dtype, int M,
+                                       int nH, int n_split, omp_stream_t s) {
+  OMP_CHECK_ARG(q && K && Vt && groups && out, "omp_dec_cross_attn_step: null pointer");
   OMP_CHECK_ARG(R > 0, "omp_dec_cross_attn_step: bad R");
   OMP_CHECK_ARG(dtype == OMP_F32 || dtype == OMP_BF16, "omp_dec_cross_attn_step: bad dtype");
-  OMP_CHECK_ARG(n_tiles > 0 && n_split > 0 && M > 0, "omp_dec_cross_attn_step: bad sizes");
-  OMP_CHECK_ARG(ldvt % 32 == 0 && ldvt >= M, "omp_dec_cross_attn_step: ldvt must be a multiple of 32 and >= M (got %lld)", (long long)ldvt);
+  OMP_CHECK_ARG(n_groups > 0 && n_split > 0 && M > 0, "omp_dec_cross_attn_step: bad sizes");
   CrossP cp;
-  cp.q = q; cp.ldq = ldq; cp.K = K; cp.ldk = ldk; cp.kbs = k_batch_stride;
-  cp.Vt = Vt; cp.ldvt = ldvt; cp.vbs = vt_batch_stride; cp.kmask = key_mask; cp.tiles = tiles;
-  cp.out = out; cp.ldo = ldo; cp.partial = partial; cp.M = M; cp.nH = nH; cp.R = R;
-  return launch_cross(cp, n_tiles, dtype, n_split, (hipStream_t)s);
+  cp.q = q; cp.ldq = ldq; cp.K = K; cp.V = Vt; cp.img_stride = img_stride; cp.kmask = key_mask; cp.groups = groups;
+  cp.out = out; cp.ldo = ldo; cp.partial = partial; cp.M = M; cp.Mpad = Mpad; cp.nH = nH; cp.R = R; cp.kpw = 0;
+  return launch_cross(cp, n_groups, dtype, n_split, q_tiles, (hipStream_t)s);
 }
 
 extern "C" int omp_head_softmax_mask_argmax(const float* logits, int ld, int R, const omp_sample_cfg* cfg,
@@ -619,18 +667,18 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
   RUN(omp_dec_embed_ln(P->seq, P->seq_ld, P->d_pos, P->word_emb, P->pos_tab, P->emb_g, P->emb_b, P->x,
                        P->pre_norm ? nullptr : P->y, T, R, d, P->eps, st));
   CrossP cp;
-  cp.q = P->q; cp.ldq = d; cp.ldk = P->ldk; cp.kbs = P->k_batch_stride; cp.ldvt = P->ldvt;
-  cp.vbs = P->vt_batch_stride; cp.kmask = P->key_mask; cp.tiles = P->tiles; cp.out = P->att; cp.ldo = d;
-  cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R;
+  cp.q = P->q; cp.ldq = d; cp.img_stride = P->kv_img_stride; cp.Mpad = P->Mpad;
+  cp.kmask = P->key_mask; cp.groups = P->tiles; cp.out = P->att; cp.ldo = d;
+  cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R; cp.kpw = 0;
   for (int li = 0; li < P->n_layers; ++li) {
     const omp_dec_layer& L = P->layers[li];
-    cp.K = L.crossK; cp.Vt = L.crossVt;
+    cp.K = L.crossK; cp.V = L.crossVt;
     if (P->pre_norm) {
       RUN(ln_gemm(P, L.n1_g, L.n1_b, L.sa_in_w, 3 * d, L.sa_bias_tab, P->d_pos, 3 * d, P->qkv, T, OMP_ACT_NONE, st));
       RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, T, R, P->n_heads, d, P->Lmax, st));
       RUN(gemm(P, P->att, d, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
       RUN(ln_gemm(P, L.n2_g, L.n2_b, L.ca_q_w, d, L.ca_qbias_tab, P->d_pos, d, P->q, T, OMP_ACT_NONE, st));
-      RUN(launch_cross(cp, P->n_tiles, T, P->n_split, st));
+      RUN(launch_cross(cp, P->n_tiles, T, P->n_split, P->q_tiles, st));
       RUN(gemm(P, P->att, d, L.ca_out_w, d, d, L.ca_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
       RUN(ln_gemm(P, L.n3_g, L.n3_b, L.ff1_w, P->d_ff, L.ff1_b, nullptr, 0, P->ffh, T, OMP_ACT_RELU, st));
       RUN(gemm(P, P->ffh, P->d_ff, L.ff2_w, P->d_ff, d, L.ff2_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
@@ -640,7 +688,7 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
       RUN(gemm(P, P->att, d, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x2, OMP_F32, OMP_ACT_NONE, st));
       RUN(omp_layernorm(P->x2, OMP_F32, L.n1_g, L.n1_b, P->y, T, P->x, R, d, P->eps, st));
       RUN(gemm(P, P->y, d, L.ca_q_w, d, d, L.ca_qbias_tab, P->d_pos, d, nullptr, P->q, T, OMP_ACT_NONE, st));
-      RUN(launch_cross(cp, P->n_tiles, T, P->n_split, st));
+      RUN(launch_cross(cp, P->n_tiles, T, P->n_split, P->q_tiles, st));
       RUN(gemm(P, P->att, d, L.ca_out_w, d, d, L.ca_out_b, nullptr, 0, P->x, P->x2, OMP_F32, OMP_ACT_NONE, st));
       RUN(omp_layernorm(P->x2, OMP_F32, L.n2_g, L.n2_b, P->y, T, P->x, R, d, P->eps, st));
       RUN(gemm(P, P->y, d, L.ff1_w, d, P->d_ff, L.ff1_b, nullptr, 0, nullptr, P->ffh, T, OMP_ACT_RELU, st));
@@ -661,7 +709,8 @@ int check_plan(const omp_decoder_plan* P) {
   OMP_CHECK_ARG(P->dtype == OMP_F32 || P->dtype == OMP_BF16, "omp_decoder_run: bad dtype");
   OMP_CHECK_ARG(P->n_layers > 0 && P->n_layers <= OMP_MAX_DEC_LAYERS, "omp_decoder_run: bad n_layers %d", P->n_layers);
   OMP_CHECK_ARG(P->d_model == P->n_heads * DH, "omp_decoder_run: head_dim must be 64");
-  OMP_CHECK_ARG(P->R > 0 && P->Lmax > 0 && P->M > 0 && P->n_tiles > 0 && P->n_split > 0, "omp_decoder_run: bad sizes");
+  OMP_CHECK_ARG(P->R > 0 && P->Lmax > 0 && P->M > 0 && P->n_tiles > 0 && P->n_split > 0 && P->q_tiles > 0 && P->Mpad >= P->M,
+                "omp_decoder_run: bad sizes");
   OMP_CHECK_ARG(P->seq && P->d_pos && P->probs && P->x && P->y && P->qkv && P->att && P->q && P->ffh && P->hh0 &&
                     P->hh1 && P->logits && P->tiles,
                 "omp_decoder_run: null buffer in plan");
@@ -673,7 +722,9 @@ struct GraphSlot {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
 };
-std::vector<GraphSlot> g_slots;
+// fixed table (no reallocation): pipeline lanes drive their own slots from their own host threads
+constexpr int MAX_GRAPH_SLOTS = 4096;
+GraphSlot g_slots[MAX_GRAPH_SLOTS];
 
 int sample_and_advance(const omp_decoder_plan* P, hipStream_t st) {
   return omp_head_softmax_mask_argmax(P->logits, P->vocab, P->R, &P->sample, P->seq, P->probs, P->seq_ld,
@@ -706,7 +757,7 @@ extern "C" int omp_prof_read(double* total_ms, int64_t* count) {
 }
 
 extern "C" int omp_decoder_graph_reset(int slot) {
-  if (slot >= 0 && slot < (int)g_slots.size()) {
+  if (slot >= 0 && slot < MAX_GRAPH_SLOTS) {
     if (g_slots[slot].exec) (void)hipGraphExecDestroy(g_slots[slot].exec);
     if (g_slots[slot].graph) (void)hipGraphDestroy(g_slots[slot].graph);
     g_slots[slot] = GraphSlot();
@@ -735,7 +786,7 @@ extern "C" int omp_decoder_run(const omp_decoder_plan* P, int first_pos, int n_s
       RUN(sample_and_advance(P, st));
       continue;
     }
-    if ((int)g_slots.size() <= graph_slot) g_slots.resize(graph_slot + 1);
+    OMP_CHECK_ARG(graph_slot < MAX_GRAPH_SLOTS, "omp_decoder_run: graph slot %d out of range", graph_slot);
     GraphSlot& gs = g_slots[graph_slot];
     if (gs.exec == nullptr) {
       hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);

@@ -18,8 +18,8 @@
 
 namespace {
 
-int g_prefetch = 2;      // K tiles of register prefetch in gemm_tiled (1 or 2)
-int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows, 4 small split-K (debug/testing)
+int g_prefetch = 1;      // K tiles of register prefetch in gemm_tiled (1 or 2; 2 measured slower: 160 VGPRs)
+int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows, 4 small split-K, 5 dma128 (debug/testing)
 
 struct GemmP {
   const void* A; int64_t lda;
@@ -31,6 +31,8 @@ struct GemmP {
   int act; int trans_out; int64_t trans_rows, trans_ld;
   int tiles_m, tiles_n; int small_hint;
   const float* ln_g; const float* ln_b; float ln_eps;   // optional LayerNorm prologue (A is fp32)
+  int store_mode; int bias_m;                           // OMP_STORE_*; bias indexed by m instead of n
+  int kv_B, kv_tok, kv_mpad, kv_nH, kv_kb;              // blocked K / V^T destination geometry
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -39,18 +41,56 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-// Store the 4 consecutive-n values a lane holds for token m.
+// Store 4 consecutive-n values v (bias and activation already applied) of token m: adds the residual and
+// honours the destination layout (plain / transposed / blocked K / blocked V^T).
 template <typename TOut>
-__device__ __forceinline__ void epilogue_store(const GemmP& p, const float* bias, int64_t m, int n,
-                                               f32x4 acc) {
+__device__ __forceinline__ void store4(const GemmP& p, int64_t m, int n, const float* vin) {
   if (m >= p.M || n >= p.N) return;
   const TOut* res = reinterpret_cast<const TOut*>(p.residual);
   TOut* C = reinterpret_cast<TOut*>(p.C);
-  float v[4];
+  float v[4] = {vin[0], vin[1], vin[2], vin[3]};
+  if (p.store_mode == OMP_STORE_KBLK) {
+    // m = memory token (image b, key ml), n..n+3 = 4 dims of one head of one (decoder, layer) slab:
+    // K slab [nl][b][h][Mpad][64]
+    const int d = p.kv_nH * 64;
+    const int b = (int)(m / p.kv_tok), ml = (int)(m % p.kv_tok);
+    const int nl = n / d, h = (n % d) >> 6, dd = n & 63;
+    TOut* dst = C + ((((int64_t)nl * p.kv_B + b) * p.kv_nH + h) * p.kv_mpad + ml) * 64 + dd;
+    if (n + 3 < p.N) {
+      if constexpr (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+      else *reinterpret_cast<bf16x4*>(dst) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    } else {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float b = (bias != nullptr && n + r < p.N) ? bias[n + r] : 0.0f;
-    v[r] = apply_act(acc[r] + b, p.act);
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p.N) dst[r] = from_f32<TOut>(v[r]);
+    }
+    return;
+  }
+  if (p.store_mode == OMP_STORE_VBLK) {
+    // swapped operands: m = value feature (decoder-layer nl, head h, dim dd), n..n+3 = 4 memory tokens.
+    // V^T slab [nl][b][h][Mpad/KB][64][KB]; inside a block the KB keys sit in the order the PV matrix-core
+    // product consumes them (bf16: slot 8g + 4*half + r <-> key 16*half + 4g + r; f32: natural order).
+    const int d = p.kv_nH * 64, KB = p.kv_kb;
+    const int nl = (int)(m / d), h = (int)(m % d) >> 6, dd = (int)m & 63;
+    auto slot = [&](int tok, int& b) -> int64_t {
+      b = tok / p.kv_tok;
+      const int ml = tok - b * p.kv_tok;
+      const int blk = ml / KB, kl = ml - blk * KB;
+      const int pos = (KB == 32) ? (((kl & 15) >> 2) * 8 + (kl >> 4) * 4 + (kl & 3)) : kl;
+      return ((((int64_t)nl * p.kv_B + b) * p.kv_nH + h) * (p.kv_mpad / KB) + blk) * (64 * KB) + dd * KB + pos;
+    };
+    int b0, b3;
+    const int64_t i0 = slot(n, b0);
+    if (n + 3 < p.N && (p.kv_tok & 3) == 0) {   // 4 tokens of one image, contiguous slots
+      (void)b3;
+      if constexpr (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(C + i0) = f32x4{v[0], v[1], v[2], v[3]};
+      else *reinterpret_cast<bf16x4*>(C + i0) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p.N) C[slot(n + r, b3)] = from_f32<TOut>(v[r]);
+    }
+    return;
   }
   if (p.trans_out) {
     int64_t bidx = m / p.trans_rows, mi = m % p.trans_rows;
@@ -90,6 +130,21 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, const float* bias
       }
     }
   }
+}
+
+// bias + activation of the 4 consecutive-n values a lane holds for token m, then store4.
+template <typename TOut>
+__device__ __forceinline__ void epilogue_store(const GemmP& p, const float* bias, int64_t m, int n,
+                                               f32x4 acc) {
+  if (m >= p.M || n >= p.N) return;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float b = 0.0f;
+    if (bias != nullptr) b = p.bias_m ? bias[m] : (n + r < p.N ? bias[n + r] : 0.0f);
+    v[r] = apply_act(acc[r] + b, p.act);
+  }
+  store4<TOut>(p, m, n, v);
 }
 
 // bijective XCD remap: consecutive logical tile ids land on the same XCD (block b runs on XCD b%8)
@@ -232,6 +287,202 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmP p) {
       const int64_t m = m0 + wm * (BM / 2) + j * 16 + lrow;
       epilogue_store<TOut>(p, bias, m, n, acc[i][j]);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_dma<T,TOut,BM,BN>: the large-M GEMM (Swin / FPN / projection / K-V slabs).
+//   * operand tiles go global -> LDS by DMA (global_load_lds_dwordx4, no staging registers); the LDS image
+//     is lane-linear per wave instruction (8 rows x 128 B), so the XOR swizzle that makes the fragment
+//     ds_read_b128 conflict-free is applied to the per-lane SOURCE address (chunk c of row r lives in
+//     slot c ^ (r & 7));
+//   * two LDS stages, ONE raw s_barrier per K tile: wait own DMA of tile t -> barrier -> issue DMA of tile
+//     t+1 into the other stage -> MFMAs of tile t (the next tile's loads fly under them);
+//   * epilogue through LDS: accumulators (+bias, activation) are written as fp32 rows, read back row-
+//     contiguous and leave as 16-byte stores of full 128/256-byte row segments, the residual arriving the
+//     same way -- instead of 8-byte stores scattered over 16 rows per instruction.
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename TOut, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
+  typedef Mma<T> MM;
+  typedef typename MM::frag frag;
+  constexpr int ROWB = 128;                       // bytes of K per LDS row
+  constexpr int KT = ROWB / (int)sizeof(T);       // k elements per tile
+  constexpr int STEPS = KT / MM::KSTEP;           // 2
+  constexpr int EPC = 16 / (int)sizeof(T);        // elements per 16-byte chunk
+  constexpr int FM = BM / 32, FN = BN / 32;       // frags per wave (wave tile = BM/2 x BN/2)
+  constexpr int AI = BM / 32, WI = BN / 32;       // DMA instructions per wave per tile (8 rows each)
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int ES = BN + 4;                      // epilogue row pitch in floats (bank spread)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // max(2 * STAGE, BM * ES * 4)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int n0 = tn * BN;
+
+  // DMA source pointers: lane l of a wave instruction fills slot (l & 7) of row (l >> 3) of an 8-row piece
+  const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+  const T* a_src[AI];
+  const T* w_src[WI];
+#pragma unroll
+  for (int j = 0; j < AI; ++j) {
+    int64_t gm = m0 + wave * (BM / 4) + j * 8 + lr; if (gm > p.M - 1) gm = p.M - 1;
+    a_src[j] = reinterpret_cast<const T*>(p.A) + gm * p.lda + lc * EPC;
+  }
+#pragma unroll
+  for (int j = 0; j < WI; ++j) {
+    int gn = n0 + wave * (BN / 4) + j * 8 + lr; if (gn > p.N - 1) gn = p.N - 1;
+    w_src[j] = reinterpret_cast<const T*>(p.W) + (int64_t)gn * p.ldw + lc * EPC;
+  }
+  auto issue = [&](int kt, int buf) {
+    const int koff = kt * KT;
+    char* abase = smem + buf * STAGE + (wave * (BM / 4)) * ROWB;
+    char* wbase = smem + buf * STAGE + BM * ROWB + (wave * (BN / 4)) * ROWB;
+#pragma unroll
+    for (int j = 0; j < AI; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(abase + j * 8 * ROWB), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < WI; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(wbase + j * 8 * ROWB), 16, 0, 0);
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lrow = lane & 15, lg = lane >> 4;
+  auto compute = [&](int buf) {
+    const char* as = smem + buf * STAGE + (wm * (BM / 2)) * ROWB;
+    const char* ws = smem + buf * STAGE + BM * ROWB + (wn * (BN / 2)) * ROWB;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      frag fw[FN], fx[FM];
+      const int c = s * 4 + lg;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int row = i * 16 + lrow;   // (row & 7) == (lrow & 7): fragment tiles are 16-row aligned
+        fw[i] = *reinterpret_cast<const frag*>(ws + row * ROWB + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int row = j * 16 + lrow;
+        fx[j] = *reinterpret_cast<const frag*>(as + row * ROWB + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) MM::mma(acc[i][j], fw[i], fx[j]);
+    }
+  };
+
+  const int nk = p.K / KT;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    // own DMA of tile kt has landed; after the barrier everybody's has, and everybody is done reading the
+    // other stage (tile kt-1), so it can be refilled while tile kt is multiplied
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    compute(kt & 1);
+  }
+
+  // ---- epilogue phase 1: act(acc + bias) -> fp32 rows in LDS ------------------------------------
+  __builtin_amdgcn_s_barrier();   // all waves are done with the operand stages
+  float* E = reinterpret_cast<float*>(smem);
+  const float* bias = p.bias;
+  if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int nl = wn * (BN / 2) + i * 16 + lg * 4;
+    float bn[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr && !p.bias_m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n0 + nl + r < p.N) bn[r] = bias[n0 + nl + r];
+    }
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int ml = wm * (BM / 2) + j * 16 + lrow;
+      float bm = 0.f;
+      if (bias != nullptr && p.bias_m && m0 + ml < p.M) bm = bias[m0 + ml];
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[i][j][r] + bn[r] + bm, p.act);
+      *reinterpret_cast<f32x4*>(E + ml * ES + nl) = o;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: row-contiguous 16-byte stores ------------------------------------------------------
+  constexpr int CH = 16 / (int)sizeof(TOut);   // output elements per 16-byte chunk
+  constexpr int CPR = BN / CH;                 // chunks per tile row
+  constexpr int RPP = 256 / CPR;               // rows per pass
+  const TOut* res = reinterpret_cast<const TOut*>(p.residual);
+  TOut* C = reinterpret_cast<TOut*>(p.C);
+  const bool vec_ok = p.store_mode == OMP_STORE_PLAIN && !p.trans_out && (p.ldc % CH) == 0 &&
+                      (res == nullptr || (p.ldr % CH) == 0);
+  const int cidx = tid % CPR, rsub = tid / CPR;
+  const int n = n0 + cidx * CH;
+  if (n >= p.N) return;
+  if (vec_ok && n + CH <= p.N) {
+#pragma unroll 4
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+      const int r = pass * RPP + rsub;
+      const int64_t m = m0 + r;
+      if (m < p.M) {
+        float v[CH];
+#pragma unroll
+        for (int q = 0; q < CH; q += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
+          v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
+        }
+        if (res != nullptr) {
+          float rv[CH];
+          unpack16(*reinterpret_cast<const typename Vec16<TOut>::type*>(res + m * p.ldr + n), rv);
+#pragma unroll
+          for (int q = 0; q < CH; ++q) v[q] += rv[q];
+        }
+        typename Vec16<TOut>::type o;
+        pack16(v, o);
+        *reinterpret_cast<typename Vec16<TOut>::type*>(C + m * p.ldc + n) = o;
+      }
+    }
+  } else {
+    // ragged N edge, odd pitches and the transposed / blocked K / blocked V^T destinations: 4 values at a time
+#pragma unroll 1
+    for (int it = 0; it < (BM / RPP) * (CH / 4); ++it) {
+      const int pass = it / (CH / 4), q = (it % (CH / 4)) * 4;
+      const int r = pass * RPP + rsub;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
+      const float v[4] = {t[0], t[1], t[2], t[3]};
+      store4<TOut>(p, m0 + r, n + q, v);
+    }
+  }
+}
+
+template <typename T, typename TOut, int BM, int BN>
+int launch_dma(GemmP& p, hipStream_t st) {
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int EBYTES = BM * (BN + 4) * 4;
+  constexpr size_t smem = (2 * STAGE > EBYTES) ? 2 * STAGE : EBYTES;
+  auto kern = gemm_dma<T, TOut, BM, BN>;
+  static bool done = false;   // per template instantiation
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      omp_set_error("omp_gemm_bias_act: cannot raise dynamic LDS limit");
+      return OMP_ERR_LAUNCH;
+    }
+    done = true;
+  }
+  p.tiles_m = (int)ceil_div64(p.M, BM); p.tiles_n = (int)ceil_div64(p.N, BN);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+  return OMP_OK;
 }
 
 // Small-M path: grid (ceil(N/64), ceil(M/16)), 4 waves, wave w owns output features
@@ -451,9 +702,12 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
   if (which == 0) {
     if (p.M <= 64) which = 3;
     else if (ceil_div64(p.M, 128) * ceil_div64(p.N, 128) < 512) which = 2;
-    else which = 1;
+    else which = 5;
   }
-  if (which == 3) {
+  if (which == 5) {
+    int rc = launch_dma<T, TOut, 128, 128>(p, st);
+    if (rc != OMP_OK) return rc;
+  } else if (which == 3) {
     dim3 grid((unsigned)ceil_div64(p.N, 64), (unsigned)ceil_div64(p.M, 16));
     hipLaunchKernelGGL((gemm_rows<T, TOut>), grid, dim3(256), 0, st, p);
   } else if (which == 2) {
@@ -506,6 +760,21 @@ extern "C" int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s) {
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act;
   p.trans_out = a->trans_out; p.trans_rows = a->trans_rows; p.trans_ld = a->trans_ld; p.tiles_m = p.tiles_n = 0;
   p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.small_hint = a->small_m_splitk;
+  p.store_mode = a->store_mode; p.bias_m = a->bias_along_m;
+  p.kv_B = a->kv_images; p.kv_tok = a->kv_tokens; p.kv_mpad = a->kv_mpad; p.kv_nH = a->kv_heads; p.kv_kb = a->kv_key_block;
+  if (p.store_mode != OMP_STORE_PLAIN) {
+    OMP_CHECK_ARG(p.store_mode == OMP_STORE_KBLK || p.store_mode == OMP_STORE_VBLK, "omp_gemm_bias_act: bad store_mode %d", p.store_mode);
+    OMP_CHECK_ARG(!a->trans_out && a->residual == nullptr && a->ln_gamma == nullptr && !a->small_m_splitk,
+                  "omp_gemm_bias_act: blocked K/V stores take no residual / trans_out / LayerNorm prologue");
+    OMP_CHECK_ARG(p.kv_B > 0 && p.kv_tok > 0 && p.kv_nH > 0 && (p.kv_kb == 16 || p.kv_kb == 32) && p.kv_mpad >= p.kv_tok &&
+                      p.kv_mpad % p.kv_kb == 0,
+                  "omp_gemm_bias_act: bad blocked K/V geometry");
+    const int64_t toks = (int64_t)p.kv_B * p.kv_tok;
+    OMP_CHECK_ARG(p.store_mode == OMP_STORE_KBLK ? (a->M == toks && a->N % (p.kv_nH * 64) == 0)
+                                                 : (a->N == toks && a->M % (p.kv_nH * 64) == 0),
+                  "omp_gemm_bias_act: blocked K/V store shape mismatch (M=%lld N=%d)", (long long)a->M, a->N);
+  }
+  OMP_CHECK_ARG(!p.bias_m || (a->bias_row == nullptr), "omp_gemm_bias_act: bias_along_m excludes bias_row");
   OMP_CHECK_ARG((a->ln_gamma == nullptr) == (a->ln_beta == nullptr), "omp_gemm_bias_act: ln_gamma and ln_beta go together");
   hipStream_t st = (hipStream_t)s;
   if (a->dtype == OMP_F32) return launch_gemm<float, float>(p, st);

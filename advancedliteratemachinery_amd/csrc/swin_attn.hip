@@ -158,6 +158,243 @@ __global__ __launch_bounds__(256) void swin_attn_kernel(const T* __restrict__ qk
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Matrix-core version (the one that runs; the scalar kernel above is kept as an independent
+// cross-check, selectable with omp_debug_swin_attn_impl).
+//
+// One wave = one (window, head).  The 49 tokens are padded to 64 = 4 tiles of 16:
+//   S^T[key][query] = K[key,:] . Q[query,:]       head_dim 32 = ONE k-step of the 16x16x32 bf16 MFMA
+//                                                  (two 16x16x16-equivalent steps of 4 f32 MFMAs)
+//   softmax over keys in registers: a lane owns query (l & 15) of each query tile and 4 keys
+//   {4*(l>>4) + r} of each key tile -> 16 scores per query tile in-lane + two xor-shuffles
+//   O^T[d][query] += V^T[d][key] * P[key][query]   P comes straight from the S^T accumulators
+// Q and K fragments are 16-byte loads straight from the qkv rows in HBM (8 per lane); only V needs a
+// transpose and goes through LDS once (written as [dim][key] in the k-slot order the second product
+// wants, pitch padded so the ds_read_b128 of a fragment is conflict-free).  Everything else the
+// reference does between the qkv and proj Linears is index arithmetic exactly as in the scalar kernel.
+// Per wave: 32 MFMAs for 12.5 KB of HBM traffic -> the kernel is bound by HBM, not by LDS/VALU.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct SwinTraits;
+template <>
+struct SwinTraits<bf16_t> {
+  static constexpr int QS = 1;    // k-steps over head_dim 32 in QK^T
+  static constexpr int PS = 2;    // k-steps over the 64 (padded) keys in PV
+  static constexpr int KPS = 32;  // keys per PV k-step
+  static constexpr int VP = 72;   // V^T row pitch in elements (64 keys + pad: 144 B)
+  __device__ static __forceinline__ int slot(int j) {   // key j -> position inside its 32-key step
+    const int kl = j & 31;
+    return (j & 32) + ((kl & 15) >> 2) * 8 + (kl >> 4) * 4 + (kl & 3);
+  }
+  __device__ static __forceinline__ bf16x8 pfrag(const float* a, const float* b) {
+    bf16x8 f = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+    return f;
+  }
+};
+template <>
+struct SwinTraits<float> {
+  static constexpr int QS = 2;
+  static constexpr int PS = 4;
+  static constexpr int KPS = 16;
+  static constexpr int VP = 68;   // 272 B
+  __device__ static __forceinline__ int slot(int j) { return j; }
+  __device__ static __forceinline__ f32x4 pfrag(const float* a, const float*) { return f32x4{a[0], a[1], a[2], a[3]}; }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const T* __restrict__ qkv,
+                                                              const float* __restrict__ qkv_bias,
+                                                              const float* __restrict__ table,
+                                                              T* __restrict__ out, int B, int H, int W, int C,
+                                                              int nH, int shift, int nWy, int nWx) {
+  typedef Mma<T> MM;
+  typedef SwinTraits<T> ST;
+  typedef typename MM::frag frag;
+  constexpr int NV = Vec16<T>::N;          // elements per 16-byte chunk (8 / 4)
+  constexpr int VP = ST::VP;
+  __shared__ __attribute__((aligned(16))) T vt[4][HD * VP];   // per wave: V^T [32 dims][64 key slots (+pad)]
+  __shared__ float tab[4][176];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y * 4 + wave;
+  if (head >= nH) return;                  // whole wave; no block-wide barrier below
+  int widx = blockIdx.x;
+  const int wx = widx % nWx; widx /= nWx;
+  const int wy = widx % nWy;
+  const int b = widx / nWy;
+  const int Hp = nWy * WS, Wp = nWx * WS;
+  const int C3 = 3 * C;
+  T* vs = vt[wave];
+
+  // window-local token t (0..48) -> row of qkv (or -1: padding token, q/k/v = bias)
+  auto token_of = [&](int t, int& sy, int& sx) -> int64_t {
+    const int ty = (t * 37) >> 8, tx = t - ty * WS;   // t / 7 for t < 64
+    sy = wy * WS + ty; sx = wx * WS + tx;
+    int py = sy + shift, px = sx + shift;
+    if (py >= Hp) py -= Hp;
+    if (px >= Wp) px -= Wp;
+    return (py < H && px < W) ? ((int64_t)b * H + py) * W + px : (int64_t)-1;
+  };
+  // 16 bytes of q (sel 0) / k (1) / v (2) of token tok at head dims [d0, d0 + NV)
+  auto load_chunk = [&](int64_t tok, int sel, int d0) -> frag {
+    if (tok >= 0) return ld16<T>(qkv + tok * C3 + sel * C + head * HD + d0);
+    float t[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) t[i] = qkv_bias[sel * C + head * HD + d0 + i];
+    frag f;
+    pack16(t, f);
+    return f;
+  };
+
+  // ---- issue every global load first -------------------------------------------------------------
+  frag qf[4][ST::QS], kf[4][ST::QS];
+  int64_t qtok[4];
+  int qsy[4], qsx[4];
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4) {
+    int i = t4 * 16 + li; if (i > WT - 1) i = WT - 1;      // clamped rows are never stored / are masked
+    int sy, sx;
+    const int64_t tok = token_of(i, sy, sx);
+    qtok[t4] = (t4 * 16 + li < WT) ? tok : (int64_t)-1;
+    qsy[t4] = sy; qsx[t4] = sx;
+#pragma unroll
+    for (int s = 0; s < ST::QS; ++s) {
+      qf[t4][s] = load_chunk(tok, 0, s * MM::KSTEP + g * MM::KPL);
+      kf[t4][s] = load_chunk(tok, 1, s * MM::KSTEP + g * MM::KPL);
+    }
+  }
+  // V: lane (key = it*16 + lane/CPR, chunk = lane % CPR) -> 16-byte row pieces, coalesced per token
+  constexpr int CPR = HD / NV;             // chunks per 32-dim row: 4 (bf16) / 8 (f32)
+  constexpr int KPI = 64 / CPR;            // keys per iteration
+  frag vchunk[64 / KPI];
+#pragma unroll
+  for (int it = 0; it < 64 / KPI; ++it) {
+    const int j = it * KPI + lane / CPR, dc = lane % CPR;
+    int sy, sx;
+    if (j < WT) {
+      const int64_t tok = token_of(j, sy, sx);
+      vchunk[it] = load_chunk(tok, 2, dc * NV);
+    } else {
+      float z[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) z[i] = 0.f;   // padded key slots must be finite: P = 0 there
+      pack16(z, vchunk[it]);
+    }
+  }
+  for (int idx = lane; idx < 169; idx += 64) tab[wave][idx] = table[idx * nH + head];
+
+  // ---- V^T -> LDS -----------------------------------------------------------------------------------
+#pragma unroll
+  for (int it = 0; it < 64 / KPI; ++it) {
+    const int j = it * KPI + lane / CPR, dc = lane % CPR;
+    const int pos = ST::slot(j);
+#pragma unroll
+    for (int e = 0; e < NV; ++e) vs[(dc * NV + e) * VP + pos] = vchunk[it][e];
+  }
+
+  // ---- S^T = K Q^T; the reference's q * scale (swin_transformer.py:130) is applied to the fp32 products ----
+  const float scale = 0.17677669529663687f;  // 32^-0.5
+  // per-lane key geometry: acc[r] of key tile kt is key j = kt*16 + 4g + r
+  int kty[16], ktx[16], krid[16];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = kt * 16 + g * 4 + r;
+      const int ty = (j * 37) >> 8, tx = j - ty * WS;
+      kty[kt * 4 + r] = ty; ktx[kt * 4 + r] = tx;
+      int rid = 0;
+      if (shift > 0) {
+        const int ssy = wy * WS + ty, ssx = wx * WS + tx;
+        const int ry = ssy < Hp - WS ? 0 : (ssy < Hp - shift ? 1 : 2);
+        const int rx = ssx < Wp - WS ? 0 : (ssx < Wp - shift ? 1 : 2);
+        rid = ry * 3 + rx;
+      }
+      krid[kt * 4 + r] = rid;
+    }
+
+  f32x4 oacc[2][4];   // [dim tile][query tile]
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) oacc[dt][t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's V^T and table stores have landed (own data only)
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4) {
+    // geometry of this lane's query of tile t4
+    const int i = t4 * 16 + li;
+    const int ity = (i * 37) >> 8, itx = i - ity * WS;
+    int rid_i = 0;
+    if (shift > 0) {
+      const int ry = qsy[t4] < Hp - WS ? 0 : (qsy[t4] < Hp - shift ? 1 : 2);
+      const int rx = qsx[t4] < Wp - WS ? 0 : (qsx[t4] < Wp - shift ? 1 : 2);
+      rid_i = ry * 3 + rx;
+    }
+    float sc[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < ST::QS; ++s) MM::mma(st, kf[kt][s], qf[t4][s]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = kt * 16 + g * 4 + r;
+        float a = st[r] * scale;
+        if (j < WT && i < WT) {
+          a += tab[wave][(ity - kty[kt * 4 + r] + WS - 1) * (2 * WS - 1) + (itx - ktx[kt * 4 + r] + WS - 1)];
+          if (shift > 0 && krid[kt * 4 + r] != rid_i) a += -100.0f;
+        } else if (j >= WT) {
+          a = -INFINITY;
+        }
+        sc[kt * 4 + r] = a;
+        mx = fmaxf(mx, a);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { sc[k] = expf(sc[k] - mx); l += sc[k]; }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sc[k] *= inv;
+    // O^T += V^T P : k-step ps covers keys [ps*KPS, +KPS)
+#pragma unroll
+    for (int ps = 0; ps < ST::PS; ++ps) {
+      const frag pf = ST::pfrag(sc + ps * (ST::KPS / 4), sc + ps * (ST::KPS / 4) + 4);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const frag vf = *reinterpret_cast<const frag*>(vs + (dt * 16 + li) * VP + ps * ST::KPS + g * MM::KPL);
+        MM::mma(oacc[dt][t4], vf, pf);
+      }
+    }
+  }
+
+  // ---- store: acc[r] <-> (dim = dt*16 + 4g + r, query = t4*16 + li) -----------------------------------
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4) {
+    if (qtok[t4] >= 0) {
+      T* dst = out + qtok[t4] * C + head * HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const f32x4 o = oacc[dt][t4];
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<f32x4*>(dst + dt * 16) = o;
+        } else {
+          bf16x4 ov = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+          *reinterpret_cast<bf16x4*>(dst + dt * 16) = ov;
+        }
+      }
+    }
+  }
+}
+
+int g_swin_impl = 0;   // 0 = matrix cores, 1 = scalar cross-check kernel
+
 }  // namespace
 
 extern "C" int omp_swin_window_attn(const void* qkv, const float* qkv_bias, const float* rel_bias_table,
@@ -170,13 +407,27 @@ extern "C" int omp_swin_window_attn(const void* qkv, const float* qkv_bias, cons
   OMP_CHECK_ARG(B > 0 && H > 0 && W > 0, "omp_swin_window_attn: bad shape");
   const int nWy = (H + WS - 1) / WS, nWx = (W + WS - 1) / WS;
   dim3 grid((unsigned)((int64_t)B * nWy * nWx), (unsigned)((nH + 3) / 4));
-  if (dtype == OMP_F32)
-    hipLaunchKernelGGL((swin_attn_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv,
-                       qkv_bias, rel_bias_table, (float*)out, B, H, W, C, nH, shift, nWy, nWx);
-  else if (dtype == OMP_BF16)
-    hipLaunchKernelGGL((swin_attn_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv,
-                       qkv_bias, rel_bias_table, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx);
-  else { omp_set_error("omp_swin_window_attn: bad dtype %d", dtype); return OMP_ERR_INVALID; }
+  if (dtype != OMP_F32 && dtype != OMP_BF16) { omp_set_error("omp_swin_window_attn: bad dtype %d", dtype); return OMP_ERR_INVALID; }
+  if (g_swin_impl == 1) {
+    if (dtype == OMP_F32)
+      hipLaunchKernelGGL((swin_attn_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv,
+                         qkv_bias, rel_bias_table, (float*)out, B, H, W, C, nH, shift, nWy, nWx);
+    else
+      hipLaunchKernelGGL((swin_attn_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv,
+                         qkv_bias, rel_bias_table, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx);
+  } else {
+    if (dtype == OMP_F32)
+      hipLaunchKernelGGL((swin_attn_mfma_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv,
+                         qkv_bias, rel_bias_table, (float*)out, B, H, W, C, nH, shift, nWy, nWx);
+    else
+      hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv,
+                         qkv_bias, rel_bias_table, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx);
+  }
   OMP_CHECK_LAUNCH("omp_swin_window_attn");
+  return OMP_OK;
+}
+
+extern "C" int omp_debug_swin_attn_impl(int which) {
+  g_swin_impl = which == 1 ? 1 : 0;
   return OMP_OK;
 }

@@ -1,0 +1,93 @@
+"""Batch pipelining over HIP streams: several image batches in flight on one GPU.
+
+One batch through the hot path is a chain of very different phases -- the Swin encoder (matrix-core /
+HBM bound, fills the chip), the point decoder (~130 strictly sequential steps of small kernels: latency
+bound, a fraction of the CUs busy), the polygon / recognition decoders (medium kernels).  Run back to back
+they leave most of the MI355X idle most of the time.  A `LanePool` keeps `n_lanes` batches in flight, each
+lane on its own HIP stream (+ two side streams for polygon || recognition) with its own decoder state
+(K/V slabs, KV caches, captured hipGraphs -- `Decoder.fork()`), so the latency-bound phases of one batch run
+under the throughput-bound phases of the others.  Weights are shared; nothing is replicated but buffers.
+
+Each lane is driven by its own host thread (the per-batch host work is ctypes / HIP calls that release the
+GIL, and the EOS polls of the point decoder only block their own lane).  The reference has no counterpart:
+engine/val.py:19-35 processes one image at a time, synchronously.
+"""
+import queue
+import threading
+from concurrent.futures import Future
+
+import torch
+
+
+class Lane(object):
+    def __init__(self, device, index):
+        self.index = index
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device)
+        self.side = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        self._dec = None
+        self._dec_src = None
+
+    def decoder(self, base):
+        """This lane's private fork of the model's decoder (re-forked when the engine was rebuilt)."""
+        if self._dec is None or self._dec_src is not base:
+            self._dec, self._dec_src = base.fork(), base
+        self._dec.use_graph = base.use_graph
+        return self._dec
+
+
+class LanePool(object):
+    """submit(fn) runs fn(lane) on the next lane (round robin) inside that lane's stream context and
+    returns a Future of (result, event); the event is recorded on the lane stream after fn's last launch."""
+
+    def __init__(self, device, n_lanes):
+        self.device = torch.device(device)
+        self.lanes = [Lane(self.device, i) for i in range(max(1, n_lanes))]
+        self._queues = [queue.Queue() for _ in self.lanes]
+        self._next = 0
+        self._threads = []
+        for lane, q in zip(self.lanes, self._queues):
+            t = threading.Thread(target=self._worker, args=(lane, q), daemon=True, name='omp355-lane%d' % lane.index)
+            t.start()
+            self._threads.append(t)
+
+    def _worker(self, lane, q):
+        torch.cuda.set_device(self.device)
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            fn, fut = item
+            if not fut.set_running_or_notify_cancel():
+                continue
+            try:
+                with torch.cuda.stream(lane.stream):
+                    res = fn(lane)
+                    ev = torch.cuda.Event()
+                    ev.record(lane.stream)
+                fut.set_result((res, ev))
+            except BaseException as e:  # noqa: BLE001 -- delivered to the submitter
+                fut.set_exception(e)
+
+    def submit(self, fn):
+        fut = Future()
+        i = self._next
+        self._next = (i + 1) % len(self.lanes)
+        self._queues[i].put((fn, fut))
+        return fut
+
+    def infer(self, model, img, mask, sequence, **kw):
+        """model.infer(...) on the next lane; Future of (results, event)."""
+        return self.submit(lambda lane: model.infer(img, mask, sequence, lane=lane, **kw))
+
+    def synchronize(self):
+        for lane in self.lanes:
+            lane.stream.synchronize()
+            for s in lane.side:
+                s.synchronize()
+
+    def close(self):
+        for q in self._queues:
+            q.put(None)
+        for t in self._threads:
+            t.join(timeout=5)

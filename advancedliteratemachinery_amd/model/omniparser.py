@@ -109,8 +109,13 @@ class OmniParser(nn.Module):
 
     # -- batched inference ------------------------------------------------------------------------
     @torch.no_grad()
-    def infer(self, img, mask, sequence, forced_instances=None, has_padding=None):
+    def infer(self, img, mask, sequence, forced_instances=None, has_padding=None, lane=None):
+        """lane: a pipeline Lane (engine/pipeline.py) -- private decoder state + side streams, so several
+        batches can be in flight on different HIP streams; None = the model's own state."""
         enc, dec = self.engine()
+        side = None
+        if lane is not None:
+            dec, side = lane.decoder(dec), lane.side
         a = self.args
         dev = img.device
         B = img.shape[0]
@@ -130,14 +135,14 @@ class OmniParser(nn.Module):
             self._mark('pt_decode')
             if a.infer_vie:
                 sizes = sequence[3]
-                return self._kie(dec, kv, pts, poly_sos, rec_sos, sizes, B)
+                return self._kie(dec, kv, pts, poly_sos, rec_sos, sizes, B, side)
             counts = [int(ids.numel()) // 2 for ids, _ in pts]
             R = sum(counts)
             if R == 0:
                 return [None] * B
             points = torch.cat([ids.reshape(-1, 2) for ids, _ in pts], 0).to(dev, torch.int32)
             (poly, _), (rec, rprob) = dec.decode_poly_and_rec(kv, points, counts, poly_sos, rec_sos, a.rec_length,
-                                                              streams=self._side_streams(dev))
+                                                              streams=side if side is not None else self._side_streams(dev))
             poly, rec, rprob = poly.long(), rec.long(), rprob.clone()
             self._mark('poly_rec_decode')
             out, r0 = [], 0
@@ -153,7 +158,7 @@ class OmniParser(nn.Module):
             return out
 
     # -- KIE assembly (reference transformer.py:143-217) --------------------------------------------------
-    def _kie(self, dec, kv, pts, poly_sos, rec_sos, sizes, B):
+    def _kie(self, dec, kv, pts, poly_sos, rec_sos, sizes, B, side=None):
         a = self.args
         nb = a.num_bins
         events, words, counts = [], [], []
@@ -178,7 +183,8 @@ class OmniParser(nn.Module):
         if words:
             points = torch.tensor(words, dtype=torch.int32, device=kv['K'].device)
             (poly, _), (rec, _) = dec.decode_poly_and_rec(kv, points, counts, poly_sos, rec_sos, a.rec_length,
-                                                          infer_vie=True, streams=self._side_streams(kv['K'].device))
+                                                          infer_vie=True,
+                                                          streams=side if side is not None else self._side_streams(kv['K'].device))
             poly, rec = poly.cpu(), rec.cpu()
         i2c = index2class(a)
         sizes = _image_sizes(sizes, B)

@@ -10,7 +10,10 @@ computed once per image and shared by all of its text instances, all images of a
 instances decoded in lock-step.  The host touches the device once per `poll` steps (EOS flags of
 the point decoder) and once per phase (results).
 """
+import copy
 import ctypes
+import itertools
+import os
 
 import torch
 
@@ -62,7 +65,7 @@ class _Phase(object):
         self.y, self.att, self.q, self.hh0, self.hh1 = e(R, d), e(R, d), e(R, d), e(R, d), e(R, d)
         self.qkv, self.ffh = e(R, 3 * d), e(R, ff)
         self.logits = e(R, V, dtype=torch.float32)
-        self.partial = e(R, nH, max(1, n_split // 4), 68, dtype=torch.float32)   # workgroup-level partials
+        self.partial = e(R, nH, max(1, n_split), 68, dtype=torch.float32)   # workgroup-level partials
         self.kc = [e(R, Lmax, d) for _ in range(L)]
         self.vc = [e(R, Lmax, d) for _ in range(L)]
         self.plan = _lib.DecoderPlan()
@@ -79,6 +82,7 @@ class Decoder(object):
         if self.L > _lib.MAX_DEC_LAYERS:
             raise ValueError('too many decoder layers')
         self.use_graph = False
+        self.n_split_override = int(os.environ.get('OMP355_CROSS_SPLIT', '0'))
         self._graph_slots = {}
         self._phases = {}
         self._kv = {}
@@ -125,17 +129,24 @@ class Decoder(object):
 
     # -- memory K/V: once per batch ---------------------------------------------------------------
     def project_memory(self, memory, mem_pos, B, M, key_mask):
-        """K = (memory+pos) Wk^T + bk  [B*M, NL*d];  V^T = (memory Wv^T + bv)^T  [B, NL*d, Mpad]."""
-        Mpad = _round_up(M, 32)  # a 32-key block never runs past a V^T row
+        """Cross-attention memory of all (decoder, layer) pairs, written by the GEMM epilogues straight into
+        the head-blocked slabs the step kernel streams (DESIGN.md "cross-attention memory layout"):
+          K   = (memory+pos) Wk^T + bk  ->  [NL][B][nH][Mpad][64]
+          V^T = (memory Wv^T + bv)^T    ->  [NL][B][nH][Mpad/KB][64][KB]
+        The padded tail (keys >= M) is zero from allocation and never written."""
+        KB = 16 if self.dtype == torch.float32 else 32
+        Mpad = _round_up(M, KB)
         key = (B, M)
         if key not in self._kv:
-            nld = self.NL * self.d
-            self._kv[key] = (torch.empty(B * M, nld, dtype=self.dtype, device=self.device),
-                             torch.zeros(B, nld, Mpad, dtype=self.dtype, device=self.device))
+            self._kv[key] = (torch.zeros(self.NL, B, self.nH, Mpad, 64, dtype=self.dtype, device=self.device),
+                             torch.zeros(self.NL, B, self.nH, Mpad // KB, 64, KB, dtype=self.dtype, device=self.device))
         K_all, Vt_all = self._kv[key]
-        ops.gemm(mem_pos, self.Wk_all, self.bk_all, out=K_all)
-        ops.gemm(memory, self.Wv_all, self.bv_all, out=Vt_all, trans_rows=M, trans_ld=Mpad, ldc=Mpad)
-        return dict(K=K_all, Vt=Vt_all, B=B, M=M, Mpad=Mpad, key_mask=key_mask)
+        geom = (B, M, Mpad, self.nH, KB)
+        ops.gemm(mem_pos, self.Wk_all, self.bk_all, out=K_all, store_mode=_lib.STORE_KBLK, kv=geom)
+        # swapped operands: rows = value features, columns = memory tokens, so a lane owns 4 consecutive keys
+        ops.gemm(self.Wv_all, memory, self.bv_all, out=Vt_all, store_mode=_lib.STORE_VBLK, kv=geom, bias_along_m=True,
+                 M=self.Wv_all.shape[0], N=B * M, K=self.d)
+        return dict(K=K_all, Vt=Vt_all, B=B, M=M, Mpad=Mpad, KB=KB, key_mask=key_mask)
 
     # -- plans --------------------------------------------------------------------------------------
     def _phase(self, kind, R, Lmax, seq_ld, n_split):
@@ -146,41 +157,46 @@ class Decoder(object):
 
     @staticmethod
     def make_tiles(counts):
-        """rows sorted by image; tiles of <=16 consecutive rows of ONE image: (row0, nrows, image)."""
-        tiles, r0 = [], 0
+        """rows sorted by image -> (groups, q_tiles): groups of <= 16*q_tiles consecutive rows of ONE image,
+        (row0, nrows, image); one cross-attention workgroup streams an (image, head) key range once per group."""
+        mx = max(counts) if counts else 1
+        qt = 1 if mx <= 16 else (2 if mx <= 32 else 4)
+        groups, r0 = [], 0
         for img, n in enumerate(counts):
-            for o in range(0, n, 16):
-                tiles.append((r0 + o, min(16, n - o), img))
+            for o in range(0, n, 16 * qt):
+                groups.append((r0 + o, min(16 * qt, n - o), img))
             r0 += n
-        return tiles
+        return groups, qt
 
     def _bind(self, ph, kv, tiles, n_prompt, suppress_eos, infer_vie):
+        tiles, qt = tiles
         P, a, d = ph.plan, self.args, self.d
         esz = 4 if self.dtype == torch.float32 else 2
         P.dtype, P.n_layers, P.d_model, P.n_heads, P.d_ff, P.vocab = ops.dt(self.dtype), self.L, d, self.nH, self.ff, self.V
         P.pre_norm = 1 if a.tfm_pre_norm else 0
-        P.R, P.Lmax, P.M, P.n_tiles, P.n_split, P.n_prompt = ph.R, ph.Lmax, kv['M'], len(tiles), ph.n_split, n_prompt
+        P.R, P.Lmax, P.M, P.Mpad, P.n_tiles, P.q_tiles, P.n_split, P.n_prompt = (ph.R, ph.Lmax, kv['M'], kv['Mpad'], len(tiles), qt,
+                                                                                 ph.n_split, n_prompt)
         P.eps = LN_EPS
         t = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 3)
         ph.tiles[:t.shape[0]].copy_(t.to(self.device, non_blocking=False))
         ph.n_tiles = t.shape[0]
         kidx = KINDS.index(ph.kind)
-        nld = self.NL * d
+        img_stride = self.nH * kv['Mpad'] * 64
+        slab = kv['B'] * img_stride   # one (decoder, layer) slab, K and V^T alike
         for l, w in enumerate(self.layers[ph.kind]):
             Lc = P.layers[l]
             for name in ('sa_in_w', 'sa_bias_tab', 'sa_out_w', 'sa_out_b', 'ca_q_w', 'ca_qbias_tab', 'ca_out_w',
                          'ca_out_b', 'ff1_w', 'ff1_b', 'ff2_w', 'ff2_b', 'n1_g', 'n1_b', 'n2_g', 'n2_b', 'n3_g', 'n3_b'):
                 setattr(Lc, name, w[name].data_ptr())
             Lc.kcache, Lc.vcache = ph.kc[l].data_ptr(), ph.vc[l].data_ptr()
-            off = (kidx * self.L + l) * d
-            Lc.crossK = kv['K'].data_ptr() + off * esz
-            Lc.crossVt = kv['Vt'].data_ptr() + off * kv['Mpad'] * esz
+            off = (kidx * self.L + l) * slab * esz
+            Lc.crossK = kv['K'].data_ptr() + off
+            Lc.crossVt = kv['Vt'].data_ptr() + off
         P.word_emb, P.pos_tab = self.word.data_ptr(), self.pos_tab[ph.kind].data_ptr()
         P.emb_g, P.emb_b = self.emb_g.data_ptr(), self.emb_b.data_ptr()
         P.fn_g, P.fn_b = self.fn[ph.kind][0].data_ptr(), self.fn[ph.kind][1].data_ptr()
         (P.h0_w, P.h0_b), (P.h1_w, P.h1_b), (P.h2_w, P.h2_b) = [(w.data_ptr(), b.data_ptr()) for w, b in self.head[ph.kind]]
-        P.ldk, P.k_batch_stride = nld, kv['M'] * nld
-        P.ldvt, P.vt_batch_stride = kv['Mpad'], nld * kv['Mpad']
+        P.kv_img_stride = img_stride
         P.key_mask = kv['key_mask'].data_ptr() if kv['key_mask'] is not None else None
         P.tiles = ph.tiles.data_ptr()
         P.seq, P.seq_ld, P.d_pos, P.probs = ph.seq.data_ptr(), ph.seq_ld, ph.d_pos.data_ptr(), ph.probs.data_ptr()
@@ -194,7 +210,14 @@ class Decoder(object):
         ph._keepalive = (kv['K'], kv['Vt'], kv['key_mask'])
         return P
 
-    _next_slot = [0]   # graph slots live in the shared library: ids must be unique per PROCESS
+    _slot_ids = itertools.count()   # graph slots live in the shared library: ids must be unique per PROCESS
+
+    def fork(self):
+        """A decoder that shares the packed weights but owns its phase buffers, K/V slabs and graph slots:
+        one per pipeline lane (engine/pipeline.py), so lanes can be in different phases at the same time."""
+        other = copy.copy(self)
+        other._graph_slots, other._phases, other._kv = {}, {}, {}
+        return other
 
     def __del__(self):
         try:
@@ -210,8 +233,7 @@ class Decoder(object):
             return -1
         key = bytes(plan)
         if key not in self._graph_slots:
-            self._graph_slots[key] = Decoder._next_slot[0]
-            Decoder._next_slot[0] += 1
+            self._graph_slots[key] = next(Decoder._slot_ids)
         return self._graph_slots[key]
 
     def _run(self, ph, first_pos, n_steps):
@@ -220,19 +242,21 @@ class Decoder(object):
         rc = _lib.lib().omp_decoder_run(ctypes.byref(ph.plan), first_pos, n_steps, self._slot(ph.plan), ops.stream())
         _lib.check(rc, 'omp_decoder_run')
 
-    def _n_split(self, n_tiles, M):
-        """Key slices per (tile, head) of the cross-attention kernel: up to 4 waves per workgroup (merged in
-        LDS) x S workgroups (merged by a small kernel).  Aim for >= 512 workgroups so that all 256 CUs pull
-        from HBM; power of two, at least one key block per slice."""
+    def _n_split(self, tiles, M):
+        """Workgroup-level key splits S of the cross-attention kernel (each workgroup's 4 waves split again).
+        Per-wave slice ~4 key blocks (one memory round trip with 4 blocks in flight) but never fewer than
+        ~512 workgroups' worth of parallelism when the memory is large; power of two <= 16."""
+        groups, qt = tiles
         kb = 16 if self.dtype == torch.float32 else 32
-        wgs = max(1, n_tiles * self.nH)
+        if self.n_split_override:
+            return self.n_split_override
+        per_wave = 4 * kb * (2 if qt > 1 else 1)
         S = 1
-        while wgs * S < 512 and S < 16:
+        while S < 16 and 4 * S * per_wave < M:
             S *= 2
-        ns = 4 * S
-        while ns > 1 and ns * kb > M:
-            ns //= 2
-        return ns
+        while S > 1 and len(groups) * self.nH * S > 4096:
+            S //= 2
+        return S
 
     # -- greedy drivers ---------------------------------------------------------------------------
     def decode_points(self, kv, prompt, max_new=None, forced_instances=None, poll=16):
@@ -246,7 +270,7 @@ class Decoder(object):
         if suppress:
             S = min((3 if a.infer_vie else 2) * forced_instances, limit)
         tiles = self.make_tiles([1] * B)
-        ph = self._phase('pt', B, n_prompt - 1 + S, n_prompt + S + 1, self._n_split(len(tiles), kv['M']))
+        ph = self._phase('pt', B, n_prompt - 1 + S, n_prompt + S + 1, self._n_split(tiles, kv['M']))
         self._bind(ph, kv, tiles, n_prompt, suppress, a.infer_vie)
         ph.seq.zero_(); ph.probs.zero_(); ph.finished.zero_(); ph.lengths.zero_(); ph.d_pos.zero_()
         ph.seq[:, :n_prompt] = torch.tensor(prompt, dtype=torch.int32, device=self.device)
@@ -280,7 +304,7 @@ class Decoder(object):
         [R,2] on the device.  Returns the phase; drive it with `_run(ph, pos, n)` for 2 + n_new positions."""
         R = int(points.shape[0])
         tiles = self.make_tiles(counts)
-        ph = self._phase(kind, R, 2 + n_new, 3 + n_new + 1, self._n_split(len(tiles), kv['M']))
+        ph = self._phase(kind, R, 2 + n_new, 3 + n_new + 1, self._n_split(tiles, kv['M']))
         self._bind(ph, kv, tiles, 3, False, infer_vie)
         ph.d_pos.zero_()
         ph.seq[:, 0:2] = points
@@ -331,7 +355,7 @@ class Decoder(object):
         seqs = seqs.to(self.device, torch.int32)
         R, Ls = seqs.shape
         tiles = self.make_tiles(counts)
-        ph = self._phase(kind, R, Ls, Ls + 1, self._n_split(len(tiles), kv['M']))
+        ph = self._phase(kind, R, Ls, Ls + 1, self._n_split(tiles, kv['M']))
         self._bind(ph, kv, tiles, n_prompt, False, infer_vie)
         ph.d_pos.zero_()
         ph.seq[:, :Ls] = seqs

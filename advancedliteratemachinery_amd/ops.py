@@ -54,7 +54,7 @@ def layernorm(x, gamma, beta, out_dtype=None, out=None, out_f32=None, eps=1e-5, 
 
 def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None, M=None, lda=None,
          ldw=None, ldc=None, N=None, K=None, bias_row=None, bias_row_stride=0, trans_rows=0, trans_ld=0,
-         ln=None, ln_eps=1e-5, small_m=False):
+         ln=None, ln_eps=1e-5, small_m=False, store_mode=0, kv=None, bias_along_m=False):
     """out[M,N] = act(A[M,K] @ W[N,K]^T + bias) + residual.  A/W may be strided row views (lda/ldw)."""
     K = K or A.shape[-1]
     N = N or W.shape[0]
@@ -66,7 +66,7 @@ def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
         if trans_rows:
             raise ValueError('trans_out needs a preallocated (zeroed) output')
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
-    ldc = ldc or (out.stride(-2) if out.dim() > 1 else N)
+    ldc = ldc or (out.stride(-2) if out.dim() > 1 and not store_mode else N)
     a = _lib.GemmArgs()
     a.A, a.lda, a.W, a.ldw = ptr(A), lda, ptr(W), ldw
     a.bias, a.bias_row, a.bias_row_stride = ptr(bias), ptr(bias_row), bias_row_stride
@@ -77,6 +77,9 @@ def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     if ln is not None:
         a.ln_gamma, a.ln_beta, a.ln_eps = ptr(ln[0]), ptr(ln[1]), float(ln_eps)
     a.small_m_splitk = 1 if small_m else 0
+    a.store_mode, a.bias_along_m = store_mode, 1 if bias_along_m else 0
+    if kv is not None:  # (images, tokens per image, padded tokens, heads, key block) of the blocked K / V^T slabs
+        a.kv_images, a.kv_tokens, a.kv_mpad, a.kv_heads, a.kv_key_block = kv
     a.trans_out, a.trans_rows, a.trans_ld = (1 if trans_rows else 0), trans_rows, trans_ld
     rc = _lib.lib().omp_gemm_bias_act(ctypes.byref(a), stream())
     _lib.check(rc, 'omp_gemm_bias_act')
@@ -151,11 +154,11 @@ def dec_self_attn_step(qkv, kcache, vcache, out, d_pos, nH):
     _lib.check(rc, 'omp_dec_self_attn_step')
 
 
-def dec_cross_attn_step(q, K, ldk, kbs, Vt, ldvt, vbs, key_mask, tiles, n_tiles, partial, out, M, nH, n_split):
+def dec_cross_attn_step(q, K, Vt, img_stride, Mpad, key_mask, groups, n_groups, q_tiles, partial, out, M, nH, n_split):
     R = q.shape[0]
-    rc = _lib.lib().omp_dec_cross_attn_step(ptr(q), q.stride(0), ptr(K), ldk, kbs, ptr(Vt), ldvt, vbs,
-                                            ptr(key_mask), ptr(tiles), n_tiles, R, ptr(partial), ptr(out),
-                                            out.stride(0), dt(q), M, nH, n_split, stream())
+    rc = _lib.lib().omp_dec_cross_attn_step(ptr(q), q.stride(0), ptr(K), ptr(Vt), img_stride, Mpad, ptr(key_mask),
+                                            ptr(groups), n_groups, q_tiles, R, ptr(partial), ptr(out), out.stride(0),
+                                            dt(q), M, nH, n_split, stream())
     _lib.check(rc, 'omp_dec_cross_attn_step')
 
 
@@ -170,3 +173,8 @@ def head_sample(logits, cfg, seq, probs, finished, lengths, d_pos, advance=True)
 def force_gemm_kernel(which):
     """debug/testing: 0 auto, 1 tiled 128x128, 2 tiled 64x64, 3 row-streaming."""
     _lib.check(_lib.lib().omp_debug_force_gemm_kernel(which), 'omp_debug_force_gemm_kernel')
+
+
+def swin_attn_impl(which):
+    """debug/testing: 0 = matrix-core window attention (default), 1 = scalar cross-check kernel."""
+    _lib.check(_lib.lib().omp_debug_swin_attn_impl(which), 'omp_debug_swin_attn_impl')

@@ -26,12 +26,13 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 1
+#define OMP_ABI_VERSION 2
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
 enum { OMP_F32 = 0, OMP_BF16 = 1 };
 enum { OMP_ACT_NONE = 0, OMP_ACT_GELU = 1, OMP_ACT_RELU = 2 };
+enum { OMP_STORE_PLAIN = 0, OMP_STORE_KBLK = 2, OMP_STORE_VBLK = 3 };
 /* decoder kinds (reference: model/transformer.py:26-33 pt/poly/rec decoders) */
 enum { OMP_DEC_PT = 0, OMP_DEC_POLY = 1, OMP_DEC_REC = 2 };
 
@@ -84,6 +85,18 @@ typedef struct {
   const float* ln_beta;
   float ln_eps;
   int32_t small_m_splitk; /* hint: M <= 64 weight-streaming GEMM -> split-K workgroups */
+  /* destination layout.  OMP_STORE_KBLK / OMP_STORE_VBLK write the decoder cross-attention memory
+   * K / V straight into the head-blocked slabs omp_dec_cross_attn_step streams (see DESIGN.md
+   * "cross-attention memory layout"):
+   *   KBLK: M = kv_images*kv_tokens memory tokens, N = n_slabs*kv_heads*64 features ->
+   *         C[slab][image][head][kv_mpad][64]
+   *   VBLK: operands swapped by the caller (A = Wv [n_slabs*kv_heads*64, K], W = memory tokens
+   *         [kv_images*kv_tokens, K], bias_along_m = 1) ->
+   *         C[slab][image][head][kv_mpad/kv_key_block][64][kv_key_block], keys of a block in
+   *         matrix-core order (bf16, block 32: slot 8g+4*half+r <- key 16*half+4g+r; f32, block 16: natural) */
+  int32_t store_mode;
+  int32_t bias_along_m; /* bias[m] instead of bias[n] */
+  int32_t kv_images, kv_tokens, kv_mpad, kv_heads, kv_key_block;
 } omp_gemm_args;
 int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s);
 
@@ -142,17 +155,18 @@ int omp_dec_self_attn_step(const void* qkv, void* kcache, void* vcache, void* ou
                            const int32_t* d_pos, int dtype, int R, int nH, int d, int Lmax,
                            omp_stream_t s);
 
-/* Cross attention of R query rows over per-image memory K [B][M][ldk] / V^T [B][d][M]; rows are
- * grouped in tiles of <=16 consecutive rows of one image: tiles[t] = {row0, nrows, image}.
- * Keys are split in n_split chunks (flash-style partials in `partial`, fp32
- * [R][nH][n_split][66], R = total rows) and combined.  All queries of an image share its K/V: the memory
- * is never replicated.  Replaces multihead_attn of transformer.py:416-420/:442-446 with
- * memory.repeat (transformer.py:88-96). */
-int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K, int64_t ldk,
-                            int64_t k_batch_stride, const void* Vt, int64_t ldvt,
-                            int64_t vt_batch_stride, const uint8_t* key_mask, const int32_t* tiles,
-                            int n_tiles, int R, float* partial, void* out, int64_t ldo, int dtype,
-                            int M, int nH, int n_split, omp_stream_t s);
+/* Cross attention of R query rows over per-image memory K / V^T in the head-blocked slabs written by
+ * omp_gemm_bias_act(OMP_STORE_KBLK / OMP_STORE_VBLK):  K [image][head][Mpad][64],
+ * V^T [image][head][Mpad/KB][64][KB] (KB = 32 bf16 / 16 f32), img_stride = nH*Mpad*64 elements.
+ * Rows are grouped by image: groups[g] = {row0, nrows <= 16*q_tiles, image}; a workgroup streams its
+ * key range of one (image, head) once for all rows of the group.  Keys are cut in n_split workgroup
+ * splits (power of two <= 16) x 4 waves; n_split > 1 goes through `partial`
+ * (fp32 [R][nH][n_split][68]) and a merge kernel.  The memory is never replicated per query row.
+ * Replaces multihead_attn of transformer.py:416-420/:442-446 with memory.repeat (transformer.py:88-96). */
+int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K, const void* Vt, int64_t img_stride,
+                            int Mpad, const uint8_t* key_mask, const int32_t* groups, int n_groups,
+                            int q_tiles, int R, float* partial, void* out, int64_t ldo, int dtype, int M,
+                            int nH, int n_split, omp_stream_t s);
 
 /* Greedy sampling of one step from logits [R, ld] fp32: softmax over the support, candidate
  * filtering, argmax, probability; appends the token at seq[r, *d_pos + 1], the probability at
@@ -189,19 +203,19 @@ typedef struct {
   const float *n1_g, *n1_b, *n2_g, *n2_b, *n3_g, *n3_b;
   void* kcache;                /* [R,Lmax,d] */
   void* vcache;
-  const void* crossK;          /* [B][M][ldk] slice of this layer */
-  const void* crossVt;         /* [B][d][M] slice of this layer */
+  const void* crossK;          /* this layer's K slab   [B][nH][Mpad][64] */
+  const void* crossVt;         /* this layer's V^T slab [B][nH][Mpad/KB][64][KB] */
 } omp_dec_layer;
 
 typedef struct {
   int32_t dtype, n_layers, d_model, n_heads, d_ff, vocab, pre_norm;
-  int32_t R, Lmax, M, n_tiles, n_split, n_prompt;
+  int32_t R, Lmax, M, Mpad, n_tiles, q_tiles, n_split, n_prompt; /* n_tiles = row groups, see omp_dec_cross_attn_step */
   float eps;
   omp_dec_layer layers[OMP_MAX_DEC_LAYERS];
   const float *word_emb, *pos_tab, *emb_g, *emb_b, *fn_g, *fn_b;
   const void *h0_w, *h1_w, *h2_w;
   const float *h0_b, *h1_b, *h2_b;
-  int64_t ldk, k_batch_stride, ldvt, vt_batch_stride;
+  int64_t kv_img_stride;
   const uint8_t* key_mask;
   const int32_t* tiles;
   /* state */
@@ -240,6 +254,7 @@ int omp_prof_enable(int on);
 int omp_prof_read(double* total_ms, int64_t* count);
 int omp_debug_force_gemm_kernel(int which);
 int omp_debug_set_gemm_prefetch(int tiles);
+int omp_debug_swin_attn_impl(int which); /* 0 = matrix-core kernel (default), 1 = scalar cross-check kernel */
 
 /* Single teacher-forced step that also leaves logits in plan->logits (parity tests). */
 int omp_decoder_step_logits(const omp_decoder_plan* plan, int pos, omp_stream_t s);

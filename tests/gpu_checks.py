@@ -67,7 +67,7 @@ def check_gemm():
               (64, 512, 512), (2049, 256, 1024), (16, 2048, 512)]
     for dn, dt in DTYPES.items():
         tol = 2e-4 if dt == torch.float32 else 3e-2
-        for which in (0, 1, 2, 3):
+        for which in (0, 1, 2, 3, 5):
             ops.force_gemm_kernel(which)
             for (M, N, K) in shapes:
                 if which == 3 and M > 600:
@@ -146,8 +146,17 @@ def check_patch_embed():
 
 def check_window_attn():
     out = []
+    for impl, iname in ((0, 'mfma'), (1, 'scalar')):
+        ops.swin_attn_impl(impl)
+        out += _check_window_attn(iname)
+    ops.swin_attn_impl(0)
+    return out
+
+
+def _check_window_attn(iname):
+    out = []
     for dn, dt in DTYPES.items():
-        for (B, H, W, C, nH) in ((2, 10, 13, 128, 4), (1, 14, 14, 256, 8), (2, 5, 7, 1024, 32), (1, 20, 9, 512, 16)):
+        for (B, H, W, C, nH) in ((2, 10, 13, 128, 4), (1, 14, 14, 256, 8), (2, 5, 7, 1024, 32), (1, 20, 9, 512, 16), (1, 3, 30, 96, 3)):
             for shift in (0, 3):
                 x = rnd(B, H, W, C, seed=C + shift)
                 Wqkv = q(rnd(3 * C, C, seed=1) / math.sqrt(C) * 2, dt)
@@ -156,7 +165,7 @@ def check_window_attn():
                 # the reference core is evaluated on the SAME (rounded) qkv values
                 ref = _ref_window_attention_from_qkv(qkv_in.reshape(B, H, W, 3 * C), bqkv, table, nH, shift)
                 y = ops.swin_window_attn(qkv_in.to(DEV, dt), bqkv.to(DEV), table.to(DEV), B, H, W, C, nH, shift)
-                out.append(rec('window_attn[%s,B%d %dx%d C%d shift%d]' % (dn, B, H, W, C, shift),
+                out.append(rec('window_attn[%s,%s,B%d %dx%d C%d shift%d]' % (iname, dn, B, H, W, C, shift),
                                maxerr(y.reshape(B, H, W, C), ref), 2e-5 if dt == torch.float32 else 3e-2))
     return out
 
@@ -271,6 +280,71 @@ def check_sampling():
                 adv = abs(int(d_pos.item()) - (3 + step))
                 out.append(rec('sample[%s,vie%d,step%d]' % (kind, vie, step), mism + adv + (0 if perr < 1e-5 else 1), 0,
                                'perr=%.2e' % perr))
+    return out
+
+
+def check_cross_attn():
+    """K/V projection into the head-blocked slabs (OMP_STORE_KBLK / OMP_STORE_VBLK GEMM epilogues) followed by
+    omp_dec_cross_attn_step, vs softmax attention in plain fp32 (what nn.MultiheadAttention computes,
+    transformer.py:442-446): ragged row groups, key padding mask, every query-tile count and key split."""
+    from advancedliteratemachinery_amd import _lib
+    from advancedliteratemachinery_amd.model.transformer import Decoder
+    out = []
+    nH, d = 8, 512
+    for dn, dt in DTYPES.items():
+        KB = 16 if dt == torch.float32 else 32
+        tol = 2e-5 if dt == torch.float32 else 2e-2
+        for (B, M, counts, masked) in ((2, 77, [19, 3], True), (3, 300, [1, 1, 1], False), (2, 130, [40, 64], True), (1, 4096, [5], False)):
+            Mpad = (M + KB - 1) // KB * KB
+            mem = q(rnd(B * M, d, seed=M), dt)
+            NLd = 2 * d   # two (decoder, layer) slabs
+            Wk, Wv = q(rnd(NLd, d, seed=1) / math.sqrt(d), dt), q(rnd(NLd, d, seed=2) / math.sqrt(d), dt)
+            bk, bv = rnd(NLd, seed=3) * 0.1, rnd(NLd, seed=4) * 0.1
+            Kd = torch.zeros(2, B, nH, Mpad, 64, device=DEV, dtype=dt)
+            Vd = torch.zeros(2, B, nH, Mpad // KB, 64, KB, device=DEV, dtype=dt)
+            geom = (B, M, Mpad, nH, KB)
+            ops.gemm(mem.to(DEV, dt), Wk.to(DEV, dt), bk.to(DEV), out=Kd, store_mode=_lib.STORE_KBLK, kv=geom)
+            ops.gemm(Wv.to(DEV, dt), mem.to(DEV, dt), bv.to(DEV), out=Vd, store_mode=_lib.STORE_VBLK, kv=geom, bias_along_m=True,
+                     M=NLd, N=B * M, K=d)
+            Kref = q(mem @ Wk.t() + bk, dt).reshape(B, M, 2, nH, 64)
+            Vref = q(mem @ Wv.t() + bv, dt).reshape(B, M, 2, nH, 64)
+            # layout check of the slabs themselves (slab 1)
+            kerr = maxerr(Kd[1, :, :, :M], Kref[:, :, 1].permute(0, 2, 1, 3))
+            vblk = Vd[1].float().cpu()   # [B][nH][Mpad/KB][64][KB]
+            if KB == 32:
+                kl = torch.arange(32)
+                pos = ((kl & 15) >> 2) * 8 + (kl >> 4) * 4 + (kl & 3)
+                nat = torch.empty_like(vblk)
+                nat[..., kl] = vblk[..., pos]
+                vblk = nat
+            vnat = vblk.permute(0, 1, 2, 4, 3).reshape(B, nH, Mpad, 64)[:, :, :M]
+            verr = maxerr(vnat, Vref[:, :, 1].permute(0, 2, 1, 3))
+            out.append(rec('kv_slabs[%s,B%d,M%d] K' % (dn, B, M), kerr, tol))
+            out.append(rec('kv_slabs[%s,B%d,M%d] V^T' % (dn, B, M), verr, tol))
+            R = sum(counts)
+            qq = q(rnd(R, d, seed=7), dt)
+            kmask = torch.zeros(B, M, dtype=torch.bool)
+            if masked:
+                kmask[B - 1, M - M // 3:] = True
+            # reference (slab 1)
+            ref = torch.empty(R, d)
+            r0 = 0
+            for b, n in enumerate(counts):
+                qh = qq[r0:r0 + n].reshape(n, nH, 64).permute(1, 0, 2) / 8.0
+                kh = Kref[b, :, 1].permute(1, 0, 2)
+                vh = Vref[b, :, 1].permute(1, 0, 2)
+                att = qh @ kh.transpose(-2, -1)
+                att = att.masked_fill(kmask[b][None, None, :], float('-inf')).softmax(-1)
+                ref[r0:r0 + n] = (att @ vh).permute(1, 0, 2).reshape(n, d)
+                r0 += n
+            groups, qt = Decoder.make_tiles(counts)
+            gd = torch.tensor(groups, dtype=torch.int32, device=DEV)
+            km = kmask.to(torch.uint8).to(DEV) if masked else None
+            for S in (1, 2, 8):
+                o = torch.empty(R, d, device=DEV, dtype=dt)
+                partial = torch.empty(R, nH, S, 68, device=DEV)
+                ops.dec_cross_attn_step(qq.to(DEV, dt), Kd[1], Vd[1], nH * Mpad * 64, Mpad, km, gd, len(groups), qt, partial, o, M, nH, S)
+                out.append(rec('cross_attn[%s,B%d,M%d,qt%d,S%d,mask=%s]' % (dn, B, M, qt, S, masked), maxerr(o, ref), tol))
     return out
 
 
@@ -445,5 +519,41 @@ def check_graph_matches_eager(dtype_name='fp32'):
     return [rec('graph==eager[%s]' % dtype_name, bad, 0)]
 
 
+def check_lanes(dtype_name='fp32', n_lanes=3, n_jobs=7):
+    """engine/pipeline.py: batches pipelined over lanes (own streams, forked decoder state, graphs) return
+    exactly what the synchronous path returns, whatever lane they ran on and however they overlapped."""
+    from advancedliteratemachinery_amd.engine.pipeline import LanePool
+    args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=8)
+    depths = (2, 2, 2, 2)
+    sd = weights.make_state_dict(args, seed=6, depths=depths)
+    model = build_model(args, sd, depths, DTYPES[dtype_name], graph=True)
+    model.engine()
+    seqs = O.default_prompts(args)
+    jobs = []
+    for j in range(n_jobs):
+        B = 1 + j % 3
+        imgs = rnd(B, 3, 64 + 32 * (j % 2), 96, seed=20 + j).to(DEV)
+        jobs.append((imgs, torch.zeros(B, imgs.shape[2], 96, dtype=torch.bool, device=DEV)))
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ref = [model.infer(i, m, seqs, forced_instances=3) for i, m in jobs]
+    st.synchronize()
+    pool = LanePool(DEV, n_lanes)
+    bad = 0
+    try:
+        for rep in range(2):   # second round replays every lane's captured graphs
+            futs = [pool.infer(model, i, m, seqs, forced_instances=3) for i, m in jobs]
+            for f, r in zip(futs, ref):
+                got, ev = f.result()
+                ev.synchronize()
+                for gb, rb in zip(got, r):
+                    for k in range(3):
+                        bad += 0 if bool((gb[0][k] == rb[0][k]).all()) else 1
+                    bad += 0 if maxerr(gb[1][0], rb[1][0]) < 1e-6 else 1
+    finally:
+        pool.close()
+    return [rec('lanes==direct[%s,%d lanes,%d jobs]' % (dtype_name, n_lanes, n_jobs), bad, 0)]
+
+
 ALL_OP_CHECKS = [check_layernorm, check_gemm, check_gemm_small, check_patch_embed, check_window_attn, check_patch_merge, check_fpn,
-                 check_posembed, check_sampling]
+                 check_posembed, check_sampling, check_cross_attn]

@@ -43,3 +43,8 @@ def test_golden_fp32_graph_and_overlap(C, name):
 
 def test_graph_replay_matches_eager(C):
     _assert_all(C.check_graph_matches_eager('fp32'))
+
+
+def test_pipelined_lanes_match_direct(C):
+    """Batches in flight on several HIP streams (engine/pipeline.py) == the synchronous path."""
+    _assert_all(C.check_lanes('fp32'))

@@ -19,7 +19,7 @@ def C():
 
 
 @pytest.mark.parametrize('name', ['check_layernorm', 'check_gemm', 'check_gemm_small', 'check_patch_embed', 'check_window_attn',
-                                  'check_patch_merge', 'check_fpn', 'check_posembed', 'check_sampling'])
+                                  'check_patch_merge', 'check_fpn', 'check_posembed', 'check_sampling', 'check_cross_attn'])
 def test_op(C, name):
     _assert_all(getattr(C, name)())
 

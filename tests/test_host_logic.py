@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name), 'libomp355.so does not export %s' % name
-    assert h.omp_abi_version() == 1
+    assert h.omp_abi_version() == _lib.ABI_VERSION
 
 
 def test_state_dict_layout_matches_reference_keys():
@@ -155,3 +155,35 @@ def test_decode_pred_seq_record_format():
     recs = decode_pred_seq([t[0] for t in r[0]], r[1][0], {'file_name': 'a.jpg', 'orig_size': (480, 640)}, args)
     assert len(recs) == 2 and set(recs[0]) == {'image_id', 'pts', 'score', 'polys', 'rec'}
     assert len(recs[0]['polys']) == 16 and abs(recs[0]['pts'][0][0] - r[0][0][0, 0].item() / 1000 * 640) < 1e-3
+
+
+def test_erf_fast_twin_matches_scipy():
+    """numpy twin of csrc/common.h erf_fast (the GELU epilogue's branch-free erf): same constants, fp32
+    arithmetic, checked against scipy.special.erf -- pins the coefficients the kernel is built with."""
+    import re
+    import numpy as np
+    from scipy.special import erf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'advancedliteratemachinery_amd', 'csrc', 'common.h')).read()
+    body = src[src.index('float erf_fast(float a)'):src.index('// nn.GELU()')]
+    consts = [float(c) for c in re.findall(r'(-?\d\.\d+e-?\d+)f', body)]
+    assert len(consts) == 13, consts
+    f = np.float32
+
+    def fma(a, b, c):
+        return (np.float64(a) * np.float64(b) + np.float64(c)).astype(f)
+    a = np.linspace(-6, 6, 400001).astype(f)
+    t, s_ = np.abs(a), (a * a).astype(f)
+    r = fma(f(consts[0]), t, f(consts[1]))
+    u = fma(f(consts[2]), t, f(consts[3]))
+    r = fma(r, s_, u)
+    for c in consts[4:7]:
+        r = fma(r, t, f(c))
+    r = fma(r, t, -t)
+    big = np.copysign((1.0 - np.exp(r.astype(np.float64))).astype(f), a)
+    q = np.full_like(a, consts[7])
+    for c in consts[8:13]:
+        q = fma(q, s_, f(c))
+    small = fma(q, a, a)
+    y = np.where(t > 0.927734375, big, small)
+    assert np.abs(y.astype(np.float64) - erf(a.astype(np.float64))).max() < 1.5e-7

@@ -45,6 +45,7 @@ def main():
     allr += run(C.check_batch_equivalence, 'fp32')
     allr += run(C.check_batch_equivalence, 'bf16')
     allr += run(C.check_graph_matches_eager, 'fp32')
+    allr += run(C.check_lanes, 'fp32')
     nbad = sum(1 for r in allr if not r['ok'])
     print('SUMMARY: %d checks, %d failed' % (len(allr), nbad))
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)

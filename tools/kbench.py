@@ -1,0 +1,156 @@
+"""Per-kernel micro-benchmarks on the GPU box (development aid; not part of the product or the tests).
+
+  python tools/kbench.py cross|gemm|dec_gemm|selfattn|all
+
+Times each libomp355 entry point in isolation with HIP events over many back-to-back launches on one
+stream (so launch gaps are included, as they are in a captured decoder step) and prints achieved
+GB/s / TFLOP/s next to the algorithmic bytes / flops."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from advancedliteratemachinery_amd import _lib, ops  # noqa: E402
+
+DEV = 'cuda'
+
+
+def timeit(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3  # us
+
+
+def bench_cross(dtype=torch.bfloat16):
+    B, M, nH, d = 8, 4096, 8, 512
+    KB = 32 if dtype == torch.bfloat16 else 16
+    esz = 2 if dtype == torch.bfloat16 else 4
+    Mpad = (M + KB - 1) // KB * KB
+    # several layer slabs so that consecutive launches do not hit the same (L2 / MALL resident) memory
+    NS = 6
+    K = torch.randn(NS, B, nH, Mpad, 64, device=DEV).to(dtype)
+    V = torch.randn(NS, B, nH, Mpad // KB, 64, KB, device=DEV).to(dtype)
+    for rows_per_img in (1, 64):
+        R = B * rows_per_img
+        qt = 1 if rows_per_img <= 16 else (2 if rows_per_img <= 32 else 4)
+        groups = []
+        for b in range(B):
+            for o in range(0, rows_per_img, 16 * qt):
+                groups.append((b * rows_per_img + o, min(16 * qt, rows_per_img - o), b))
+        g = torch.tensor(groups, dtype=torch.int32, device=DEV)
+        q = torch.randn(R, d, device=DEV).to(dtype)
+        out = torch.empty(R, d, device=DEV, dtype=dtype)
+        alg = B * 2 * M * d * esz + 2 * R * d * esz
+        for S in (1, 2, 4, 8, 16):
+            partial = torch.empty(R, nH, S, 68, device=DEV)
+            state = [0]
+
+            def fn():
+                i = state[0] % NS
+                state[0] += 1
+                ops.dec_cross_attn_step(q, K[i], V[i], nH * Mpad * 64, Mpad, None, g, len(groups), qt, partial, out, M, nH, S)
+            us = timeit(fn, iters=60)
+            print('cross[%s] rows/img=%-3d qt=%d S=%-2d groups=%d : %7.1f us  %6.0f GB/s (%.2f of 8 TB/s)'
+                  % (str(dtype)[6:], rows_per_img, qt, S, len(groups), us, alg / us / 1e3, alg / us / 1e3 / 8000), flush=True)
+
+
+def bench_gemm(dtype=torch.bfloat16):
+    # (M, N, K, act, residual) of the Swin-B stages at B=8 1024x1024 and the K/V projection
+    shapes = [(524288, 384, 128, 0, 0), (524288, 128, 128, 0, 1), (524288, 512, 128, 1, 0), (524288, 128, 512, 0, 1),
+              (131072, 768, 256, 0, 0), (131072, 256, 256, 0, 1), (131072, 1024, 256, 1, 0), (131072, 256, 1024, 0, 1),
+              (32768, 1536, 512, 0, 0), (32768, 512, 512, 0, 1), (32768, 2048, 512, 1, 0), (32768, 512, 2048, 0, 1),
+              (8192, 3072, 1024, 0, 0), (8192, 1024, 1024, 0, 1), (8192, 4096, 1024, 1, 0), (8192, 1024, 4096, 0, 1),
+              (32768, 6144, 512, 0, 0)]
+    for (M, N, K, act, res) in shapes:
+        A = torch.randn(M, K, device=DEV).to(dtype)
+        W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(dtype)
+        bias = torch.randn(N, device=DEV)
+        out = torch.empty(M, N, device=DEV, dtype=dtype)
+        r = torch.randn(M, N, device=DEV).to(dtype) if res else None
+        us = timeit(lambda: ops.gemm(A, W, bias, residual=r, act=act, out=out), iters=20, warm=3)
+        fl = 2.0 * M * N * K
+        by = (M * K + N * K + M * N * (2 if res else 1)) * 2
+        print('gemm[%s] %7dx%5dx%5d act=%d res=%d : %8.1f us  %6.1f TF/s  %6.0f GB/s' % (str(dtype)[6:], M, N, K, act, res, us, fl / us / 1e6, by / us / 1e3),
+              flush=True)
+
+
+def bench_dec_gemm(dtype=torch.bfloat16):
+    """decoder-step GEMMs: weight streaming at R = 8 rows (point decoder) and R = 512 (polygon / recognition)."""
+    for R in (8, 64, 512):
+        for (N, K, ln) in ((1536, 512, 1), (512, 512, 0), (2048, 512, 1), (512, 2048, 0), (1104, 512, 0)):
+            W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(dtype)
+            bias = torch.randn(N, device=DEV)
+            x = torch.randn(R, K, device=DEV)
+            g, b = torch.ones(K, device=DEV), torch.zeros(K, device=DEV)
+            A = x.to(dtype)
+            if ln and R <= 64:
+                out = torch.empty(R, N, device=DEV, dtype=dtype)
+                us = timeit(lambda: ops.gemm(x, W, bias, out=out, ln=(g, b)), iters=100)
+            elif ln:
+                out = torch.empty(R, N, device=DEV, dtype=dtype)
+                y = torch.empty(R, K, device=DEV, dtype=dtype)
+
+                def fn():
+                    ops.layernorm(x, g, b, out=y)
+                    ops.gemm(y, W, bias, out=out)
+                us = timeit(fn, iters=100)
+            else:
+                out = torch.zeros(R, N, device=DEV)
+                us = timeit(lambda: ops.gemm(A, W, bias, residual=out, out=out, out_dtype=torch.float32, small_m=True), iters=100)
+            print('dec_gemm[%s] R=%-3d N=%-4d K=%-4d ln=%d : %6.1f us  (weights %.2f MB -> %5.0f GB/s, %5.1f TF/s)'
+                  % (str(dtype)[6:], R, N, K, ln, us, N * K * 2 / 1e6, N * K * 2 / us / 1e3, 2.0 * R * N * K / us / 1e6), flush=True)
+
+
+def bench_selfattn(dtype=torch.bfloat16):
+    d, nH = 512, 8
+    for (R, Lmax, pos) in ((8, 140, 70), (8, 140, 135), (512, 40, 20), (512, 40, 34)):
+        qkv = torch.randn(R, 3 * d, device=DEV).to(dtype)
+        kc = torch.randn(R, Lmax, d, device=DEV).to(dtype)
+        vc = torch.randn(R, Lmax, d, device=DEV).to(dtype)
+        out = torch.empty(R, d, device=DEV, dtype=dtype)
+        dp = torch.tensor([pos], dtype=torch.int32, device=DEV)
+        us = timeit(lambda: ops.dec_self_attn_step(qkv, kc, vc, out, dp, nH), iters=100)
+        print('selfattn[%s] R=%-3d pos=%-3d : %6.1f us' % (str(dtype)[6:], R, pos, us), flush=True)
+
+
+def bench_misc(dtype=torch.bfloat16):
+    B, H, W = 8, 256, 256
+    for (C, nH, hh) in ((128, 4, 256), (256, 8, 128), (512, 16, 64), (1024, 32, 32)):
+        qkv = torch.randn(B * hh * hh, 3 * C, device=DEV).to(dtype)
+        bias = torch.randn(3 * C, device=DEV)
+        tab = torch.randn(169, nH, device=DEV)
+        out = torch.empty(B * hh * hh, C, device=DEV, dtype=dtype)
+        for shift in (0, 3):
+            us = timeit(lambda: ops.swin_window_attn(qkv, bias, tab, B, hh, hh, C, nH, shift, out=out), iters=10, warm=2)
+            by = B * hh * hh * 4 * C * 2
+            print('swin_attn C=%-4d shift=%d : %8.1f us  %6.0f GB/s' % (C, shift, us, by / us / 1e3), flush=True)
+        x = torch.randn(B * hh * hh, C, device=DEV).to(dtype)
+        g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        y = torch.empty_like(x)
+        us = timeit(lambda: ops.layernorm(x, g, b, out=y), iters=10, warm=2)
+        print('layernorm rows=%d C=%-4d : %8.1f us  %6.0f GB/s' % (B * hh * hh, C, us, 2 * x.numel() * 2 / us / 1e3), flush=True)
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['all']
+    print(torch.cuda.get_device_name(0), flush=True)
+    _lib.lib()
+    if 'cross' in what or 'all' in what:
+        bench_cross()
+    if 'dec_gemm' in what or 'all' in what:
+        bench_dec_gemm()
+    if 'selfattn' in what or 'all' in what:
+        bench_selfattn()
+    if 'gemm' in what or 'all' in what:
+        bench_gemm()
+    if 'misc' in what or 'all' in what:
+        bench_misc()
