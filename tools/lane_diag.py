@@ -1,0 +1,69 @@
+"""Bisect a pipelined-lanes hang on the GPU box (development aid).
+
+  python tools/lane_diag.py <scenario>      scenario: test | nograph | onelane | sameshape | relaxed | nolanes_threads
+
+Every scenario arms faulthandler (all thread stacks, then exit) so a hang costs <= 50 s and says where."""
+import faulthandler
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+faulthandler.dump_traceback_later(int(os.environ.get('DIAG_TIMEOUT', '50')), exit=True)
+
+import torch  # noqa: E402
+
+from tests import gpu_checks as C  # noqa: E402
+
+
+def log(*a):
+    print('[%6.2f]' % (time.time() - T0), *a, flush=True)
+
+
+T0 = time.time()
+
+
+def main():
+    sc = sys.argv[1]
+    from advancedliteratemachinery_amd.engine.pipeline import LanePool
+    from advancedliteratemachinery_amd.utils.parser import make_args
+    from oracle import omniparser_ref as O, weights
+    args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=8)
+    depths = (2, 2, 2, 2)
+    sd = weights.make_state_dict(args, seed=6, depths=depths)
+    graph = sc not in ('nograph',)
+    model = C.build_model(args, sd, depths, torch.float32, graph=graph)
+    model.engine()
+    seqs = O.default_prompts(args)
+    n_lanes = 1 if sc == 'onelane' else 3
+    jobs = []
+    for j in range(7):
+        B = 1 + (0 if sc == 'sameshape' else j % 3)
+        H = 64 + (0 if sc == 'sameshape' else 32 * (j % 2))
+        imgs = C.rnd(B, 3, H, 96, seed=20 + j).to('cuda')
+        jobs.append((imgs, torch.zeros(B, H, 96, dtype=torch.bool, device='cuda')))
+    log('scenario', sc, 'graph', graph, 'lanes', n_lanes)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ref = [model.infer(i, m, seqs, forced_instances=3) for i, m in jobs]
+    st.synchronize()
+    log('reference done')
+    pool = LanePool('cuda', n_lanes)
+    bad = 0
+    for rep in range(2):
+        futs = [pool.infer(model, i, m, seqs, forced_instances=3) for i, m in jobs]
+        for k, (f, r) in enumerate(zip(futs, ref)):
+            got, ev = f.result()
+            log('rep', rep, 'job', k, 'future ready')
+            ev.synchronize()
+            for gb, rb in zip(got, r):
+                for q in range(3):
+                    bad += 0 if bool((gb[0][q] == rb[0][q]).all()) else 1
+            log('rep', rep, 'job', k, 'compared, bad =', bad)
+    pool.close()
+    log('DONE scenario', sc, 'bad', bad)
+
+
+if __name__ == '__main__':
+    main()
