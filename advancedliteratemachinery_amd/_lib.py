@@ -82,6 +82,7 @@ _SIGS = {
     'omp_debug_force_gemm_kernel': (c_int, [c_int]),
     'omp_debug_set_gemm_prefetch': (c_int, [c_int]),
     'omp_debug_swin_attn_impl': (c_int, [c_int]),
+    'omp_debug_cross_q4': (c_int, [c_int]),
     'omp_prof_enable': (c_int, [c_int]),
     'omp_prof_read': (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
 }

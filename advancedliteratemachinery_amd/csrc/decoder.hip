@@ -107,12 +107,14 @@ __device__ __forceinline__ void store8(bf16_t* p, const float* v) {
 // across the 8 slots at the end.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc,
-                                                           T* __restrict__ vc, T* __restrict__ out,
-                                                           const int32_t* __restrict__ d_pos, int R, int nH,
-                                                           int d, int Lmax) {
-  const int r = blockIdx.x, h = blockIdx.y;
-  const int lane = threadIdx.x, js = lane >> 3, dc = lane & 7;
+__global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc,
+                                                            T* __restrict__ vc, T* __restrict__ out,
+                                                            const int32_t* __restrict__ d_pos, int R, int nH,
+                                                            int d, int Lmax) {
+  // 4 heads of one row per workgroup (waves are independent; fewer, fatter workgroups dispatch faster)
+  const int r = blockIdx.x, h = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (h >= nH) return;
+  const int lane = threadIdx.x & 63, js = lane >> 3, dc = lane & 7;
   const int p = *d_pos;
   const T* row = qkv + (int64_t)r * 3 * d + h * DH + dc * 8;
   float q[8], kn[8], vn[8];
@@ -235,6 +237,22 @@ struct CrossTraits<float> {
 };
 
 constexpr int CROSS_PSTR = 68;   // m, l, pad, pad, o[64]
+
+// wait until at most `blocks` of this wave's most recently issued key blocks (IPB DMA instructions each) are
+// still in flight (the count must be an immediate; the switch is wave-uniform)
+template <int IPB>
+__device__ __forceinline__ void wait_dma_blocks(int blocks) {
+  switch (blocks) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPB * 1) : "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPB * 2) : "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPB * 3) : "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPB * 4) : "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPB * 5) : "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPB * 6) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPB * 7) : "memory"); break;
+  }
+}
 
 template <typename T, int NW, int QT, int PD>
 __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
@@ -400,6 +418,170 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// cross attention, many query rows per image (33..64: the polygon / recognition phases), bf16.
+//
+// dec_cross_attn_kernel gives every wave ALL query tiles and a private key slice: with 4 tiles a wave has
+// room for only two key blocks in flight and serialises 4x(QK^T, softmax, PV) behind every block -- it is
+// latency bound (1.8 TB/s).  Here the decomposition is turned around: the 4 waves of a workgroup each own ONE
+// tile of 16 queries and all consume the SAME key stream, which is staged once per workgroup in an LDS ring by
+// DMA (global_load_lds_dwordx4): NS blocks of 32 keys (4 KB of K + 4 KB of V^T each) are in flight per
+// workgroup without costing a register, every byte of K/V still crosses HBM->CU once per (image, head), and
+// no cross-wave merge is needed (a wave owns its queries; only the S workgroup-level key splits meet, in
+// dec_cross_merge_kernel).  LDS image of a block = 32 rows x 128 B for K (row = key) and for V^T (row = two
+// consecutive dims x 32 key slots); a DMA instruction fills 8 rows lane-linearly, so the XOR swizzle that
+// makes the 16-byte fragment reads conflict-free (slot = chunk ^ (row & 7)) is applied to the per-lane
+// SOURCE address.  Ring protocol as in gemm_dma: wait own DMA of block b (counted vmcnt, later blocks stay in
+// flight) -> one s_barrier (everybody's part of b has landed, everybody is done with b-1) -> refill the
+// stage of b-1 with block b+NS-1 -> compute b.
+// ---------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
+  typedef bf16_t T;
+  typedef Mma<T> MM;
+  typedef MM::frag frag;
+  constexpr int KB = 32, BLKB = 8192;   // keys per block; bytes per ring stage (K then V^T)
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int grp = blockIdx.x, h = blockIdx.y, sp = blockIdx.z, S = gridDim.z;
+  const int row0 = p.groups[grp * 3], nrows = p.groups[grp * 3 + 1], img = p.groups[grp * 3 + 2];
+  const bool active = wave * 16 < nrows;          // wave-uniform: this wave's query tile exists
+  const int kbeg = sp * p.kpw;                    // kpw: keys per workgroup split, multiple of KB
+  int kend = kbeg + p.kpw;
+  if (kend > p.M) kend = p.M;
+  const int nblk = kbeg < kend ? (kend - kbeg + KB - 1) / KB : 0;
+
+  const int64_t slab = (int64_t)img * p.img_stride + (int64_t)h * p.Mpad * 64;
+  // DMA: lane l of this wave's instruction fills slot (l & 7) of row 8*wave + (l >> 3) of the block image
+  const int dr = lane >> 3, dc = (lane & 7) ^ dr;
+  const T* ksrc = reinterpret_cast<const T*>(p.K) + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
+  const T* vsrc = reinterpret_cast<const T*>(p.V) + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
+  auto issue = [&](int blk, int stage) {
+    const int64_t off = (int64_t)(kbeg + blk * KB) * 64;   // a block is KB*64 elements in both slabs
+    char* dst = ring + stage * BLKB + wave * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + off),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + off),
+                                     (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 0);
+  };
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < nblk) issue(t, t);
+
+  // fragment byte offsets inside a stage
+  int koff[2][2], voff[4];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) koff[sb][st] = (sb * 16 + li) * 128 + (((st * 4 + g) ^ (li & 7)) << 4);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int rw = dt * 8 + (li >> 1), c = (li & 1) * 4 + g;
+    voff[dt] = 4096 + rw * 128 + ((c ^ (rw & 7)) << 4);
+  }
+
+  // Q fragments (B operand) of this wave's tile, 1/sqrt(64) folded in
+  frag qf[2];
+  {
+    int qi = wave * 16 + li;
+    if (qi > nrows - 1) qi = nrows - 1;
+    const T* qp = reinterpret_cast<const T*>(p.q) + (int64_t)(row0 + qi) * p.ldq + h * DH + g * 8;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      float tmp[8];
+      unpack16(ld16<T>(qp + st * 32), tmp);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) tmp[i] *= 0.125f;
+      pack16(tmp, qf[st]);
+    }
+  }
+  const uint8_t* km = p.kmask ? p.kmask + (int64_t)img * p.M : nullptr;
+
+  float m = -INFINITY, lpart = 0.f;
+  f32x4 ot[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int st_c = 0, st_i = NS - 1;
+  for (int b = 0; b < nblk; ++b) {
+    const int after = nblk - 1 - b;
+    wait_dma_blocks<2>(after < NS - 2 ? after : NS - 2);
+    __builtin_amdgcn_s_barrier();
+    if (b + NS - 1 < nblk) issue(b + NS - 1, st_i);
+    if (active) {
+      const char* base = ring + st_c * BLKB;
+      const int k0 = kbeg + b * KB;
+      frag kc[2][2], vc[4];
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) kc[sb][st] = *reinterpret_cast<const frag*>(base + koff[sb][st]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vc[dt] = *reinterpret_cast<const frag*>(base + voff[dt]);
+      float sc[8];
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+        MM::mma(sacc, kc[sb][0], qf[0]);
+        MM::mma(sacc, kc[sb][1], qf[1]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[sb * 4 + r] = sacc[r];
+      }
+      if (k0 + KB > kend || km != nullptr) {   // wave-uniform: ragged tail of the split / key padding mask
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kk = k0 + sb * 16 + g * 4 + r;
+            if (kk >= kend || (km != nullptr && km[kk < p.M ? kk : p.M - 1])) sc[sb * 4 + r] = -INFINITY;
+          }
+      }
+      float bmax = sc[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) bmax = fmaxf(bmax, sc[i]);
+      bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
+      bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+      const float mn = fmaxf(m, bmax);
+      const float mref = (mn == -INFINITY) ? 0.f : mn;   // all keys so far masked: exp(-inf - 0) = 0, not NaN
+      const float alpha = __expf(m - mref);
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { sc[i] = __expf(sc[i] - mref); ps += sc[i]; }
+      lpart = lpart * alpha + ps;
+      m = mn;
+      const frag pf = CrossTraits<T>::pfrag(sc);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
+        MM::mma(ot[dt], vc[dt], pf);
+      }
+    }
+    st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+    st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
+  }
+
+  if (!active) return;
+  float l = lpart;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const int qi = wave * 16 + li;
+  if (qi >= nrows) return;
+  if (S == 1) {
+    T* dst = reinterpret_cast<T*>(p.out) + (int64_t)(row0 + qi) * p.ldo + h * DH + g * 4;
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<bf16x4*>(dst + dt * 16) = bf16x4{(bf16_t)(ot[dt][0] * inv), (bf16_t)(ot[dt][1] * inv),
+                                                          (bf16_t)(ot[dt][2] * inv), (bf16_t)(ot[dt][3] * inv)};
+  } else {
+    float* dst = p.partial + (((int64_t)(row0 + qi) * p.nH + h) * S + sp) * CROSS_PSTR;
+    if (g == 0) { dst[0] = m; dst[1] = l; }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(dst + 4 + dt * 16 + g * 4) = ot[dt];
+  }
+}
+
 // merge the S workgroup-level partials of every (row, head): one wave each, lane = output dim.
 // All loads are issued before any math (S <= 16) -- the merge is a latency-, not a bandwidth problem.
 template <typename T, int S>
@@ -527,6 +709,24 @@ int launch_merge(const CrossP& cp, int S, hipStream_t st) {
   return OMP_OK;
 }
 
+int g_cross_q4 = 1;   // 1 = LDS-ring kernel for 33..64 rows per image (bf16); 0 = register-streaming kernel everywhere
+
+template <int NS>
+int launch_cross_q4(const CrossP& cp, int n_groups, int S, hipStream_t st) {
+  const size_t smem = (size_t)NS * 8192;
+  auto kern = dec_cross_attn_q4_kernel<NS>;
+  static bool done = false;   // per template instantiation
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      omp_set_error("omp_dec_cross_attn_step: cannot raise dynamic LDS limit");
+      return OMP_ERR_LAUNCH;
+    }
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_groups, cp.nH, S), dim3(256), smem, st, cp);
+  return OMP_OK;
+}
+
 // S = workgroup-level key splits (power of two <= 16); each workgroup's 4 waves split its keys again.
 // qt = query tiles (of 16 rows) per group: 1, 2 or 4.
 int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t st) {
@@ -535,7 +735,8 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   if (S > 1 && cp.partial == nullptr) { omp_set_error("omp_dec_cross_attn_step: n_split %d needs a partial buffer", S); return OMP_ERR_INVALID; }
   const int KB = dtype == OMP_F32 ? 16 : 32;
   if (cp.Mpad % KB != 0 || cp.Mpad < cp.M) { omp_set_error("omp_dec_cross_attn_step: Mpad %d must be a multiple of %d and >= M", cp.Mpad, KB); return OMP_ERR_INVALID; }
-  const int slices = S * 4;
+  const bool q4 = g_cross_q4 != 0 && dtype == OMP_BF16 && qt == 4;   // waves own query tiles, not key slices
+  const int slices = q4 ? S : S * 4;
   cp.kpw = (((cp.M + slices - 1) / slices + KB - 1) / KB) * KB;
   const bool prof = g_prof && !g_capturing;
   if (prof) {
@@ -549,7 +750,8 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   int rc;
   const bool f = dtype == OMP_F32;
   // PD key blocks in flight per wave: with one query tile a wave's whole slice is usually 4 blocks -> all of it
-  if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st);
+  if (q4) rc = launch_cross_q4<8>(cp, n_groups, S, st);
+  else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st);
   else if (qt == 2) rc = f ? launch_cross_t<float, 2, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 2, 2>(cp, n_groups, S, st);
   else rc = f ? launch_cross_t<float, 4, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 4, 2>(cp, n_groups, S, st);
   if (rc != OMP_OK) return rc;
@@ -586,12 +788,12 @@ extern "C" int omp_dec_self_attn_step(const void* qkv, void* kcache, void* vcach
                                       omp_stream_t s) {
   OMP_CHECK_ARG(qkv && kcache && vcache && out && d_pos, "omp_dec_self_attn_step: null pointer");
   OMP_CHECK_ARG(d == nH * DH, "omp_dec_self_attn_step: head_dim must be 64 (d=%d nH=%d)", d, nH);
-  dim3 grid(R, nH);
+  dim3 grid(R, (nH + 3) / 4);
   if (dtype == OMP_F32)
-    hipLaunchKernelGGL((dec_self_attn_kernel<float>), grid, dim3(64), 0, (hipStream_t)s, (const float*)qkv,
+    hipLaunchKernelGGL((dec_self_attn_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv,
                        (float*)kcache, (float*)vcache, (float*)out, d_pos, R, nH, d, Lmax);
   else if (dtype == OMP_BF16)
-    hipLaunchKernelGGL((dec_self_attn_kernel<bf16_t>), grid, dim3(64), 0, (hipStream_t)s, (const bf16_t*)qkv,
+    hipLaunchKernelGGL((dec_self_attn_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv,
                        (bf16_t*)kcache, (bf16_t*)vcache, (bf16_t*)out, d_pos, R, nH, d, Lmax);
   else { omp_set_error("omp_dec_self_attn_step: bad dtype"); return OMP_ERR_INVALID; }
   OMP_CHECK_LAUNCH("omp_dec_self_attn_step");
@@ -753,6 +955,11 @@ extern "C" int omp_prof_read(double* total_ms, int64_t* count) {
   }
   if (total_ms) *total_ms = tot;
   if (count) *count = (int64_t)g_prof_used;
+  return OMP_OK;
+}
+
+extern "C" int omp_debug_cross_q4(int on) {
+  g_cross_q4 = on ? 1 : 0;
   return OMP_OK;
 }
 

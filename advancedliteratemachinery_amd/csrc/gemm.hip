@@ -19,7 +19,7 @@
 namespace {
 
 int g_prefetch = 1;      // K tiles of register prefetch in gemm_tiled (1 or 2; 2 measured slower: 160 VGPRs)
-int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows, 4 small split-K, 5 dma128 (debug/testing)
+int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows, 4 small split-K, 5 dma128 (2 stages), 6 dma64 ring, 7/8 dma128 with 3/4 stages
 
 struct GemmP {
   const void* A; int64_t lda;
@@ -301,8 +301,26 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmP p) {
 //     contiguous and leave as 16-byte stores of full 128/256-byte row segments, the residual arriving the
 //     same way -- instead of 8-byte stores scattered over 16 rows per instruction.
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename TOut, int BM, int BN>
+// wait until at most `tiles` of this wave's most recently issued K tiles (IPT DMA instructions each) are
+// still in flight; the count must be an immediate, hence the switch (wave-uniform, so one scalar branch)
+template <int IPT>
+__device__ __forceinline__ void wait_dma_tiles(int tiles) {
+  static_assert(IPT * 7 <= 63, "vmcnt immediate out of range");
+  switch (tiles) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT * 1) : "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT * 2) : "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT * 3) : "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT * 4) : "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT * 5) : "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT * 6) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT * 7) : "memory"); break;
+  }
+}
+
+template <typename T, typename TOut, int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
+  static_assert(NS >= 2 && NS <= 8, "2..8 LDS stages");
   typedef Mma<T> MM;
   typedef typename MM::frag frag;
   constexpr int ROWB = 128;                       // bytes of K per LDS row
@@ -313,7 +331,7 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
   constexpr int AI = BM / 32, WI = BN / 32;       // DMA instructions per wave per tile (8 rows each)
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int ES = BN + 4;                      // epilogue row pitch in floats (bank spread)
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // max(2 * STAGE, BM * ES * 4)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // max(NS * STAGE, BM * ES * 4)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -382,15 +400,25 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
     }
   };
 
+  // Ring of NS stages.  Prologue: tiles 0..NS-2 in flight.  Iteration kt: wait for this wave's DMA of tile kt
+  // (everything issued after it may stay in flight: min(nk-1-kt, NS-2) tiles), barrier -- now everybody's
+  // part of tile kt has landed AND everybody is done reading tile kt-1, whose stage (kt-1) % NS =
+  // (kt+NS-1) % NS is refilled with tile kt+NS-1 while tile kt is multiplied.  NS = 2 is the plain double
+  // buffer; with NS*KT >= K (decoder GEMMs, K = 512) the whole K extent is requested up front and the kernel
+  // costs one memory round trip instead of one per K tile.
   const int nk = p.K / KT;
-  issue(0, 0);
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < nk) issue(t, t);
+  int st_c = 0, st_i = NS - 1;   // stage of tile kt / of tile kt+NS-1
   for (int kt = 0; kt < nk; ++kt) {
-    // own DMA of tile kt has landed; after the barrier everybody's has, and everybody is done reading the
-    // other stage (tile kt-1), so it can be refilled while tile kt is multiplied
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int after = nk - 1 - kt;
+    wait_dma_tiles<AI + WI>(after < NS - 2 ? after : NS - 2);
     __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    compute(kt & 1);
+    if (kt + NS - 1 < nk) issue(kt + NS - 1, st_i);
+    compute(st_c);
+    st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+    st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
   }
 
   // ---- epilogue phase 1: act(acc + bias) -> fp32 rows in LDS ------------------------------------
@@ -466,12 +494,12 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
   }
 }
 
-template <typename T, typename TOut, int BM, int BN>
+template <typename T, typename TOut, int BM, int BN, int NS>
 int launch_dma(GemmP& p, hipStream_t st) {
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int EBYTES = BM * (BN + 4) * 4;
-  constexpr size_t smem = (2 * STAGE > EBYTES) ? 2 * STAGE : EBYTES;
-  auto kern = gemm_dma<T, TOut, BM, BN>;
+  constexpr size_t smem = (NS * STAGE > EBYTES) ? NS * STAGE : EBYTES;
+  auto kern = gemm_dma<T, TOut, BM, BN, NS>;
   static bool done = false;   // per template instantiation
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -701,11 +729,24 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
   }
   if (which == 0) {
     if (p.M <= 64) which = 3;
-    else if (ceil_div64(p.M, 128) * ceil_div64(p.N, 128) < 512) which = 2;
+    else if (ceil_div64(p.M, 128) * ceil_div64(p.N, 128) < 512) which = 6;
     else which = 5;
   }
   if (which == 5) {
-    int rc = launch_dma<T, TOut, 128, 128>(p, st);
+    int rc = launch_dma<T, TOut, 128, 128, 2>(p, st);
+    if (rc != OMP_OK) return rc;
+  } else if (which == 6) {
+    // mid-size problems (decoder phases with 65..~4000 rows, small-image encoders): 64x64 tiles and a deep
+    // ring so that the K extent is in flight at once; a shallower ring (2 workgroups per CU) once the grid
+    // is large enough to want the occupancy instead
+    int rc = (ceil_div64(p.M, 64) * ceil_div64(p.N, 64) <= 512) ? launch_dma<T, TOut, 64, 64, 8>(p, st)
+                                                                 : launch_dma<T, TOut, 64, 64, 4>(p, st);
+    if (rc != OMP_OK) return rc;
+  } else if (which == 7) {
+    int rc = launch_dma<T, TOut, 128, 128, 3>(p, st);
+    if (rc != OMP_OK) return rc;
+  } else if (which == 8) {
+    int rc = launch_dma<T, TOut, 128, 128, 4>(p, st);
     if (rc != OMP_OK) return rc;
   } else if (which == 3) {
     dim3 grid((unsigned)ceil_div64(p.N, 64), (unsigned)ceil_div64(p.M, 16));

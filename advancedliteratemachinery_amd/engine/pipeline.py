@@ -12,6 +12,7 @@ Each lane is driven by its own host thread (the per-batch host work is ctypes / 
 GIL, and the EOS polls of the point decoder only block their own lane).  The reference has no counterpart:
 engine/val.py:19-35 processes one image at a time, synchronously.
 """
+import os
 import queue
 import threading
 from concurrent.futures import Future
@@ -20,11 +21,16 @@ import torch
 
 
 class Lane(object):
-    def __init__(self, device, index):
+    def __init__(self, device, index, dec_priority=False):
         self.index = index
         self.device = device
         self.stream = torch.cuda.Stream(device=device)
-        self.side = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        # decoder phases are chains of small latency-bound kernels: with dec_priority they run on high-priority
+        # streams, so the hardware dispatcher places their workgroups ahead of the thousands queued by another
+        # lane's encoder GEMMs whenever CUs free up
+        pr = -1 if dec_priority else 0
+        self.side = (torch.cuda.Stream(device=device, priority=pr), torch.cuda.Stream(device=device, priority=pr))
+        self.dec_stream = torch.cuda.Stream(device=device, priority=pr) if dec_priority else None
         self._dec = None
         self._dec_src = None
 
@@ -40,9 +46,13 @@ class LanePool(object):
     """submit(fn) runs fn(lane) on the next lane (round robin) inside that lane's stream context and
     returns a Future of (result, event); the event is recorded on the lane stream after fn's last launch."""
 
-    def __init__(self, device, n_lanes):
+    def __init__(self, device, n_lanes, dec_priority=None):
         self.device = torch.device(device)
-        self.lanes = [Lane(self.device, i) for i in range(max(1, n_lanes))]
+        if self.device.index is None:   # torch.cuda.set_device() in the lane threads needs an explicit index
+            self.device = torch.device(self.device.type, torch.cuda.current_device())
+        if dec_priority is None:
+            dec_priority = os.environ.get('OMP355_DEC_PRIORITY', '0') == '1'
+        self.lanes = [Lane(self.device, i, dec_priority) for i in range(max(1, n_lanes))]
         self._queues = [queue.Queue() for _ in self.lanes]
         self._next = 0
         self._threads = []
@@ -52,13 +62,20 @@ class LanePool(object):
             self._threads.append(t)
 
     def _worker(self, lane, q):
-        torch.cuda.set_device(self.device)
+        boot_error = None
+        try:
+            torch.cuda.set_device(self.device)
+        except BaseException as e:  # noqa: BLE001 -- a dead lane must fail its jobs, not leave them pending forever
+            boot_error = e
         while True:
             item = q.get()
             if item is None:
                 return
             fn, fut = item
             if not fut.set_running_or_notify_cancel():
+                continue
+            if boot_error is not None:
+                fut.set_exception(boot_error)
                 continue
             try:
                 with torch.cuda.stream(lane.stream):
@@ -83,7 +100,7 @@ class LanePool(object):
     def synchronize(self):
         for lane in self.lanes:
             lane.stream.synchronize()
-            for s in lane.side:
+            for s in lane.side + ((lane.dec_stream,) if lane.dec_stream is not None else ()):
                 s.synchronize()
 
     def close(self):

@@ -131,31 +131,45 @@ class OmniParser(nn.Module):
             poly_sos = int(sequence[1].reshape(-1)[0])
             rec_sos = int(sequence[2].reshape(-1)[0])
             self._mark('kv_project')
-            pts = dec.decode_points(kv, prompt, forced_instances=forced_instances)
-            self._mark('pt_decode')
-            if a.infer_vie:
-                sizes = sequence[3]
-                return self._kie(dec, kv, pts, poly_sos, rec_sos, sizes, B, side)
-            counts = [int(ids.numel()) // 2 for ids, _ in pts]
-            R = sum(counts)
-            if R == 0:
-                return [None] * B
-            points = torch.cat([ids.reshape(-1, 2) for ids, _ in pts], 0).to(dev, torch.int32)
-            (poly, _), (rec, rprob) = dec.decode_poly_and_rec(kv, points, counts, poly_sos, rec_sos, a.rec_length,
-                                                              streams=side if side is not None else self._side_streams(dev))
-            poly, rec, rprob = poly.long(), rec.long(), rprob.clone()
-            self._mark('poly_rec_decode')
-            out, r0 = [], 0
-            for b in range(B):
-                n = counts[b]
-                if n == 0:
-                    out.append(None)
-                    continue
-                sl = slice(r0, r0 + n)
-                out.append(([points[sl].long().reshape(1, -1), poly[sl].reshape(1, -1), rec[sl].unsqueeze(0)],
-                            [rprob[sl]]))
-                r0 += n
-            return out
+            dstream = getattr(lane, 'dec_stream', None) if lane is not None else None
+            if dstream is not None:
+                # decoder phases on the lane's high-priority stream; the lane stream rejoins below
+                outer = torch.cuda.current_stream()
+                dstream.wait_stream(outer)
+                with torch.cuda.stream(dstream):
+                    out = self._decode(dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side)
+                outer.wait_stream(dstream)
+                return out
+            return self._decode(dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side)
+
+    def _decode(self, dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side):
+        """point decoder -> polygon || recognition decoders (or the KIE walk) on the current stream"""
+        a = self.args
+        pts = dec.decode_points(kv, prompt, forced_instances=forced_instances)
+        self._mark('pt_decode')
+        if a.infer_vie:
+            sizes = sequence[3]
+            return self._kie(dec, kv, pts, poly_sos, rec_sos, sizes, B, side)
+        counts = [int(ids.numel()) // 2 for ids, _ in pts]
+        R = sum(counts)
+        if R == 0:
+            return [None] * B
+        points = torch.cat([ids.reshape(-1, 2) for ids, _ in pts], 0).to(dev, torch.int32)
+        (poly, _), (rec, rprob) = dec.decode_poly_and_rec(kv, points, counts, poly_sos, rec_sos, a.rec_length,
+                                                          streams=side if side is not None else self._side_streams(dev))
+        poly, rec, rprob = poly.long(), rec.long(), rprob.clone()
+        self._mark('poly_rec_decode')
+        out, r0 = [], 0
+        for b in range(B):
+            n = counts[b]
+            if n == 0:
+                out.append(None)
+                continue
+            sl = slice(r0, r0 + n)
+            out.append(([points[sl].long().reshape(1, -1), poly[sl].reshape(1, -1), rec[sl].unsqueeze(0)],
+                        [rprob[sl]]))
+            r0 += n
+        return out
 
     # -- KIE assembly (reference transformer.py:143-217) --------------------------------------------------
     def _kie(self, dec, kv, pts, poly_sos, rec_sos, sizes, B, side=None):

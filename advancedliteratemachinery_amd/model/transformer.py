@@ -250,6 +250,13 @@ class Decoder(object):
         kb = 16 if self.dtype == torch.float32 else 32
         if self.n_split_override:
             return self.n_split_override
+        if qt == 4 and self.dtype == torch.bfloat16:
+            # LDS-ring kernel (waves own query tiles, the workgroup streams one key range): enough workgroups
+            # to put two on every CU, but at least 4 key blocks each
+            S = 1
+            while S < 16 and len(groups) * self.nH * S < 512 and M >= 8 * kb * S:
+                S *= 2
+            return S
         per_wave = 4 * kb * (2 if qt > 1 else 1)
         S = 1
         while S < 16 and 4 * S * per_wave < M:

@@ -171,8 +171,14 @@ def head_sample(logits, cfg, seq, probs, finished, lengths, d_pos, advance=True)
 
 
 def force_gemm_kernel(which):
-    """debug/testing: 0 auto, 1 tiled 128x128, 2 tiled 64x64, 3 row-streaming."""
+    """debug/testing: 0 auto, 1 tiled 128x128, 2 tiled 64x64, 3 row-streaming, 4 split-K small-M, 5 DMA 128x128 (2 stages),
+    6 DMA 64x64 ring, 7 / 8 DMA 128x128 with 3 / 4 stages."""
     _lib.check(_lib.lib().omp_debug_force_gemm_kernel(which), 'omp_debug_force_gemm_kernel')
+
+
+def cross_q4(on):
+    """debug/testing: 1 = LDS-ring cross-attention kernel for 33..64 rows per image (default), 0 = register-streaming kernel."""
+    _lib.check(_lib.lib().omp_debug_cross_q4(1 if on else 0), 'omp_debug_cross_q4')
 
 
 def swin_attn_impl(which):

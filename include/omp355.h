@@ -255,6 +255,7 @@ int omp_prof_read(double* total_ms, int64_t* count);
 int omp_debug_force_gemm_kernel(int which);
 int omp_debug_set_gemm_prefetch(int tiles);
 int omp_debug_swin_attn_impl(int which); /* 0 = matrix-core kernel (default), 1 = scalar cross-check kernel */
+int omp_debug_cross_q4(int on);          /* 1 = LDS-ring cross-attention for 33..64 rows/image (default), 0 = register-streaming kernel */
 
 /* Single teacher-forced step that also leaves logits in plan->logits (parity tests). */
 int omp_decoder_step_logits(const omp_decoder_plan* plan, int pos, omp_stream_t s);

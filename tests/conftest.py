@@ -16,7 +16,7 @@ def pytest_collection_modifyitems(config, items):
     """A wedged GPU test must fail (with every thread's stack) instead of eating the box's time limit."""
     for it in items:
         if it.get_closest_marker('gpu') is not None and it.get_closest_marker('timeout') is None:
-            it.add_marker(pytest.mark.timeout(240, method='thread'))
+            it.add_marker(pytest.mark.timeout(180, method="thread"))
 
 
 @pytest.fixture(scope='session')

@@ -67,7 +67,7 @@ def check_gemm():
               (64, 512, 512), (2049, 256, 1024), (16, 2048, 512)]
     for dn, dt in DTYPES.items():
         tol = 2e-4 if dt == torch.float32 else 3e-2
-        for which in (0, 1, 2, 3, 5):
+        for which in (0, 1, 2, 3, 5, 6, 7, 8):
             ops.force_gemm_kernel(which)
             for (M, N, K) in shapes:
                 if which == 3 and M > 600:
@@ -294,7 +294,8 @@ def check_cross_attn():
     for dn, dt in DTYPES.items():
         KB = 16 if dt == torch.float32 else 32
         tol = 2e-5 if dt == torch.float32 else 2e-2
-        for (B, M, counts, masked) in ((2, 77, [19, 3], True), (3, 300, [1, 1, 1], False), (2, 130, [40, 64], True), (1, 4096, [5], False)):
+        for (B, M, counts, masked) in ((2, 77, [19, 3], True), (3, 300, [1, 1, 1], False), (2, 130, [40, 64], True), (1, 4096, [5], False),
+                                        (2, 1000, [64, 50], False)):
             Mpad = (M + KB - 1) // KB * KB
             mem = q(rnd(B * M, d, seed=M), dt)
             NLd = 2 * d   # two (decoder, layer) slabs
@@ -341,10 +342,14 @@ def check_cross_attn():
             gd = torch.tensor(groups, dtype=torch.int32, device=DEV)
             km = kmask.to(torch.uint8).to(DEV) if masked else None
             for S in (1, 2, 8):
-                o = torch.empty(R, d, device=DEV, dtype=dt)
-                partial = torch.empty(R, nH, S, 68, device=DEV)
-                ops.dec_cross_attn_step(qq.to(DEV, dt), Kd[1], Vd[1], nH * Mpad * 64, Mpad, km, gd, len(groups), qt, partial, o, M, nH, S)
-                out.append(rec('cross_attn[%s,B%d,M%d,qt%d,S%d,mask=%s]' % (dn, B, M, qt, S, masked), maxerr(o, ref), tol))
+                # qt == 4 in bf16 has two kernels: the LDS-ring one (default) and the register-streaming one
+                for ring in ((1, 0) if (qt == 4 and dt == torch.bfloat16) else (1,)):
+                    ops.cross_q4(ring)
+                    o = torch.full((R, d), float('nan'), device=DEV, dtype=dt)
+                    partial = torch.full((R, nH, S, 68), float('nan'), device=DEV)
+                    ops.dec_cross_attn_step(qq.to(DEV, dt), Kd[1], Vd[1], nH * Mpad * 64, Mpad, km, gd, len(groups), qt, partial, o, M, nH, S)
+                    out.append(rec('cross_attn[%s,B%d,M%d,qt%d,S%d,mask=%s,ring=%d]' % (dn, B, M, qt, S, masked, ring), maxerr(o, ref), tol))
+            ops.cross_q4(1)
     return out
 
 

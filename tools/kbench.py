@@ -15,6 +15,7 @@ import torch  # noqa: E402
 from advancedliteratemachinery_amd import _lib, ops  # noqa: E402
 
 DEV = 'cuda'
+GEMM_VARIANTS = [int(v) for v in os.environ.get('KBENCH_GEMM_VARIANTS', '5,7,8').split(',')]
 
 
 def timeit(fn, iters=50, warm=5):
@@ -50,7 +51,8 @@ def bench_cross(dtype=torch.bfloat16):
         q = torch.randn(R, d, device=DEV).to(dtype)
         out = torch.empty(R, d, device=DEV, dtype=dtype)
         alg = B * 2 * M * d * esz + 2 * R * d * esz
-        for S in (1, 2, 4, 8, 16):
+        for S, ring in [(S, r) for r in ((0, 1) if rows_per_img > 32 else (0,)) for S in (1, 2, 4, 8, 16)]:
+            ops.cross_q4(ring)
             partial = torch.empty(R, nH, S, 68, device=DEV)
             state = [0]
 
@@ -59,8 +61,9 @@ def bench_cross(dtype=torch.bfloat16):
                 state[0] += 1
                 ops.dec_cross_attn_step(q, K[i], V[i], nH * Mpad * 64, Mpad, None, g, len(groups), qt, partial, out, M, nH, S)
             us = timeit(fn, iters=60)
-            print('cross[%s] rows/img=%-3d qt=%d S=%-2d groups=%d : %7.1f us  %6.0f GB/s (%.2f of 8 TB/s)'
-                  % (str(dtype)[6:], rows_per_img, qt, S, len(groups), us, alg / us / 1e3, alg / us / 1e3 / 8000), flush=True)
+            print('cross[%s] rows/img=%-3d qt=%d ring=%d S=%-2d groups=%d : %7.1f us  %6.0f GB/s (%.2f of 8 TB/s)'
+                  % (str(dtype)[6:], rows_per_img, qt, ring, S, len(groups), us, alg / us / 1e3, alg / us / 1e3 / 8000), flush=True)
+    ops.cross_q4(1)
 
 
 def bench_gemm(dtype=torch.bfloat16):
@@ -76,16 +79,20 @@ def bench_gemm(dtype=torch.bfloat16):
         bias = torch.randn(N, device=DEV)
         out = torch.empty(M, N, device=DEV, dtype=dtype)
         r = torch.randn(M, N, device=DEV).to(dtype) if res else None
-        us = timeit(lambda: ops.gemm(A, W, bias, residual=r, act=act, out=out), iters=20, warm=3)
         fl = 2.0 * M * N * K
         by = (M * K + N * K + M * N * (2 if res else 1)) * 2
-        print('gemm[%s] %7dx%5dx%5d act=%d res=%d : %8.1f us  %6.1f TF/s  %6.0f GB/s' % (str(dtype)[6:], M, N, K, act, res, us, fl / us / 1e6, by / us / 1e3),
-              flush=True)
+        for which in GEMM_VARIANTS:
+            ops.force_gemm_kernel(which)
+            us = timeit(lambda: ops.gemm(A, W, bias, residual=r, act=act, out=out), iters=20, warm=3)
+            print('gemm[%s,k%d] %7dx%5dx%5d act=%d res=%d : %8.1f us  %6.1f TF/s  %6.0f GB/s' % (str(dtype)[6:], which, M, N, K, act, res, us, fl / us / 1e6, by / us / 1e3),
+                  flush=True)
+        ops.force_gemm_kernel(0)
 
 
 def bench_dec_gemm(dtype=torch.bfloat16):
     """decoder-step GEMMs: weight streaming at R = 8 rows (point decoder) and R = 512 (polygon / recognition)."""
-    for R in (8, 64, 512):
+    for R, which in ((8, 0), (64, 0), (512, 2), (512, 6), (2048, 2), (2048, 6)):
+        ops.force_gemm_kernel(which if R > 64 else 0)
         for (N, K, ln) in ((1536, 512, 1), (512, 512, 0), (2048, 512, 1), (512, 2048, 0), (1104, 512, 0)):
             W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(dtype)
             bias = torch.randn(N, device=DEV)
@@ -106,13 +113,14 @@ def bench_dec_gemm(dtype=torch.bfloat16):
             else:
                 out = torch.zeros(R, N, device=DEV)
                 us = timeit(lambda: ops.gemm(A, W, bias, residual=out, out=out, out_dtype=torch.float32, small_m=True), iters=100)
-            print('dec_gemm[%s] R=%-3d N=%-4d K=%-4d ln=%d : %6.1f us  (weights %.2f MB -> %5.0f GB/s, %5.1f TF/s)'
-                  % (str(dtype)[6:], R, N, K, ln, us, N * K * 2 / 1e6, N * K * 2 / us / 1e3, 2.0 * R * N * K / us / 1e6), flush=True)
+            print('dec_gemm[%s,k%d] R=%-4d N=%-4d K=%-4d ln=%d : %6.1f us  (weights %.2f MB -> %5.0f GB/s, %5.1f TF/s)'
+                  % (str(dtype)[6:], which, R, N, K, ln, us, N * K * 2 / 1e6, N * K * 2 / us / 1e3, 2.0 * R * N * K / us / 1e6), flush=True)
 
 
 def bench_selfattn(dtype=torch.bfloat16):
+    ops.force_gemm_kernel(0)
     d, nH = 512, 8
-    for (R, Lmax, pos) in ((8, 140, 70), (8, 140, 135), (512, 40, 20), (512, 40, 34)):
+    for (R, Lmax, pos) in ((8, 140, 70), (8, 140, 135), (512, 40, 20), (512, 40, 34), (2048, 40, 34)):
         qkv = torch.randn(R, 3 * d, device=DEV).to(dtype)
         kc = torch.randn(R, Lmax, d, device=DEV).to(dtype)
         vc = torch.randn(R, Lmax, d, device=DEV).to(dtype)
