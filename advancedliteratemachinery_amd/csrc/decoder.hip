@@ -527,14 +527,27 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc[sb * 4 + r] = sacc[r];
       }
-      if (k0 + KB > kend || km != nullptr) {   // wave-uniform: ragged tail of the split / key padding mask
+      // masking, branch-free per element (both conditions are wave-uniform): key padding mask bytes are all
+      // loaded before any is used; the ragged tail of the split needs only the index compare
+      if (km != nullptr) {
+        uint8_t mk[8];
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
+        for (int i = 0; i < 8; ++i) {
+          const int kk = k0 + (i >> 2) * 16 + g * 4 + (i & 3);
+          mk[i] = km[kk < p.M ? kk : p.M - 1];
+        }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kk = k0 + sb * 16 + g * 4 + r;
-            if (kk >= kend || (km != nullptr && km[kk < p.M ? kk : p.M - 1])) sc[sb * 4 + r] = -INFINITY;
-          }
+        for (int i = 0; i < 8; ++i) {
+          const int kk = k0 + (i >> 2) * 16 + g * 4 + (i & 3);
+          const bool dead = (kk >= kend) | (mk[i] != 0);
+          sc[i] = dead ? -INFINITY : sc[i];
+        }
+      } else if (k0 + KB > kend) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int kk = k0 + (i >> 2) * 16 + g * 4 + (i & 3);
+          sc[i] = (kk >= kend) ? -INFINITY : sc[i];
+        }
       }
       float bmax = sc[0];
 #pragma unroll

@@ -12,8 +12,12 @@ reference's state-dict layout.  Random weights never emit a sensible EOS, so dec
 25+2 recognition steps, every step a full 4-layer decoder pass for every row.  Nothing is skipped
 or cached across steps; images are resident in HBM before the timed region.
 
-Scaling is weak: every rank processes its own `--batch` images; ranks exchange one all-gather of
-the decoded (padded) sequences per step, as a real image-sharded deployment would.
+Engine scheduling (all inside the timed region): `--coalesce` consecutive steps are merged into one engine
+call (dynamic batching: the latency-bound decoder steps then advance coalesce*batch images per launch)
+and `--lanes` such groups are in flight at once on separate HIP streams (engine/pipeline.py).
+
+Scaling is weak: every rank processes its own `--batch` images per step; ranks exchange one all-gather
+of the decoded (padded) sequences per engine call, as a real image-sharded deployment would.
 
 One JSON line on rank 0: images/s (whole job), chars/s, ms per step, the roofline record of the
 dominant HBM-bound kernel (decoder cross-attention, timed with HIP events on its launch stream)
@@ -39,8 +43,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=12)
-    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--steps', type=int, default=16)
+    p.add_argument('--warmup', type=int, default=4)
     p.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     p.add_argument('--size', type=int, default=1024)
     p.add_argument('--instances', type=int, default=64, help='forced text instances per image')
@@ -50,8 +54,11 @@ def parse():
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--phase-times', action='store_true', help='also print a per-phase time breakdown (stderr)')
     p.add_argument('--overlap', type=int, default=1, help='polygon || recognition decoders on two streams')
-    p.add_argument('--lanes', type=int, default=int(os.environ.get('OMP355_LANES', '3')),
-                   help='batches in flight per GPU (engine/pipeline.py): consecutive steps overlap on separate HIP streams')
+    p.add_argument('--lanes', type=int, default=int(os.environ.get('OMP355_LANES', '2')),
+                   help='step groups in flight per GPU (engine/pipeline.py): they overlap on separate HIP streams')
+    p.add_argument('--coalesce', type=int, default=int(os.environ.get('OMP355_COALESCE', '4')),
+                   help='consecutive steps (batches of --batch images) merged into one engine call: the decoders then '
+                        'advance coalesce*batch images per launch (dynamic batching across steps); 1 = every step alone')
     return p.parse_args()
 
 
@@ -104,6 +111,21 @@ def gather_results(results, B, N, rec_len, world, device):
         dist.all_gather_into_tensor(all_pr, probs)
         return all_ids, all_pr
     return ids, probs
+
+
+def pmc_traffic(images_per_launch):
+    """HBM bytes per cross-attention launch from the rocprofv3 PMC passes (separate runs; tools/pmc_cross_json.py
+    turns their summaries into profiles/pmc_cross_attn.json).  FETCH_SIZE is in KiB and counts 16-byte/lane
+    streaming reads at half their size on gfx950 (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE is in KiB."""
+    path = os.environ.get('OMP355_PMC_JSON', os.path.join(ROOT, 'profiles', 'pmc_cross_attn.json'))
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if int(rec['images_per_launch']) != int(images_per_launch):
+            return None
+        return float(rec['fetch_kib_mean']) * 1024.0 * 2.0 + float(rec['write_kib_mean']) * 1024.0
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def host_cores():
@@ -231,45 +253,63 @@ def main():
     lanes = max(1, a.lanes)
     pool = LanePool(device, lanes) if lanes > 1 else None
 
+    G = max(1, a.coalesce)
+
+    def group_input(g):
+        """g consecutive steps as one engine call: the g batches are concatenated inside the timed region (a serving
+        engine receives them as separate tensors)."""
+        if g == 1:
+            return img, mask
+        return torch.cat([img] * g, 0), torch.cat([mask] * g, 0)
+
     def one_step():
-        """synchronous form (lanes == 1, phase breakdown, roofline leg): one batch on the current stream"""
+        """synchronous form (phase breakdown, roofline leg): ONE batch on the current stream"""
         res = model.infer(img, mask, seqs, forced_instances=N, has_padding=False)
         return gather_results(res, B, N, args.rec_length, world, device)
 
+    def run_group(g, lane=None):
+        gi, gm = group_input(g)
+        res = model.infer(gi, gm, seqs, forced_instances=N, has_padding=False, lane=lane)
+        return gather_results(res, B * g, N, args.rec_length, 1, device)
+
     def run_steps(k):
-        """k steps = k batches through the whole hot path.  With lanes > 1 consecutive batches are in flight on
-        different HIP streams (lane threads enqueue them); the per-batch all-gather of the decoded sequences is
-        issued from THIS thread in step order, after the lane's completion event, so every rank calls the
-        collectives in the same order."""
-        if pool is None:
-            out = None
-            for _ in range(k):
-                out = one_step()
-            return out
-        futs = [pool.submit(lambda lane: gather_results(
-            model.infer(img, mask, seqs, forced_instances=N, has_padding=False, lane=lane), B, N, args.rec_length, 1, device))
-            for _ in range(k)]
+        """k steps = k batches through the whole hot path, in groups of `coalesce` consecutive steps per engine call.
+        With lanes > 1 consecutive groups are in flight on different HIP streams (lane threads enqueue them); the
+        all-gather of the decoded sequences (one per group) is issued from THIS thread in step order, after the
+        lane's completion event, so every rank calls the collectives in the same order."""
+        sizes = [G] * (k // G) + ([k % G] if k % G else [])
         out = None
-        for f in futs:
+        if pool is None:
+            for g in sizes:
+                ids, probs = run_group(g)
+                out = exchange(ids, probs, g)
+            return out
+        futs = [pool.submit(lambda lane, g=g: run_group(g, lane)) for g in sizes]
+        for f, g in zip(futs, sizes):
             (ids, probs), ev = f.result()
             torch.cuda.current_stream().wait_event(ev)
-            if world > 1:
-                all_ids = torch.empty(world * B, N, ids.shape[2], dtype=torch.int32, device=device)
-                all_pr = torch.empty(world * B, N, args.rec_length, dtype=torch.float32, device=device)
-                dist.all_gather_into_tensor(all_ids, ids)
-                dist.all_gather_into_tensor(all_pr, probs)
-                out = (all_ids, all_pr)
-            else:
-                out = (ids, probs)
+            out = exchange(ids, probs, g)
         return out
+
+    def exchange(ids, probs, g):
+        if world == 1:
+            return ids, probs
+        all_ids = torch.empty(world * B * g, N, ids.shape[2], dtype=torch.int32, device=device)
+        all_pr = torch.empty(world * B * g, N, args.rec_length, dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(all_ids, ids)
+        dist.all_gather_into_tensor(all_pr, probs)
+        return all_ids, all_pr
 
     def barrier():
         if world > 1:
             dist.barrier()
 
     with torch.cuda.stream(stream):
-        if pool is not None:
-            run_steps(lanes)          # untimed set-up: every lane allocates its buffers and captures its graphs
+        # untimed set-up: every lane (or the model itself) allocates its buffers and captures its graphs for
+        # both group sizes the timed region will use (full groups and the remainder group)
+        for g in sorted({G, a.steps % G, a.warmup % G} - {0}):
+            for _ in range(lanes):
+                run_steps(g)
         run_steps(a.warmup)
         torch.cuda.synchronize()
         barrier()
@@ -286,7 +326,8 @@ def main():
     ips = total_images / elapsed
     # sanity: the forced workload really produced N instances x rec_length chars per image
     ids, _ = out
-    assert ids.shape[0] == world * B and int((ids[:, :, 34:] >= args.num_bins).all()), 'decode output malformed'
+    last_g = a.steps % G or G
+    assert ids.shape[0] == world * B * last_g and int((ids[:, :, 34:] >= args.num_bins).all()), 'decode output malformed'
 
     if a.phase_times and rank == 0:
         print('phase ms: %s' % json.dumps(phase_breakdown(model, one_step, stream)), file=sys.stderr, flush=True)
@@ -300,12 +341,13 @@ def main():
         was = model.use_graph
         model.use_graph = False
         h = _lib.lib()
+        n_groups = (a.steps + G - 1) // G
         with torch.cuda.stream(stream):
-            one_step()
+            run_group(G)
             torch.cuda.synchronize()
             h.omp_prof_enable(1)
-            for _ in range(a.steps):
-                one_step()
+            for _ in range(n_groups):   # the same engine calls as the timed region (groups of G steps), eagerly
+                run_group(G)
             torch.cuda.synchronize()
         tot, cnt = ctypes.c_double(0), ctypes.c_int64(0)
         h.omp_prof_read(ctypes.byref(tot), ctypes.byref(cnt))
@@ -313,15 +355,19 @@ def main():
         model.use_graph = was
         M = (a.size // 16) ** 2
         esz = 2 if a.dtype == 'bf16' else 4
-        # algorithmic bytes per launch: K + V^T of the B images (d=512), q in + o out of the rows
-        rows_avg = B * (1 * (2 * N + 6) + N * (34 + 27)) / float((2 * N + 6) + 34 + 27)
-        alg = B * 2 * M * 512 * esz + rows_avg * 2 * 512 * esz
+        BI = B * G   # images per launch
+        # algorithmic bytes per launch: K + V^T of the images in the call (d = 512) + q in / o out of
+        # the rows (launch-weighted: 1 row/image in the point phase, N rows/image in polygon / recognition)
+        rows_avg = BI * (1 * (2 * N + 6) + N * (34 + 27)) / float((2 * N + 6) + 34 + 27)
+        alg = BI * 2 * M * 512 * esz + rows_avg * 2 * 512 * esz
         avg_s = (tot.value / 1e3) / max(1, cnt.value)
         ach = alg / avg_s / 1e9
-        roof = dict(bound='hbm', kernel='dec_cross_attn_kernel', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=ach / HBM_PEAK_GBS, traffic=None, launches=int(cnt.value), avg_us=avg_s * 1e6,
-                    alg_bytes_per_launch=alg,
-                    note='hipEvent-bracketed eager launches over the same %d steps (graph replay cannot be bracketed)' % a.steps)
+        roof = dict(bound='hbm', kernel='dec_cross_attn_kernel / dec_cross_attn_q4_kernel', achieved=ach, peak=HBM_PEAK_GBS,
+                    unit='GB/s', frac=ach / HBM_PEAK_GBS, traffic=pmc_traffic(BI), launches=int(cnt.value),
+                    avg_us=avg_s * 1e6, alg_bytes_per_launch=alg, images_per_launch=BI,
+                    note='hipEvent-bracketed eager launches of the same %d engine calls (graph replay cannot be bracketed); '
+                         'traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch from the committed PMC passes '
+                         '(profiles/), null when they were taken at another images-per-launch' % n_groups)
 
     if rank == 0:
         rec = dict(metric='images/sec (1024x1024) + chars/sec decoded, OmniParser text-spotting', value=ips, unit='images/s',
@@ -331,7 +377,8 @@ def main():
                    config=dict(workload='OmniParser text-spotting, Swin-B, batch %d/GPU @ %dx%d, forced %d instances/image '
                                         '(%d pt + 34 poly + 27 rec decoder steps), %s' % (B, a.size, a.size, N, 2 * N + 6, a.dtype),
                                global_batch=world * B, image_size=a.size, instances_per_image=N, parallelism='image-sharded dp%d' % world,
-                               hip_graph=bool(a.graph), lanes=lanes))
+                               hip_graph=bool(a.graph), lanes=lanes, coalesce=G,
+                               images_per_engine_call=B * G))
         if roof is not None:
             rec['roofline'] = roof
         if not a.no_cpu_baseline and world == 1:

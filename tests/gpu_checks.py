@@ -166,7 +166,8 @@ def _check_window_attn(iname):
                 ref = _ref_window_attention_from_qkv(qkv_in.reshape(B, H, W, 3 * C), bqkv, table, nH, shift)
                 y = ops.swin_window_attn(qkv_in.to(DEV, dt), bqkv.to(DEV), table.to(DEV), B, H, W, C, nH, shift)
                 out.append(rec('window_attn[%s,%s,B%d %dx%d C%d shift%d]' % (iname, dn, B, H, W, C, shift),
-                               maxerr(y.reshape(B, H, W, C), ref), 2e-5 if dt == torch.float32 else 3e-2))
+                               maxerr(y.reshape(B, H, W, C), ref), 2e-5 if dt == torch.float32 else 6e-2,
+                               'max|ref|=%.1f (bf16: P and the output are rounded to 8 mantissa bits)' % ref.abs().max().item()))
     return out
 
 
