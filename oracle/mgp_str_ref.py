@@ -1,0 +1,167 @@
+"""CPU fp32 restatement of MGP-STR inference (BASELINE config 5).  TEST INFRASTRUCTURE ONLY: imported by
+tests/, oracle/gen_golden_mgp.py and nothing on the product path.
+
+What it follows (paths relative to /root/reference/OCR/MGP-STR/):
+  * forward_features        modules/mgp_str.py:64-94   (cls token kept, NO final self.norm, three A^3 heads)
+  * TokenLearner (A^3)      modules/token_learner.py:21-33
+  * result decoding/fusion  test_final.py:145-240, utils.py:52-87 (char table), EOS ids 1 / 2 / 102
+  * the ViT blocks come from timm==0.4.12 (MGP-STR/requirements.txt:4), which is NOT vendored in the
+    reference and not installed here.  Restated from its published definition:
+      PatchEmbed = Conv2d(3, E, k=4, s=4) -> flatten(2).transpose(1, 2)
+      Block      = x + Attn(LN(x)); x + Mlp(LN(x)), LayerNorm eps = 1e-6
+      Attention  = qkv Linear(bias) -> reshape(B, N, 3, H, hd) -> (q @ k^T) * hd^-0.5 -> softmax -> @ v -> proj
+      Mlp        = fc1 -> GELU(erf) -> fc2
+    Pinning: tests/test_oracle_mgp.py checks the A^3 module against the REAL reference class and the encoder
+    against the `transformers` port of MGP-STR (MgpstrModel, written by the MGP-STR authors) -- an independent
+    implementation of the same definition, NOT the pinned timm release: the ViT blocks are therefore
+    "parity pinned to a third-party port", the A^3 / heads / decode code to the reference itself.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+CHARACTER = '0123456789abcdefghijklmnopqrstuvwxyz'          # test_final.py default --character
+CHAR_TABLE = ['[GO]', '[s]'] + list(CHARACTER)               # utils.py:15-21
+BPE_VOCAB, WP_VOCAB = 50257, 30522                           # mgp_str.py:59-60
+BPE_EOS, WP_EOS = 2, 102                                     # test_final.py:206,227
+BASE = dict(embed=768, depth=12, heads=12, mlp_ratio=4, img=(32, 128), patch=4, max_len=27, num_class=38)
+
+
+def cfg(**over):
+    c = dict(BASE)
+    c.update(over)
+    return c
+
+
+def make_state_dict(c, seed=0, prefix='mgp_str.'):
+    """Seeded procedural checkpoint in the reference's key layout (Model.mgp_str.*, models.py:36): timm
+    VisionTransformer keys + the three TokenLearners and heads.  Includes timm's unused `norm` / `head`."""
+    g = torch.Generator().manual_seed(seed)
+    E, D, L, V = c['embed'], c['depth'], c['max_len'], c['num_class']
+    Hd = int(E * c['mlp_ratio'])
+    T = (c['img'][0] // c['patch']) * (c['img'][1] // c['patch']) + 1
+    r = lambda *s, std=0.02: torch.randn(*s, generator=g) * std          # noqa: E731
+    sd = {}
+    p = prefix
+    sd[p + 'cls_token'] = r(1, 1, E)
+    sd[p + 'pos_embed'] = r(1, T, E)
+    sd[p + 'patch_embed.proj.weight'] = r(E, 3, c['patch'], c['patch'], std=0.1)
+    sd[p + 'patch_embed.proj.bias'] = r(E, std=0.05)
+    for i in range(D):
+        b = '%sblocks.%d.' % (p, i)
+        sd[b + 'norm1.weight'] = 1 + r(E, std=0.05); sd[b + 'norm1.bias'] = r(E, std=0.05)
+        sd[b + 'attn.qkv.weight'] = r(3 * E, E, std=1.5 / math.sqrt(E)); sd[b + 'attn.qkv.bias'] = r(3 * E, std=0.05)
+        sd[b + 'attn.proj.weight'] = r(E, E, std=0.7 / math.sqrt(E)); sd[b + 'attn.proj.bias'] = r(E, std=0.05)
+        sd[b + 'norm2.weight'] = 1 + r(E, std=0.05); sd[b + 'norm2.bias'] = r(E, std=0.05)
+        sd[b + 'mlp.fc1.weight'] = r(Hd, E, std=1.0 / math.sqrt(E)); sd[b + 'mlp.fc1.bias'] = r(Hd, std=0.05)
+        sd[b + 'mlp.fc2.weight'] = r(E, Hd, std=0.7 / math.sqrt(Hd)); sd[b + 'mlp.fc2.bias'] = r(E, std=0.05)
+    sd[p + 'norm.weight'] = torch.ones(E); sd[p + 'norm.bias'] = torch.zeros(E)          # unused by MGPSTR.forward
+    sd[p + 'head.weight'] = r(V, E); sd[p + 'head.bias'] = torch.zeros(V)                 # timm's head, unused
+    for name, vocab in (('char', V), ('bpe', BPE_VOCAB if c.get('full_vocab', True) else c['bpe_vocab']),
+                        ('wp', WP_VOCAB if c.get('full_vocab', True) else c['wp_vocab'])):
+        t = '%s%s_tokenLearner.' % (p, name)
+        sd[t + 'token_norm.weight'] = 1 + r(E, std=0.05); sd[t + 'token_norm.bias'] = r(E, std=0.05)
+        sd[t + 'tokenLearner.0.weight'] = r(E, E // 8, 1, 1, std=1.0 / math.sqrt(E // 8))
+        sd[t + 'tokenLearner.1.weight'] = r(L, E, 1, 1, std=2.0 / math.sqrt(E))
+        sd[t + 'feat.weight'] = r(E, E // 8, 1, 1, std=1.0 / math.sqrt(E // 8))
+        sd[t + 'norm.weight'] = 1 + r(E, std=0.05); sd[t + 'norm.bias'] = r(E, std=0.05)
+        sd['%s%s_head.weight' % (p, name)] = r(vocab, E, std=3.0 / math.sqrt(E))
+        sd['%s%s_head.bias' % (p, name)] = r(vocab, std=0.1)
+    return sd
+
+
+# ---------------------------------------------------------------------------------------------
+def embed(sd, c, img, p='mgp_str.'):
+    """mgp_str.py:66-71 + timm PatchEmbed."""
+    x = F.conv2d(img, sd[p + 'patch_embed.proj.weight'], sd[p + 'patch_embed.proj.bias'], stride=c['patch'])
+    x = x.flatten(2).transpose(1, 2)
+    cls = sd[p + 'cls_token'].expand(img.shape[0], -1, -1)
+    return torch.cat((cls, x), dim=1) + sd[p + 'pos_embed']
+
+
+def block(sd, c, x, i, p='mgp_str.', eps=1e-6):
+    """timm 0.4.12 Block / Attention / Mlp (published definition, see the module docstring)."""
+    b = '%sblocks.%d.' % (p, i)
+    E, H = c['embed'], c['heads']
+    B, N, _ = x.shape
+    y = F.layer_norm(x, (E,), sd[b + 'norm1.weight'], sd[b + 'norm1.bias'], eps)
+    qkv = F.linear(y, sd[b + 'attn.qkv.weight'], sd[b + 'attn.qkv.bias']).reshape(B, N, 3, H, E // H).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    att = ((q @ k.transpose(-2, -1)) * (E // H) ** -0.5).softmax(dim=-1)
+    y = (att @ v).transpose(1, 2).reshape(B, N, E)
+    x = x + F.linear(y, sd[b + 'attn.proj.weight'], sd[b + 'attn.proj.bias'])
+    y = F.layer_norm(x, (E,), sd[b + 'norm2.weight'], sd[b + 'norm2.bias'], eps)
+    y = F.linear(F.gelu(F.linear(y, sd[b + 'mlp.fc1.weight'], sd[b + 'mlp.fc1.bias'])), sd[b + 'mlp.fc2.weight'], sd[b + 'mlp.fc2.bias'])
+    return x + y
+
+
+def encoder(sd, c, img, p='mgp_str.'):
+    x = embed(sd, c, img, p)
+    for i in range(c['depth']):
+        x = block(sd, c, x, i, p)
+    return x            # timm's final norm is NOT applied (mgp_str.py:73-74)
+
+
+def token_learner(sd, c, x, name, p='mgp_str.'):
+    """token_learner.py:21-33: LN -> grouped 1x1 conv (g=8) -> 1x1 conv to L maps -> softmax over the tokens;
+    feat = grouped 1x1 conv of the same LN output; pooled = maps @ feat; LN.  Returns (maps [B,L,T], out [B,L,E])."""
+    t = '%s%s_tokenLearner.' % (p, name)
+    E = c['embed']
+    y = F.layer_norm(x, (E,), sd[t + 'token_norm.weight'], sd[t + 'token_norm.bias'], 1e-5)
+    y4 = y.transpose(1, 2).unsqueeze(-1)                       # [B, E, T, 1]
+    sel = F.conv2d(F.conv2d(y4, sd[t + 'tokenLearner.0.weight'], groups=8), sd[t + 'tokenLearner.1.weight'])
+    sel = F.softmax(sel.flatten(2), dim=-1)                    # [B, L, T]
+    feat = F.conv2d(y4, sd[t + 'feat.weight'], groups=8).flatten(2).transpose(1, 2)   # [B, T, E]
+    out = torch.einsum('...si,...id->...sd', sel, feat)
+    return sel, F.layer_norm(out, (E,), sd[t + 'norm.weight'], sd[t + 'norm.bias'], 1e-5)
+
+
+def heads(sd, c, x, p='mgp_str.'):
+    attens, outs = [], []
+    for name in ('char', 'bpe', 'wp'):
+        a, y = token_learner(sd, c, x, name, p)
+        attens.append(a)
+        outs.append(F.linear(y, sd['%s%s_head.weight' % (p, name)], sd['%s%s_head.bias' % (p, name)]))
+    return attens, outs
+
+
+def forward(sd, c, img, p='mgp_str.'):
+    """MGPSTR.forward(x, is_eval=True), mgp_str.py:96-101 -> [attens, char_out, bpe_out, wp_out]."""
+    x = encoder(sd, c, img, p)
+    attens, (ch, bp, wp) = heads(sd, c, x, p)
+    return attens, ch, bp, wp
+
+
+# ---------------------------------------------------------------------------------------------
+def decode(char_out, bpe_out, wp_out):
+    """test_final.py:145-240 without the tokenizer-dependent strings (GPT-2 / BERT vocabularies are not
+    available offline): per sample the greedy ids (position 0 = [GO] dropped), the confidence of each granularity
+    (cumprod of the max-softmax probabilities up to and including its EOS; 0.0 when no EOS) and the fused choice
+    (highest confidence, strict > in the order char, bpe, wp; -1 when all are 0)."""
+    res = []
+    ids, probs = [], []
+    for lg in (char_out, bpe_out, wp_out):
+        ids.append(lg.topk(1, dim=-1)[1].squeeze(-1)[:, 1:])
+        probs.append(F.softmax(lg, dim=2).max(dim=2)[0][:, 1:])
+    B = char_out.shape[0]
+    for b in range(B):
+        # char: the reference searches the decoded STRING for '[s]' and uses the string index as a token count
+        s = ''.join(CHAR_TABLE[i] for i in ids[0][b].tolist())
+        eos = s.find('[s]')
+        conf = []
+        pr = probs[0][b][:eos + 1]
+        conf.append(float(pr.cumprod(dim=0)[-1]) if pr.numel() else 0.0)
+        for k, eos_id in ((1, BPE_EOS), (2, WP_EOS)):
+            lst = ids[k][b].tolist()
+            e = lst.index(eos_id) if eos_id in lst else -1
+            pr = probs[k][b][:e + 1]
+            conf.append(float(pr.cumprod(dim=0)[-1]) if pr.numel() else 0.0)
+        best, which = 0.0, -1
+        for k in range(3):
+            if conf[k] > best:
+                best, which = conf[k], k
+        res.append(dict(char_ids=ids[0][b].tolist(), bpe_ids=ids[1][b].tolist(), wp_ids=ids[2][b].tolist(),
+                        char_text=s[:eos],   # eos == -1 -> s[:-1], exactly like test_final.py:178
+                        conf=conf, choice=which))
+    return res
