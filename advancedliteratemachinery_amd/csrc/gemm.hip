@@ -580,37 +580,60 @@ __global__ __launch_bounds__(256) void gemm_small(GemmP p) {
     if (u < nsteps) fw[u] = ld16<T>(wp + kbeg + u * MM::KSTEP);
 
   if constexpr (LN) {
+    // LayerNorm prologue: wave w normalises rows w, w+4, ... of the (<= MF*16) rows into LDS.  Rows are taken
+    // RB at a time with ALL their loads issued before the first reduction, so a wave pays one memory round
+    // trip and RB interleaved shuffle chains per batch instead of one of each per row.
     const float* X = reinterpret_cast<const float*>(p.A);
-    const int nch = p.K / 4;  // float4 chunks per row
-    for (int r = wave; r < MF * 16; r += 4) {
-      char* dst = alds + r * astride;
-      if (r < p.M) {
-        const float* xr = X + (int64_t)r * p.lda;
-        float v[4][4];
-        float s = 0.f;
+    const int nch = p.K / 4;  // float4 chunks per row (<= 256)
+    constexpr int RB = 4;
+    const float invK = 1.0f / (float)p.K;
+#pragma unroll 1
+    for (int rb = 0; rb < MF * 4; rb += RB) {
+      f32x4 v[RB][4];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const int r = wave + 4 * (rb + j);
+        const float* xr = X + (int64_t)(r < p.M ? r : 0) * p.lda;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int c = lane + 64 * it;
-          if (c < nch) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(xr + c * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { v[it][i] = t[i]; s += t[i]; }
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[it][i] = 0.f;
-          }
+          v[j][it] = (c < nch && r < p.M) ? *reinterpret_cast<const f32x4*>(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        s = wave_sum(s);
-        const float mean = s / (float)p.K;
+      }
+      float mean[RB], rstd[RB];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) s += (v[j][it][0] + v[j][it][1]) + (v[j][it][2] + v[j][it][3]);
+        mean[j] = s;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < RB; ++j) mean[j] += __shfl_xor(mean[j], o, 64);
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        mean[j] *= invK;
         float q = 0.f;
 #pragma unroll
         for (int it = 0; it < 4; ++it)
           if (lane + 64 * it < nch) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const float d = v[it][i] - mean; q += d * d; }
+            for (int i = 0; i < 4; ++i) { const float d = v[j][it][i] - mean[j]; q += d * d; }
           }
-        q = wave_sum(q);
-        const float rstd = 1.0f / sqrtf(q / (float)p.K + p.ln_eps);
+        rstd[j] = q;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < RB; ++j) rstd[j] += __shfl_xor(rstd[j], o, 64);
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const int r = wave + 4 * (rb + j);
+        const bool live = r < p.M;
+        const float rs = 1.0f / sqrtf(rstd[j] * invK + p.ln_eps);
+        char* dst = alds + r * astride;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int c = lane + 64 * it;
@@ -619,14 +642,8 @@ __global__ __launch_bounds__(256) void gemm_small(GemmP p) {
             const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + c * 4);
             T* o = reinterpret_cast<T*>(dst) + c * 4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = from_f32<T>((v[it][i] - mean) * rstd * gg[i] + bb[i]);
+            for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(live ? (v[j][it][i] - mean[j]) * rs * gg[i] + bb[i] : 0.f);
           }
-        }
-      } else {
-        for (int c = lane; c < nch; c += 64) {
-          T* o = reinterpret_cast<T*>(dst) + c * 4;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(0.f);
         }
       }
     }

@@ -170,6 +170,38 @@ def head_sample(logits, cfg, seq, probs, finished, lengths, d_pos, advance=True)
     _lib.check(rc, 'omp_head_softmax_mask_argmax')
 
 
+def vit_patch_embed(img, w, bias, cls, pos, out_dtype):
+    """img [B,3,H,W] fp32 -> tokens [B, T, E] with T = (H/4)*(W/4) + 1 (token 0 = cls), pos_embed added."""
+    _c(img, 'img')
+    B, _, H, W = img.shape
+    E = w.shape[0]
+    T = (H // 4) * (W // 4) + 1
+    out = torch.empty((B, T, E), dtype=out_dtype, device=img.device)
+    rc = _lib.lib().omp_vit_patch_embed(ptr(img), ptr(w), ptr(bias), ptr(cls), ptr(pos), ptr(out), dt(out), B, H, W, E, stream())
+    _lib.check(rc, 'omp_vit_patch_embed')
+    return out
+
+
+def a3_pool(sel, feat, B, T, S, want_attn=True):
+    """sel fp32 [B*T, >=S], feat [B*T, C] -> (pooled fp32 [B*S, C], maps fp32 [B, S, T] or None)."""
+    C = feat.shape[-1]
+    pooled = torch.empty((B * S, C), dtype=torch.float32, device=feat.device)
+    attn = torch.empty((B, S, T), dtype=torch.float32, device=feat.device) if want_attn else None
+    rc = _lib.lib().omp_a3_pool(ptr(sel), sel.stride(0), ptr(feat), dt(feat), ptr(pooled), ptr(attn), B, T, S, C, stream())
+    _lib.check(rc, 'omp_a3_pool')
+    return pooled, attn
+
+
+def row_argmax_prob(logits):
+    """logits fp32 [R, V] -> (ids int32 [R], prob fp32 [R]): greedy id and its softmax probability."""
+    R, V = logits.shape
+    ids = torch.empty(R, dtype=torch.int32, device=logits.device)
+    prob = torch.empty(R, dtype=torch.float32, device=logits.device)
+    rc = _lib.lib().omp_row_argmax_prob(ptr(logits), logits.stride(0), R, V, ptr(ids), ptr(prob), stream())
+    _lib.check(rc, 'omp_row_argmax_prob')
+    return ids, prob
+
+
 def force_gemm_kernel(which):
     """debug/testing: 0 auto, 1 tiled 128x128, 2 tiled 64x64, 3 row-streaming, 4 split-K small-M, 5 DMA 128x128 (2 stages),
     6 DMA 64x64 ring, 7 / 8 DMA 128x128 with 3 / 4 stages."""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 2
+#define OMP_ABI_VERSION 3
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -247,6 +247,27 @@ typedef struct {
 int omp_decoder_run(const omp_decoder_plan* plan, int first_pos, int n_steps, int graph_slot,
                     omp_stream_t s);
 int omp_decoder_graph_reset(int graph_slot);
+
+/* ---- MGP-STR recogniser (reference: OCR/MGP-STR; BASELINE config 5) ------------------------------------
+ * The ViT-B encoder reuses omp_layernorm / omp_gemm_bias_act / omp_dec_cross_attn_step (a ViT layer's k and v
+ * projections write the blocked slabs, an image's 257 tokens are row groups of that image); these three entry
+ * points cover what is specific to MGP-STR. */
+
+/* Patch embedding + cls token + position embedding.  Replaces timm PatchEmbed (Conv2d(3,E,4,4) -> flatten ->
+ * transpose) and modules/mgp_str.py:66-70.  img NCHW fp32 [B,3,H,W] (H, W multiples of 4); w [E,3,4,4], bias [E],
+ * cls [E], pos [(H/4)*(W/4)+1, E] fp32; out [B, (H/4)*(W/4)+1, E] token-major, token 0 = cls. */
+int omp_vit_patch_embed(const float* img, const float* w, const float* bias, const float* cls, const float* pos,
+                        void* out, int out_dtype, int B, int H, int W, int E, omp_stream_t s);
+
+/* A^3 module core, modules/token_learner.py:27-31: maps[b,s,:] = softmax over the T tokens of sel[b,:,s];
+ * pooled[b,s,:] = sum_i maps[b,s,i] * feat[b,i,:].  sel fp32 [B*T, ld_sel] (S <= 28 columns), feat [B*T, C]
+ * (dtype), pooled fp32 [B*S, C], attn fp32 [B,S,T] or NULL. */
+int omp_a3_pool(const float* sel, int ld_sel, const void* feat, int dtype, float* pooled, float* attn, int B, int T,
+                int S, int C, omp_stream_t s);
+
+/* Greedy id and its softmax probability for every row of logits fp32 [R, ld] (V columns used).  Replaces
+ * topk(1) + softmax(...).max(dim=2) of test_final.py:145-170. */
+int omp_row_argmax_prob(const float* logits, int64_t ld, int R, int V, int32_t* ids, float* prob, omp_stream_t s);
 
 /* Measurement hooks (bench.py roofline leg): hipEvent-bracket every eagerly launched decoder
  * cross-attention kernel on its launch stream; read back total milliseconds and launch count. */

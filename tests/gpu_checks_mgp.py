@@ -1,0 +1,135 @@
+"""GPU parity checks of the MGP-STR path (BASELINE config 5): libomp355 through the C ABI wrappers vs the CPU
+oracle (oracle/mgp_str_ref.py, pinned to the reference in tests/test_oracle_mgp.py) and vs the golden fixture
+produced by the reference's own code.  Same record format as tests/gpu_checks.py."""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from advancedliteratemachinery_amd import ops
+from advancedliteratemachinery_amd.model import mgp_str as M
+from oracle import gen_golden_mgp as G
+from oracle import mgp_str_ref as R
+from tests.gpu_checks import DEV, DTYPES, maxerr, q, rec, rnd
+
+
+def build(c, sd, dtype):
+    m = M.MGPSTR({k: c[k] for k in ('embed', 'depth', 'heads', 'mlp_ratio', 'img', 'patch', 'max_len', 'num_class')}, engine_dtype=dtype)
+    m.load_reference_state_dict({'module.' + k: v for k, v in sd.items()})
+    return m.to(DEV)
+
+
+def check_vit_patch_embed():
+    out = []
+    c = R.cfg(depth=1)
+    sd = R.make_state_dict(c, seed=2)
+    for (B, H, W) in ((3, 32, 128), (2, 8, 20)):
+        cc = dict(c, img=(H, W))
+        T = (H // 4) * (W // 4) + 1
+        sd2 = dict(sd)
+        sd2['mgp_str.pos_embed'] = rnd(1, T, 768, seed=4) * 0.1
+        img = rnd(B, 3, H, W, seed=H)
+        ref = R.embed(sd2, cc, img)
+        for dn, dt in DTYPES.items():
+            y = ops.vit_patch_embed(img.to(DEV), sd2['mgp_str.patch_embed.proj.weight'].reshape(768, 48).contiguous().to(DEV),
+                                    sd2['mgp_str.patch_embed.proj.bias'].to(DEV), sd2['mgp_str.cls_token'].reshape(768).contiguous().to(DEV),
+                                    sd2['mgp_str.pos_embed'].reshape(T, 768).contiguous().to(DEV), dt)
+            out.append(rec('vit_patch_embed[%s,B%d %dx%d]' % (dn, B, H, W), maxerr(y, ref), 2e-5 if dt == torch.float32 else 2e-2))
+    return out
+
+
+def check_a3_pool():
+    out = []
+    for (B, T, S, C) in ((3, 257, 27, 768), (2, 50, 5, 100), (1, 257, 27, 1024)):
+        sel = rnd(B * T, S, seed=T) * 2.0
+        for dn, dt in DTYPES.items():
+            feat = q(rnd(B * T, C, seed=C), dt)
+            maps = F.softmax(sel.reshape(B, T, S).transpose(1, 2), dim=-1)
+            ref = torch.einsum('bsi,bid->bsd', maps, feat.reshape(B, T, C)).reshape(B * S, C)
+            pooled, attn = ops.a3_pool(sel.to(DEV), feat.to(DEV, dt), B, T, S, True)
+            out.append(rec('a3_pool[%s,B%d T%d S%d C%d] pooled' % (dn, B, T, S, C), maxerr(pooled, ref), 2e-5))
+            out.append(rec('a3_pool[%s,B%d T%d S%d C%d] maps' % (dn, B, T, S, C), maxerr(attn, maps), 2e-6))
+    return out
+
+
+def check_row_argmax_prob():
+    out = []
+    for (Rn, V) in ((81, 50257), (54, 38), (7, 30522)):
+        lg = rnd(Rn, V, seed=V) * 3.0
+        ids, pr = ops.row_argmax_prob(lg.to(DEV))
+        ref_p, ref_i = F.softmax(lg, dim=1).max(dim=1)
+        out.append(rec('row_argmax_prob[%dx%d] ids' % (Rn, V), float((ids.cpu().long() != ref_i).sum()), 0))
+        out.append(rec('row_argmax_prob[%dx%d] prob' % (Rn, V), maxerr(pr, ref_p), 1e-6))
+    return out
+
+
+def check_vit_block(dtype_name='fp32'):
+    """one encoder block (LN, q/k/v projections into the blocked slabs, 257-token attention on the cross-attention
+    kernels, proj + residual, MLP) vs the oracle's block, and the slab path at two batch sizes"""
+    dt = DTYPES[dtype_name]
+    out = []
+    c = R.cfg(depth=1)
+    sd = R.make_state_dict(c, seed=8)
+    model = build(c, sd, dt)
+    for B in (1, 3):
+        img = rnd(B, 3, 32, 128, seed=B)
+        with torch.no_grad():
+            ref = R.encoder(sd, c, img)
+        x, _, T = model.encode(img.to(DEV))
+        out.append(rec('vit_block[%s,B%d]' % (dtype_name, B), maxerr(x.reshape(B, T, -1), ref), 2e-4 if dt == torch.float32 else 0.15,
+                       'max|ref|=%.1f' % ref.abs().max().item()))
+    return out
+
+
+def check_mgp_e2e(dtype_name='fp32', depth=2):
+    dt = DTYPES[dtype_name]
+    c = R.cfg(depth=depth)
+    sd = R.make_state_dict(c, seed=21)
+    model = build(c, sd, dt)
+    img = rnd(3, 3, 32, 128, seed=5).clamp(-1, 1)
+    with torch.no_grad():
+        ratt, rch, rbp, rwp = R.forward(sd, c, img)
+    att, ch, bp, wp = model(img.to(DEV), is_eval=True)
+    out = []
+    ltol, atol = (1e-3, 2e-5) if dt == torch.float32 else (0.5, 2e-2)
+    for name, a, b in (('char', ch, rch), ('bpe', bp, rbp), ('wp', wp, rwp)):
+        out.append(rec('mgp_logits[%s,depth%d,%s]' % (dtype_name, depth, name), maxerr(a, b), ltol, 'max|logit|=%.1f' % b.abs().max().item()))
+    for name, a, b in zip(('char', 'bpe', 'wp'), att, ratt):
+        out.append(rec('mgp_attn[%s,depth%d,%s]' % (dtype_name, depth, name), maxerr(a, b), atol))
+    # result decoding on the device vs the oracle's restatement of test_final.py
+    got = model.recognize(img.to(DEV))
+    want = R.decode(rch, rbp, rwp)
+    same = tot = 0
+    for g, w in zip(got, want):
+        for k in ('char_ids', 'bpe_ids', 'wp_ids'):
+            tot += len(w[k])
+            same += sum(int(x == y) for x, y in zip(g[k], w[k]))
+    frac = same / max(1, tot)
+    out.append(rec('mgp_greedy_ids[%s,depth%d]' % (dtype_name, depth), 1.0 - frac, 0.0 if dt == torch.float32 else 0.3, 'agreement %.3f' % frac))
+    if dt == torch.float32:
+        worst = max(max(abs(x - y) for x, y in zip(g['conf'], w['conf'])) for g, w in zip(got, want))
+        out.append(rec('mgp_confidence[fp32,depth%d]' % depth, worst, 1e-4))
+        out.append(rec('mgp_choice[fp32,depth%d]' % depth, sum(int(g['choice'] != w['choice']) for g, w in zip(got, want)), 0))
+    return out
+
+
+def check_mgp_golden():
+    """full ViT-B (12 blocks, full vocabularies) in fp32 vs the fixture written by the reference's own code"""
+    fix = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mgp_str_base.pt'), weights_only=False)
+    c, ref = fix['cfg'], fix['ref']
+    sd = R.make_state_dict(c, seed=fix['seed_w'])
+    model = build(c, sd, torch.float32)
+    img = fix['img']
+    x, B, T = model.encode(img.to(DEV))
+    att, ch, bp, wp = model(img.to(DEV), is_eval=True)
+    got = G.reduce_outputs(x.reshape(B, T, -1).float().cpu(), [a.cpu() for a in att], ch.cpu(), bp.cpu(), wp.cpu())
+    out = [rec('mgp_golden enc_proj', maxerr(got['enc_proj'], ref['enc_proj']), 1e-3),
+           rec('mgp_golden char logits', maxerr(got['char'], ref['char']), 1e-3),
+           rec('mgp_golden bpe logits (64 cols)', maxerr(got['bpe_sub'], ref['bpe_sub']), 1e-3),
+           rec('mgp_golden wp logits (64 cols)', maxerr(got['wp_sub'], ref['wp_sub']), 1e-3)]
+    for name, a, b in zip(('char', 'bpe', 'wp'), got['attens'], ref['attens']):
+        out.append(rec('mgp_golden attn %s' % name, maxerr(a, b), 2e-5))
+    for name in ('char', 'bpe', 'wp'):
+        out.append(rec('mgp_golden %s ids' % name, float((got[name + '_ids'] != ref[name + '_ids']).sum()), 0))
+        out.append(rec('mgp_golden %s prob' % name, maxerr(got[name + '_prob'], ref[name + '_prob']), 1e-4))
+    return out

@@ -1,0 +1,38 @@
+"""MGP-STR (BASELINE config 5) GPU parity: kernels of csrc/vit.hip, the ViT block on the shared kernels, end to end
+against the oracle and against the golden fixture written by the reference's own code."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_all(records):
+    bad = [r for r in records if not r['ok']]
+    assert not bad, '\n'.join('%s: err=%.3e tol=%.1e %s' % (r['name'], r['err'], r['tol'], r['note']) for r in bad)
+
+
+@pytest.fixture(scope='module')
+def C():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from tests import gpu_checks_mgp
+    return gpu_checks_mgp
+
+
+@pytest.mark.parametrize('name', ['check_vit_patch_embed', 'check_a3_pool', 'check_row_argmax_prob'])
+def test_mgp_op(C, name):
+    _assert_all(getattr(C, name)())
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_vit_block(C, dtype):
+    _assert_all(C.check_vit_block(dtype))
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_mgp_end_to_end(C, dtype):
+    _assert_all(C.check_mgp_e2e(dtype))
+
+
+def test_mgp_golden_fp32(C):
+    _assert_all(C.check_mgp_golden())

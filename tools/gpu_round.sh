@@ -19,6 +19,7 @@ prof)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof 
        db=$(find $OUT/prof -name "*.db" 2>/dev/null | head -1); [ -n "$db" ] && python tools/rocpd_stats.py $db > $OUT/kernel_stats.txt 2>> $OUT/prof.err
        find $OUT/prof -name "*.db" -size +20M -delete 2>/dev/null;;
 kbench) timeout 600 python tools/kbench.py ${KBENCH_WHAT:-all} > $OUT/kbench.txt 2>&1; echo "kbench rc=$?" >> $OUT/rc.log;;
+mgp)   timeout 300 python tools/mgp_bench.py 512 3 > $OUT/mgp_bench.txt 2>&1; echo "mgp rc=$?" >> $OUT/rc.log;;
 sweep) timeout 300 python tools/lane_sweep.py ${SWEEP_ARGS:---lanes 2,3 --batches 32 --steps 32} > $OUT/sweep.log 2>&1; echo "sweep rc=$?" >> $OUT/rc.log;;
 esac; done
 cat $OUT/rc.log
