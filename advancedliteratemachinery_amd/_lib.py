@@ -86,6 +86,8 @@ _SIGS = {
     'omp_vit_patch_embed': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     'omp_a3_pool': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_row_argmax_prob': (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'omp_resize_normalize_pad': (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_prof_enable': (c_int, [c_int]),
     'omp_prof_read': (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
 }

@@ -43,8 +43,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=16)
-    p.add_argument('--warmup', type=int, default=4)
+    p.add_argument('--steps', type=int, default=32)
+    p.add_argument('--warmup', type=int, default=8)
     p.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     p.add_argument('--size', type=int, default=1024)
     p.add_argument('--instances', type=int, default=64, help='forced text instances per image')

@@ -269,6 +269,19 @@ int omp_a3_pool(const float* sel, int ld_sel, const void* feat, int dtype, float
  * topk(1) + softmax(...).max(dim=2) of test_final.py:145-170. */
 int omp_row_argmax_prob(const float* logits, int64_t ld, int R, int V, int32_t* ids, float* prob, omp_stream_t s);
 
+/* ---- test-time image pre-processing (the step before the hot path) -----------------
+ * Replaces dataset/transforms.py:249-298 (RandomResize([test_min_size], test_max_size) = Pillow bilinear resize
+ * through torchvision F.resize), :312-322 (ToTensor, Normalize) and the padding / mask construction of
+ * utils/nested_tensor.py:37-54 for ONE image of a batch.  src: uint8 HWC RGB on the device.  xbounds/xcoef,
+ * ybounds/ycoef: Pillow's coefficient tables ([out][2] = first source index, count; [out][ks] 22-bit fixed point;
+ * utils/preprocess.py builds them; may be NULL for an axis whose size does not change).  lut: float [3][256] =
+ * ((p / 255) - mean_c) / std_c.  dst: this image's [3, dst_h, dst_w] fp32 slice of the batch tensor; mask: its
+ * [dst_h, dst_w] uint8 slice (1 = padding) or NULL.  Bit-exact with the reference pipeline. */
+int omp_resize_normalize_pad(const uint8_t* src, int64_t src_pitch, int in_h, int in_w, const int32_t* xbounds,
+                             const int32_t* xcoef, int ksx, const int32_t* ybounds, const int32_t* ycoef, int ksy,
+                             const float* lut, float* dst, uint8_t* mask, int out_h, int out_w, int dst_h,
+                             int dst_w, omp_stream_t s);
+
 /* Measurement hooks (bench.py roofline leg): hipEvent-bracket every eagerly launched decoder
  * cross-attention kernel on its launch stream; read back total milliseconds and launch count. */
 int omp_prof_enable(int on);

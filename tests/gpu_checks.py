@@ -402,6 +402,34 @@ def check_decoder(dtype_name='fp32', pre_norm=True, with_mask=True):
     return out
 
 
+def check_decoder_long(dtype_name='fp32'):
+    """BASELINE config 4 as far as the reference allows it: the decoders' position tables hold 1024 entries
+    (transformer.py:475), so the longest sequence is 1023 input positions.  Teacher-forced logits of the point
+    decoder over a 1023-token sequence (KV cache, position-bias tables and the self-attention key loop at their
+    maximum length) vs the oracle's full-prefix decode."""
+    dt = DTYPES[dtype_name]
+    args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True)
+    sd = weights.make_state_dict(args, seed=12, depths=(2, 2, 2, 2))
+    model = build_model(args, sd, (2, 2, 2, 2), dt)
+    enc, dec = model.engine()
+    B, M, d, L = 2, 50, 512, 1023
+    mem = q(rnd(B * M, d, seed=3), dt)
+    pos = q(rnd(B * M, d, seed=4), dt)
+    mem_pos = q(mem + pos, dt)
+    kv = dec.project_memory(mem.to(DEV, dt), mem_pos.to(DEV, dt), B, M, None)
+    seqs = torch.randint(0, args.num_classes - 1, (B, L), generator=torch.Generator().manual_seed(9))
+    lg = dec.teacher_forced_logits('pt', kv, seqs, [1, 1], 7).cpu()
+    worst = scale = 0.0
+    kmask = torch.zeros(1, M, dtype=torch.bool)
+    for b in range(B):
+        mem_b = mem.reshape(B, M, d)[b].unsqueeze(1)
+        pos_b = mem_pos.reshape(B, M, d)[b].unsqueeze(1) - mem_b
+        ref = O.decode(sd, args, seqs[b:b + 1], mem_b, kmask, pos_b, 'pt')
+        worst = max(worst, (lg[b:b + 1] - ref).abs().max().item())
+        scale = max(scale, ref.abs().max().item())
+    return [rec('decoder_logits_long[%s,L=%d]' % (dtype_name, L), worst, 2e-3 if dt == torch.float32 else 0.6, 'max|logit|=%.2f' % scale)]
+
+
 # ---------------------------------------------------------------------------------------------
 # end-to-end vs golden fixtures (REAL reference outputs)
 # ---------------------------------------------------------------------------------------------

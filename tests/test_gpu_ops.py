@@ -32,3 +32,8 @@ def test_decoder_teacher_forced(C, dtype, pre_norm):
 
 def test_decoder_no_mask(C):
     _assert_all(C.check_decoder('fp32', True, with_mask=False))
+
+
+def test_decoder_longest_sequence(C):
+    """config 4 (long structured-sequence decode) up to the reference's 1024-entry position tables"""
+    _assert_all(C.check_decoder_long('fp32'))
