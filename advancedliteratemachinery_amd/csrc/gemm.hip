@@ -19,7 +19,7 @@
 namespace {
 
 int g_prefetch = 1;      // K tiles of register prefetch in gemm_tiled (1 or 2; 2 measured slower: 160 VGPRs)
-int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows, 4 small split-K, 5 dma128 (2 stages), 6 dma64 ring, 7/8 dma128 with 3/4 stages
+int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows, 4 small split-K, 5 dma128 (2 stages), 6 dma64 ring, 7/8 dma128 with 3/4 stages, 9 dma 256x256 / 8 waves
 
 struct GemmP {
   const void* A; int64_t lda;
@@ -513,6 +513,201 @@ int launch_dma(GemmP& p, hipStream_t st) {
   return OMP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_dma8<T,TOut>: 256x256 tile, 8 waves (2 along M x 4 along N, wave tile 128 x 64 = 32 accumulator
+// fragments), same DMA staging / swizzle / one-barrier-per-K-tile ring as gemm_dma with 2 stages of 64 KB.
+// Per 32-deep k-step a wave issues 12 ds_read_b128 for 32 MFMAs (gemm_dma's 2x2 waves: 8 for 16), and a
+// workgroup moves half the operand bytes per flop through L2/LDS.  The 256x256 fp32 tile does not fit in LDS
+// at once, so the epilogue runs in four 64-row chunks through the (then idle) operand stages.
+// Used for the large-M GEMMs whose N is a multiple of 256 (Swin stages 1-3, K/V projection, ViT-B).
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename TOut>
+__global__ __launch_bounds__(512) void gemm_dma8(GemmP p) {
+  typedef Mma<T> MM;
+  typedef typename MM::frag frag;
+  constexpr int BM = 256, BN = 256, NS = 2;
+  constexpr int ROWB = 128;
+  constexpr int KT = ROWB / (int)sizeof(T);
+  constexpr int STEPS = KT / MM::KSTEP;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int FM = 8, FN = 4;                   // wave tile 128 (m) x 64 (n)
+  constexpr int AI = 4, WI = 4;                   // 32 rows of A and of W per wave per K tile
+  constexpr int STAGE = (BM + BN) * ROWB;         // 64 KB
+  constexpr int ES = BN + 4;
+  constexpr int EC = 64;                          // epilogue chunk rows: 64 * 260 * 4 B = 65 KB <= 2 * STAGE
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int n0 = tn * BN;
+
+  const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+  const T* a_src[AI];
+  const T* w_src[WI];
+#pragma unroll
+  for (int j = 0; j < AI; ++j) {
+    int64_t gm = m0 + wave * 32 + j * 8 + lr; if (gm > p.M - 1) gm = p.M - 1;
+    a_src[j] = reinterpret_cast<const T*>(p.A) + gm * p.lda + lc * EPC;
+  }
+#pragma unroll
+  for (int j = 0; j < WI; ++j) {
+    int gn = n0 + wave * 32 + j * 8 + lr; if (gn > p.N - 1) gn = p.N - 1;
+    w_src[j] = reinterpret_cast<const T*>(p.W) + (int64_t)gn * p.ldw + lc * EPC;
+  }
+  auto issue = [&](int kt, int buf) {
+    const int koff = kt * KT;
+    char* abase = smem + buf * STAGE + (wave * 32) * ROWB;
+    char* wbase = smem + buf * STAGE + BM * ROWB + (wave * 32) * ROWB;
+#pragma unroll
+    for (int j = 0; j < AI; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(abase + j * 8 * ROWB), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < WI; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(wbase + j * 8 * ROWB), 16, 0, 0);
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lrow = lane & 15, lg = lane >> 4;
+  auto compute = [&](int buf) {
+    const char* as = smem + buf * STAGE + (wm * 128) * ROWB;
+    const char* ws = smem + buf * STAGE + BM * ROWB + (wn * 64) * ROWB;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      frag fw[FN], fx[FM];
+      const int c = s * 4 + lg;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int row = i * 16 + lrow;
+        fw[i] = *reinterpret_cast<const frag*>(ws + row * ROWB + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int row = j * 16 + lrow;
+        fx[j] = *reinterpret_cast<const frag*>(as + row * ROWB + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) MM::mma(acc[i][j], fw[i], fx[j]);
+    }
+  };
+
+  const int nk = p.K / KT;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    compute(kt & 1);
+  }
+
+  // ---- epilogue in four 64-row chunks: act(acc + bias) -> fp32 rows in LDS -> row-contiguous 16-byte stores ----
+  float* E = reinterpret_cast<float*>(smem);
+  const float* bias = p.bias;
+  if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
+  constexpr int CH = 16 / (int)sizeof(TOut);
+  constexpr int CPR = BN / CH;                 // 32 (bf16 out) / 64 (f32 out) chunks per tile row
+  constexpr int RPP = 512 / CPR;               // rows per pass
+  const TOut* res = reinterpret_cast<const TOut*>(p.residual);
+  TOut* C = reinterpret_cast<TOut*>(p.C);
+  const bool vec_ok = p.store_mode == OMP_STORE_PLAIN && !p.trans_out && (p.ldc % CH) == 0 &&
+                      (res == nullptr || (p.ldr % CH) == 0);
+  const int cidx = tid % CPR, rsub = tid / CPR;
+  const int n = n0 + cidx * CH;
+#pragma unroll
+  for (int chunk = 0; chunk < BM / EC; ++chunk) {
+    __syncthreads();   // chunk 0: everybody is done with the operand stages; later: with the previous chunk's rows
+    if (wm == (chunk >> 1)) {
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int nl = wn * 64 + i * 16 + lg * 4;
+        float bn[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr && !p.bias_m) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n0 + nl + r < p.N) bn[r] = bias[n0 + nl + r];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = (chunk & 1) * 4 + jj;
+          const int ml = jj * 16 + lrow;                       // row inside the chunk
+          const int64_t mg = m0 + chunk * EC + ml;
+          float bm = 0.f;
+          if (bias != nullptr && p.bias_m && mg < p.M) bm = bias[mg];
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[i][j][r] + bn[r] + bm, p.act);
+          *reinterpret_cast<f32x4*>(E + ml * ES + nl) = o;
+        }
+      }
+    }
+    __syncthreads();
+    if (n < p.N) {
+      if (vec_ok && n + CH <= p.N) {
+#pragma unroll 4
+        for (int pass = 0; pass < EC / RPP; ++pass) {
+          const int r = pass * RPP + rsub;
+          const int64_t m = m0 + chunk * EC + r;
+          if (m < p.M) {
+            float v[CH];
+#pragma unroll
+            for (int q = 0; q < CH; q += 4) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
+              v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
+            }
+            if (res != nullptr) {
+              float rv[CH];
+              unpack16(*reinterpret_cast<const typename Vec16<TOut>::type*>(res + m * p.ldr + n), rv);
+#pragma unroll
+              for (int q = 0; q < CH; ++q) v[q] += rv[q];
+            }
+            typename Vec16<TOut>::type o;
+            pack16(v, o);
+            *reinterpret_cast<typename Vec16<TOut>::type*>(C + m * p.ldc + n) = o;
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int it = 0; it < (EC / RPP) * (CH / 4); ++it) {
+          const int pass = it / (CH / 4), q = (it % (CH / 4)) * 4;
+          const int r = pass * RPP + rsub;
+          const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
+          const float v[4] = {t[0], t[1], t[2], t[3]};
+          store4<TOut>(p, m0 + chunk * EC + r, n + q, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, typename TOut>
+int launch_dma8(GemmP& p, hipStream_t st) {
+  constexpr size_t smem = 2 * (256 + 256) * 128;   // 128 KB: two operand stages (the epilogue chunks reuse them)
+  auto kern = gemm_dma8<T, TOut>;
+  static bool done = false;   // per template instantiation
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      omp_set_error("omp_gemm_bias_act: cannot raise dynamic LDS limit");
+      return OMP_ERR_LAUNCH;
+    }
+    done = true;
+  }
+  p.tiles_m = (int)ceil_div64(p.M, 256); p.tiles_n = (int)ceil_div64(p.N, 256);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
+  return OMP_OK;
+}
+
 // Small-M path: grid (ceil(N/64), ceil(M/16)), 4 waves, wave w owns output features
 // [bx*64 + 16w, +16) for tokens [by*16, +16).  No LDS, fragments come straight from global.
 template <typename T, typename TOut>
@@ -758,6 +953,9 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
     // is large enough to want the occupancy instead
     int rc = (ceil_div64(p.M, 64) * ceil_div64(p.N, 64) <= 512) ? launch_dma<T, TOut, 64, 64, 8>(p, st)
                                                                  : launch_dma<T, TOut, 64, 64, 4>(p, st);
+    if (rc != OMP_OK) return rc;
+  } else if (which == 9) {
+    int rc = launch_dma8<T, TOut>(p, st);
     if (rc != OMP_OK) return rc;
   } else if (which == 7) {
     int rc = launch_dma<T, TOut, 128, 128, 3>(p, st);

@@ -83,6 +83,23 @@ def predict(model, images, args, targets=None, orig_sizes=None):
 
 
 @torch.no_grad()
+def predict_images(model, images_u8, args, file_names=None, preprocessor=None):
+    """Raw images in, records out: uint8 RGB [H, W, 3] arrays / tensors -> the reference's val transform chain on the
+    device (utils/preprocess.py: aspect-preserving Pillow-exact resize to test_min_size / test_max_size, ToTensor,
+    Normalize, pad + mask) -> the hot path -> records in ORIGINAL image coordinates (val.py:70-100).
+    Returns (results per image, preprocessor) so the coefficient tables can be reused by the next call."""
+    from ..utils.preprocess import DevicePreprocessor
+    dev = next(model.parameters()).device
+    if preprocessor is None:
+        preprocessor = DevicePreprocessor(args.test_min_size, args.test_max_size, dev)
+    imgs = [torch.as_tensor(i).to(dev) for i in images_u8]
+    nt, _ = preprocessor(imgs)
+    targets = [{'file_name': (file_names[b] if file_names is not None else str(b)),
+                'orig_size': (int(im.shape[0]), int(im.shape[1]))} for b, im in enumerate(imgs)]
+    return predict(model, nt, args, targets=targets, orig_sizes=[t['orig_size'] for t in targets]), preprocessor
+
+
+@torch.no_grad()
 def validate(model, dataloader, epoch, args, batch_size=None):
     """Drop-in for engine.validate: iterates (samples, targets) like the reference dataloader yields them,
     writes <output_folder>/results/epXXX/<dataset>.json on rank 0 (the reference writes from every rank)."""
