@@ -51,6 +51,7 @@ class OmniParser(nn.Module):
         self._engine_key = None
         self.use_graph = True          # decoder steps replay as hipGraphs when run on a non-default stream
         self.overlap_decoders = True   # polygon || recognition decoders on two streams
+        self.enc_chunk = 32            # images per encoder pass inside one engine call (see _encode_chunked)
         self._streams = None
         self.phase_events = None       # set to [] to collect (name, torch.cuda.Event) marks per infer()
         self.eval()
@@ -124,7 +125,7 @@ class OmniParser(nn.Module):
             if has_padding is None:
                 has_padding = bool(mask.any())
             self._mark('start')
-            e = enc.encode(img, mask)
+            e = self._encode_chunked(enc, img, mask)
             self._mark('encode')
             kv = dec.project_memory(e['memory'], e['mem_pos'], B, e['M'], e['key_mask'] if has_padding else None)
             prompt = [int(t) for t in sequence[0].reshape(-1).tolist()]
@@ -141,6 +142,19 @@ class OmniParser(nn.Module):
                 outer.wait_stream(dstream)
                 return out
             return self._decode(dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side)
+
+    def _encode_chunked(self, enc, img, mask):
+        """The encoder gains nothing from more than a few images per launch (its kernels already fill the chip) while
+        its activations grow with the batch; the decoders do gain (their steps are latency-bound).  So a large engine
+        call is encoded `enc_chunk` images at a time and only the (small) memory tensors are concatenated."""
+        B, ch = img.shape[0], max(1, int(self.enc_chunk))
+        if B <= ch:
+            return enc.encode(img, mask)
+        parts = [enc.encode(img[i:i + ch], mask[i:i + ch]) for i in range(0, B, ch)]
+        out = dict(parts[0])
+        for k in ('memory', 'mem_pos', 'pos', 'key_mask'):
+            out[k] = torch.cat([p[k] for p in parts], 0)
+        return out
 
     def _decode(self, dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side):
         """point decoder -> polygon || recognition decoders (or the KIE walk) on the current stream"""

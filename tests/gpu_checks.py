@@ -522,6 +522,19 @@ def check_batch_equivalence(dtype_name='fp32', graph=False):
             n = min(x.numel(), y.numel())
             tot += max(x.numel(), y.numel())
             same += int((x.reshape(-1)[:n] == y.reshape(-1)[:n]).sum())
+    # the same engine call with the encoder run one image at a time (OmniParser._encode_chunked) must not change a token
+    model.enc_chunk = 1
+    chunked = model.infer(imgs, mask, seqs)
+    model.enc_chunk = 32
+    for b in range(3):
+        if together[b] is None or chunked[b] is None:
+            tot += 1
+            same += 1 if (together[b] is None) == (chunked[b] is None) else 0
+            continue
+        for x, y in zip(chunked[b][0], together[b][0]):
+            n = min(x.numel(), y.numel())
+            tot += max(x.numel(), y.numel())
+            same += int((x.reshape(-1)[:n] == y.reshape(-1)[:n]).sum())
     # fp32: identical tokens.  bf16: the cross-attention key split and the GEMM kernel choice depend on
     # the number of rows in flight, so summation order (not the math) differs -> near-tie flips allowed.
     frac = same / max(1, tot)

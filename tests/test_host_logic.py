@@ -187,3 +187,30 @@ def test_erf_fast_twin_matches_scipy():
     small = fma(q, a, a)
     y = np.where(t > 0.927734375, big, small)
     assert np.abs(y.astype(np.float64) - erf(a.astype(np.float64))).max() < 1.5e-7
+
+
+def test_encoder_chunking_concatenates_memory_in_image_order():
+    """OmniParser._encode_chunked: a large engine call is encoded enc_chunk images at a time; memory rows / masks of
+    the chunks are concatenated in image order and the per-batch scalars are kept"""
+    from advancedliteratemachinery_amd.model.omniparser import OmniParser
+
+    class FakeEnc(object):
+        calls = []
+
+        def encode(self, img, mask):
+            b = img.shape[0]
+            FakeEnc.calls.append(b)
+            ids = img[:, 0, 0, 0].repeat_interleave(4)          # M = 4 memory rows per image, tagged with the image id
+            return dict(memory=ids[:, None].float(), mem_pos=ids[:, None].float() + 0.5, pos=ids[:, None].float() * 0,
+                        key_mask=mask[:, 0, :4].to(torch.uint8), M=4, hw=(2, 2))
+
+    m = OmniParser.__new__(OmniParser)
+    m.enc_chunk = 3
+    img = torch.arange(8, dtype=torch.float32).reshape(8, 1, 1, 1).expand(8, 3, 2, 8).contiguous()
+    mask = torch.zeros(8, 2, 8, dtype=torch.bool)
+    mask[5] = True
+    out = OmniParser._encode_chunked(m, FakeEnc(), img, mask)
+    assert FakeEnc.calls == [3, 3, 2]
+    assert out['memory'][:, 0].tolist() == [float(i) for i in range(8) for _ in range(4)]
+    assert out['key_mask'].shape == (8, 4) and out['key_mask'][5].all() and not out['key_mask'][4].any()
+    assert out['M'] == 4 and out['hw'] == (2, 2)
