@@ -10,14 +10,14 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from advancedliteratemachinery_amd.model.mgp_str import MGPSTR  # noqa: E402
-from oracle import mgp_str_ref as R  # noqa: E402  (procedural checkpoint generator: data only)
+from advancedliteratemachinery_amd.utils import synthetic as R  # noqa: E402  (seeded procedural checkpoint: data only)
 
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    c = R.cfg()
-    sd = R.make_state_dict(c, seed=0)
+    c = R.mgp_cfg()
+    sd = R.make_mgp_state_dict(c, seed=0)
     model = MGPSTR(engine_dtype='bf16')
     model.load_reference_state_dict({'module.' + k: v for k, v in sd.items()})
     model = model.to('cuda:0')
