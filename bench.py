@@ -43,8 +43,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=32)
-    p.add_argument('--warmup', type=int, default=8)
+    p.add_argument('--steps', type=int, default=64)
+    p.add_argument('--warmup', type=int, default=16)
     p.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     p.add_argument('--size', type=int, default=1024)
     p.add_argument('--instances', type=int, default=64, help='forced text instances per image')
@@ -56,9 +56,10 @@ def parse():
     p.add_argument('--overlap', type=int, default=1, help='polygon || recognition decoders on two streams')
     p.add_argument('--lanes', type=int, default=int(os.environ.get('OMP355_LANES', '2')),
                    help='step groups in flight per GPU (engine/pipeline.py): they overlap on separate HIP streams')
-    p.add_argument('--coalesce', type=int, default=int(os.environ.get('OMP355_COALESCE', '8')),
+    p.add_argument('--coalesce', type=int, default=int(os.environ.get('OMP355_COALESCE', '16')),
                    help='consecutive steps (batches of --batch images) merged into one engine call: the decoders then '
-                        'advance coalesce*batch images per launch (dynamic batching across steps); 1 = every step alone')
+                        'advance coalesce*batch images per launch (dynamic batching across steps); 1 = every step alone; '
+                        'capped at ceil(steps / lanes) so that every lane gets work')
     return p.parse_args()
 
 
@@ -253,7 +254,8 @@ def main():
     lanes = max(1, a.lanes)
     pool = LanePool(device, lanes) if lanes > 1 else None
 
-    G = max(1, a.coalesce)
+    # steps per engine call: `coalesce`, but never so many that a lane would stay idle in a short run
+    G = max(1, min(a.coalesce, -(-a.steps // lanes)))
 
     def group_input(g):
         """g consecutive steps as one engine call: the g batches are concatenated inside the timed region (a serving

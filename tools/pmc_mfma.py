@@ -9,6 +9,7 @@ import re
 import sys
 
 SIMDS = 256 * 4
+XCDS = 8   # GRBM_GUI_ACTIVE is reported summed over the XCDs on gfx950 (calibrated on a GEMM with a known MFMA count)
 
 
 def main():
@@ -20,15 +21,15 @@ def main():
             d = agg.setdefault(k, collections.defaultdict(float))
             d[r['Counter_Name']] += float(r['Counter_Value'])
             d['_rows_' + r['Counter_Name']] += 1
-    print('# %s : MfmaUtil = MFMA_BUSY / (GUI_ACTIVE * %d SIMDs)' % (path.split('/')[-1], SIMDS))
+    print('# %s : MfmaUtil = MFMA_BUSY / (GUI_ACTIVE / %d XCDs * %d SIMDs); gui_cyc/call per XCD' % (path.split('/')[-1], XCDS, SIMDS))
     print('%-70s %10s %6s %7s %12s %10s %12s' % ('kernel', 'grid', 'wg', 'calls', 'gui_cyc/call', 'MfmaUtil%', 'lds_confl/call'))
     rows = []
     for (k, g, w), d in agg.items():
         n = d.get('_rows_GRBM_GUI_ACTIVE', 0)
         if not n or d.get('GRBM_GUI_ACTIVE', 0) <= 0:
             continue
-        util = 100.0 * d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (d['GRBM_GUI_ACTIVE'] * SIMDS)
-        rows.append((d['GRBM_GUI_ACTIVE'], k, g, w, int(n), d['GRBM_GUI_ACTIVE'] / n, util, d.get('SQ_LDS_BANK_CONFLICT', 0.0) / n))
+        util = 100.0 * d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (d['GRBM_GUI_ACTIVE'] / XCDS * SIMDS)
+        rows.append((d['GRBM_GUI_ACTIVE'], k, g, w, int(n), d['GRBM_GUI_ACTIVE'] / n / XCDS, util, d.get('SQ_LDS_BANK_CONFLICT', 0.0) / n))
     for _, k, g, w, n, cyc, util, conf in sorted(rows, reverse=True):
         if n >= (int(sys.argv[2]) if len(sys.argv) > 2 else 1):
             print('%-70s %10s %6s %7d %12.0f %10.2f %12.0f' % (k, g, w, n, cyc, util, conf))
