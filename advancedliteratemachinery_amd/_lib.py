@@ -100,6 +100,11 @@ def lib():
     """Load (once) and return the ctypes handle; raises if the library was not built."""
     global _lib
     if _lib is None:
+        # PyTorch ships its own HIP runtime and loads it into the global symbol scope.  libomp355.so must be
+        # dlopen'ed AFTER it: its kernels register themselves (at load time) with whichever runtime the loader
+        # binds first, and every stream / pointer it is handed comes from torch's.  Loaded the other way round the
+        # kernels sit in /opt/rocm's runtime while later calls bind to torch's -> "invalid device function".
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 'libomp355.so not found at %s -- build it with `python -m advancedliteratemachinery_amd.build` '

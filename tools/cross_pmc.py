@@ -1,0 +1,50 @@
+"""The two decoder cross-attention kernels in isolation at the shapes of one bench.py engine call (default: 128
+images, M = 4096 memory tokens, bf16), for the rocprofv3 --pmc passes that feed roofline.traffic when profiling the
+whole bench at that size is impractical (PMC mode serialises ~16 k dispatches per pass).  Launch mix 22 : 10 =
+the bench's 3752 : 1708 (point-decoder launches with 1 row per image : polygon / recognition launches with 64).
+    python tools/cross_pmc.py [images]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from advancedliteratemachinery_amd import ops  # noqa: E402
+from advancedliteratemachinery_amd.model.transformer import Decoder  # noqa: E402
+
+
+def main():
+    I = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    M, nH, d, KB = 4096, 8, 512, 32
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(0)
+    K = torch.randn(2, I, nH, M, 64, generator=g).to(dev, torch.bfloat16)            # two layer slabs, alternated
+    Vt = torch.randn(2, I, nH, M // KB, 64, KB, generator=g).to(dev, torch.bfloat16)
+
+    def run(rows_per_img, n_launch, S):
+        counts = [rows_per_img] * I
+        groups, qt = Decoder.make_tiles(counts)
+        gd = torch.tensor(groups, dtype=torch.int32, device=dev)
+        R = sum(counts)
+        q = torch.randn(R, d, device=dev).to(torch.bfloat16)
+        out = torch.empty(R, d, device=dev, dtype=torch.bfloat16)
+        partial = torch.empty(R, nH, S, 68, device=dev)
+        for i in range(n_launch):
+            ops.dec_cross_attn_step(q, K[i & 1], Vt[i & 1], nH * M * 64, M, None, gd, len(groups), qt, partial, out, M, nH, S)
+        torch.cuda.synchronize()
+        print('rows/img %d: %d launches, q_tiles %d, S %d, groups %d' % (rows_per_img, n_launch, qt, S, len(groups)), flush=True)
+
+    # key splits as Decoder._n_split picks them for this many images (transformer.py)
+    s_pt = 8
+    while s_pt > 1 and I * nH * s_pt > 4096:
+        s_pt //= 2
+    s_q4 = 1
+    while s_q4 < 16 and I * nH * s_q4 < 512 and M >= 8 * KB * s_q4:
+        s_q4 *= 2
+    run(1, 22, s_pt)
+    run(64, 10, s_q4)
+
+
+if __name__ == '__main__':
+    main()
