@@ -15,6 +15,7 @@ STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
 MAX_DEC_LAYERS = 8
+MAX_GRAPH_SLOTS = 4096   # csrc/decoder.hip: fixed table of cached hipGraphs
 
 c_void_p, c_int, c_int32, c_int64, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
                                               ctypes.c_int64, ctypes.c_float)

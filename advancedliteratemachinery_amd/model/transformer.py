@@ -234,7 +234,10 @@ class Decoder(object):
         key = bytes(plan)
         if key not in self._graph_slots:
             self._graph_slots[key] = next(Decoder._slot_ids)
-        return self._graph_slots[key]
+        slot = self._graph_slots[key]
+        # the library holds a fixed table of graph slots; a process that has seen more (decoder, shape) plans than
+        # that keeps working with eager launches for the new ones
+        return slot if slot < _lib.MAX_GRAPH_SLOTS else -1
 
     def _run(self, ph, first_pos, n_steps):
         if n_steps <= 0:
