@@ -19,7 +19,7 @@
 namespace {
 
 int g_prefetch = 1;      // K tiles of register prefetch in gemm_tiled (1 or 2; 2 measured slower: 160 VGPRs)
-int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows, 4 small split-K, 5 dma128 (2 stages), 6 dma64 ring, 7/8 dma128 with 3/4 stages, 9 dma 256x256 / 8 waves
+int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows, 4 small split-K, 5 dma128 (2 stages), 6 dma64 ring, 7/8 dma128 with 3/4 stages, 9 dma 256x256 / 8 waves, 10-12 experimental half-K-stage rings
 
 struct GemmP {
   const void* A; int64_t lda;
@@ -708,6 +708,215 @@ int launch_dma8(GemmP& p, hipStream_t st) {
   return OMP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_dmah<T,TOut,BM,BN,NWM,NWN,NS>  -- EXPERIMENTAL (round 2 candidate; reachable only through
+// omp_debug_force_gemm_kernel(10|11|12), not selected automatically, excluded from the default parity run).
+//
+// Diagnosis behind it (DESIGN.md "GEMM diagnosis"): with 64-deep K tiles and a 2-stage ring the DMA round trip
+// (~1 us) is exposed on every K tile; the fix is more bytes in flight per CU, i.e. a deeper ring of SMALLER
+// stages.  Here a stage is a HALF K tile (64-byte rows = 32 bf16 / 16 f32 k-elements = one MFMA k-step) and the
+// ring has NS = 4 of them: 3 stages (1.5 K tiles) stay in flight across every barrier, counted with
+// s_waitcnt vmcnt(N).  256x256 tile, 8 waves (2 x 4): stage 32 KB, ring 128 KB, 32 MFMAs per wave per barrier.
+// LDS image: rows of 64 bytes = 4 slots of 16 bytes.  A DMA instruction fills 16 rows lane-linearly (lane l ->
+// row l >> 2, slot l & 3); the fragment ds_read_b128 of a 16-row tile (lane = row + 16 * kchunk) is conflict-free
+// with slot = kchunk ^ F[(row >> 2) & 3], F = {0, 3, 2, 1}: within each of the instruction's four 16-lane service
+// groups the four lanes that share a bank quarter (row & 3) then hit four different slots.  As everywhere, the
+// swizzle is applied to the per-lane SOURCE address of the DMA.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz64(int kchunk, int row) { return kchunk ^ ((4 - ((row >> 2) & 3)) & 3); }
+
+template <typename T, typename TOut, int BM, int BN, int NWM, int NWN, int NS>
+__global__ __launch_bounds__(64 * NWM * NWN) void gemm_dmah(GemmP p) {
+  typedef Mma<T> MM;
+  typedef typename MM::frag frag;
+  constexpr int NW = NWM * NWN, NT = 64 * NW;
+  constexpr int ROWB = 64;                          // bytes of K per LDS row = one MFMA k-step
+  constexpr int KT = ROWB / (int)sizeof(T);         // 32 (bf16) / 16 (f32) == MM::KSTEP
+  static_assert(KT == MM::KSTEP, "a stage is exactly one k-step");
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int WTM = BM / NWM, WTN = BN / NWN;     // wave tile
+  constexpr int FM = WTM / 16, FN = WTN / 16;
+  constexpr int AI = BM / NW / 16, WI = BN / NW / 16;   // DMA instructions per wave per stage (16 rows each)
+  static_assert(AI >= 1 && WI >= 1 && (BM / NW) % 16 == 0 && (BN / NW) % 16 == 0, "16-row DMA pieces");
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int ES = BN + 4;
+  constexpr int EC = 64;                            // epilogue chunk rows: a chunk lies inside ONE wave row
+  static_assert(EC * ES * 4 <= NS * STAGE && WTM % EC == 0 && BM % EC == 0, "epilogue chunk fits the ring and divides the wave tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int n0 = tn * BN;
+
+  // DMA: lane l fills slot (l & 3) of row (l >> 2) of a 16-row piece with source chunk (l & 3) ^ F[l >> 4]
+  const int pr = lane >> 2, pc = swz64(lane & 3, pr);
+  const T* a_src[AI];
+  const T* w_src[WI];
+#pragma unroll
+  for (int j = 0; j < AI; ++j) {
+    int64_t gm = m0 + wave * (BM / NW) + j * 16 + pr; if (gm > p.M - 1) gm = p.M - 1;
+    a_src[j] = reinterpret_cast<const T*>(p.A) + gm * p.lda + pc * EPC;
+  }
+#pragma unroll
+  for (int j = 0; j < WI; ++j) {
+    int gn = n0 + wave * (BN / NW) + j * 16 + pr; if (gn > p.N - 1) gn = p.N - 1;
+    w_src[j] = reinterpret_cast<const T*>(p.W) + (int64_t)gn * p.ldw + pc * EPC;
+  }
+  auto issue = [&](int kt, int buf) {
+    const int koff = kt * KT;
+    char* abase = smem + buf * STAGE + (wave * (BM / NW)) * ROWB;
+    char* wbase = smem + buf * STAGE + BM * ROWB + (wave * (BN / NW)) * ROWB;
+#pragma unroll
+    for (int j = 0; j < AI; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(abase + j * 16 * ROWB), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < WI; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(wbase + j * 16 * ROWB), 16, 0, 0);
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lrow = lane & 15, lg = lane >> 4;
+  const int foff = lrow * ROWB + (swz64(lg, lrow) << 4);   // fragment tiles are 16-row aligned: (row >> 2) & 3 == (lrow >> 2)
+  auto compute = [&](int buf) {
+    const char* as = smem + buf * STAGE + (wm * WTM) * ROWB + foff;
+    const char* ws = smem + buf * STAGE + BM * ROWB + (wn * WTN) * ROWB + foff;
+    frag fw[FN], fx[FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) fw[i] = *reinterpret_cast<const frag*>(ws + i * 16 * ROWB);
+#pragma unroll
+    for (int j = 0; j < FM; ++j) fx[j] = *reinterpret_cast<const frag*>(as + j * 16 * ROWB);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) MM::mma(acc[i][j], fw[i], fx[j]);
+  };
+
+  // ring of NS half-tile stages, protocol of gemm_dma: prologue fills NS-1 stages; iteration kt waits for ITS stage
+  // only (min(nk-1-kt, NS-2) newer stages stay in flight), one barrier, refill of the stage read in iteration kt-1
+  const int nk = p.K / KT;
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < nk) issue(t, t);
+  int st_c = 0, st_i = NS - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int after = nk - 1 - kt;
+    wait_dma_tiles<AI + WI>(after < NS - 2 ? after : NS - 2);
+    __builtin_amdgcn_s_barrier();
+    if (kt + NS - 1 < nk) issue(kt + NS - 1, st_i);
+    compute(st_c);
+    st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+    st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
+  }
+
+  // ---- epilogue in EC-row chunks through the (then idle) ring: act(acc + bias) -> fp32 rows -> 16-byte stores ----
+  float* E = reinterpret_cast<float*>(smem);
+  const float* bias = p.bias;
+  if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
+  constexpr int CH = 16 / (int)sizeof(TOut);
+  constexpr int CPR = BN / CH;
+  constexpr int RPP = NT / CPR;
+  static_assert(NT % CPR == 0 && EC % RPP == 0, "store passes tile the chunk");
+  constexpr int JPC = EC / 16;                  // m-fragments per chunk (a chunk lies inside one wave row: WTM % EC == 0)
+  const TOut* res = reinterpret_cast<const TOut*>(p.residual);
+  TOut* C = reinterpret_cast<TOut*>(p.C);
+  const bool vec_ok = p.store_mode == OMP_STORE_PLAIN && !p.trans_out && (p.ldc % CH) == 0 &&
+                      (res == nullptr || (p.ldr % CH) == 0);
+  const int cidx = tid % CPR, rsub = tid / CPR;
+  const int n = n0 + cidx * CH;
+#pragma unroll
+  for (int chunk = 0; chunk < BM / EC; ++chunk) {
+    __syncthreads();   // chunk 0: the last stage has been consumed by everybody; later: the previous chunk has been stored
+    if (wm == (chunk * EC) / WTM) {
+      const int j0 = ((chunk * EC) % WTM) / 16;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int nl = wn * WTN + i * 16 + lg * 4;
+        float bn[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr && !p.bias_m) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n0 + nl + r < p.N) bn[r] = bias[n0 + nl + r];
+        }
+#pragma unroll
+        for (int jj = 0; jj < JPC; ++jj) {
+          const int ml = jj * 16 + lrow;
+          const int64_t mg = m0 + chunk * EC + ml;
+          float bm = 0.f;
+          if (bias != nullptr && p.bias_m && mg < p.M) bm = bias[mg];
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[i][j0 + jj][r] + bn[r] + bm, p.act);
+          *reinterpret_cast<f32x4*>(E + ml * ES + nl) = o;
+        }
+      }
+    }
+    __syncthreads();
+    if (n < p.N) {
+      if (vec_ok && n + CH <= p.N) {
+#pragma unroll 4
+        for (int pass = 0; pass < EC / RPP; ++pass) {
+          const int r = pass * RPP + rsub;
+          const int64_t m = m0 + chunk * EC + r;
+          if (m < p.M) {
+            float v[CH];
+#pragma unroll
+            for (int q = 0; q < CH; q += 4) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
+              v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
+            }
+            if (res != nullptr) {
+              float rv[CH];
+              unpack16(*reinterpret_cast<const typename Vec16<TOut>::type*>(res + m * p.ldr + n), rv);
+#pragma unroll
+              for (int q = 0; q < CH; ++q) v[q] += rv[q];
+            }
+            typename Vec16<TOut>::type o;
+            pack16(v, o);
+            *reinterpret_cast<typename Vec16<TOut>::type*>(C + m * p.ldc + n) = o;
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int it = 0; it < (EC / RPP) * (CH / 4); ++it) {
+          const int pass = it / (CH / 4), q = (it % (CH / 4)) * 4;
+          const int r = pass * RPP + rsub;
+          const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
+          const float v[4] = {t[0], t[1], t[2], t[3]};
+          store4<TOut>(p, m0 + chunk * EC + r, n + q, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, typename TOut, int BM, int BN, int NWM, int NWN, int NS>
+int launch_dmah(GemmP& p, hipStream_t st) {
+  constexpr size_t smem = (size_t)NS * (BM + BN) * 64;
+  auto kern = gemm_dmah<T, TOut, BM, BN, NWM, NWN, NS>;
+  static bool done = false;   // per template instantiation
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      omp_set_error("omp_gemm_bias_act: cannot raise dynamic LDS limit");
+      return OMP_ERR_LAUNCH;
+    }
+    done = true;
+  }
+  p.tiles_m = (int)ceil_div64(p.M, BM); p.tiles_n = (int)ceil_div64(p.N, BN);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * NWM * NWN), smem, st, p);
+  return OMP_OK;
+}
+
 // Small-M path: grid (ceil(N/64), ceil(M/16)), 4 waves, wave w owns output features
 // [bx*64 + 16w, +16) for tokens [by*16, +16).  No LDS, fragments come straight from global.
 template <typename T, typename TOut>
@@ -956,6 +1165,15 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
     if (rc != OMP_OK) return rc;
   } else if (which == 9) {
     int rc = launch_dma8<T, TOut>(p, st);
+    if (rc != OMP_OK) return rc;
+  } else if (which == 10) {          // experimental: 256x256, 8 waves, 4 half-K stages (128 KB)
+    int rc = launch_dmah<T, TOut, 256, 256, 2, 4, 4>(p, st);
+    if (rc != OMP_OK) return rc;
+  } else if (which == 11) {          // experimental: 128x128, 4 waves, 4 half-K stages (64 KB, two workgroups per CU)
+    int rc = launch_dmah<T, TOut, 128, 128, 2, 2, 4>(p, st);
+    if (rc != OMP_OK) return rc;
+  } else if (which == 12) {          // experimental: 256x128, 8 waves (4 x 2), 6 half-K stages (144 KB)
+    int rc = launch_dmah<T, TOut, 256, 128, 4, 2, 6>(p, st);
     if (rc != OMP_OK) return rc;
   } else if (which == 7) {
     int rc = launch_dma<T, TOut, 128, 128, 3>(p, st);

@@ -67,7 +67,9 @@ def check_gemm():
               (64, 512, 512), (2049, 256, 1024), (16, 2048, 512)]
     for dn, dt in DTYPES.items():
         tol = 2e-4 if dt == torch.float32 else 3e-2
-        for which in (0, 1, 2, 3, 5, 6, 7, 8, 9):
+        # OMP355_EXPERIMENTAL_GEMM=10,11,12 adds kernels that are not (yet) reachable without the debug selector
+        extra = tuple(int(v) for v in os.environ.get('OMP355_EXPERIMENTAL_GEMM', '').split(',') if v)
+        for which in (0, 1, 2, 3, 5, 6, 7, 8, 9) + extra:
             ops.force_gemm_kernel(which)
             for (M, N, K) in shapes:
                 if which == 3 and M > 600:
