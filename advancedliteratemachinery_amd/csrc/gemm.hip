@@ -521,7 +521,7 @@ int launch_dma(GemmP& p, hipStream_t st) {
 // at once, so the epilogue runs in four 64-row chunks through the (then idle) operand stages.
 // Used for the large-M GEMMs whose N is a multiple of 256 (Swin stages 1-3, K/V projection, ViT-B).
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename TOut>
+template <typename T, typename TOut, bool PIPE>
 __global__ __launch_bounds__(512) void gemm_dma8(GemmP p) {
   typedef Mma<T> MM;
   typedef typename MM::frag frag;
@@ -604,12 +604,74 @@ __global__ __launch_bounds__(512) void gemm_dma8(GemmP p) {
   };
 
   const int nk = p.K / KT;
-  issue(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
+  if constexpr (!PIPE) {
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      compute(kt & 1);
+    }
+  } else {
+    // Software-pipelined variant (EXPERIMENTAL, selector 13): the fragments of the NEXT k-step are loaded from LDS
+    // while the MFMAs of the current one run, and the single barrier per K tile sits in the MIDDLE of the tile:
+    //   F1 <- (tile kt, step 1) | MFMA(F0) | wait own DMA of tile kt+1, own LDS reads; barrier
+    //   DMA tile kt+2 -> the stage just read | F0 <- (tile kt+1, step 0) | MFMA(F1)
+    // so no wave ever stands between a barrier and its first MFMA waiting for ds_reads.  The barrier still orders
+    // both hazards: every wave's reads of the current stage have returned (lgkmcnt(0)) before it is refilled, and
+    // every wave's part of the next tile has landed (vmcnt(0)) before anybody reads it.
+    static_assert(STEPS == 2, "two k-steps per K tile");
+    auto load_frags = [&](int buf, int s, frag* fw, frag* fx) {
+      const char* as = smem + buf * STAGE + (wm * 128) * ROWB;
+      const char* ws = smem + buf * STAGE + BM * ROWB + (wn * 64) * ROWB;
+      const int c = s * 4 + lg;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int row = i * 16 + lrow;
+        fw[i] = *reinterpret_cast<const frag*>(ws + row * ROWB + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int row = j * 16 + lrow;
+        fx[j] = *reinterpret_cast<const frag*>(as + row * ROWB + ((c ^ (row & 7)) << 4));
+      }
+    };
+    auto mfmas = [&](const frag* fw, const frag* fx) {
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) MM::mma(acc[i][j], fw[i], fx[j]);
+    };
+    frag fw0[FN], fx0[FM], fw1[FN], fx1[FM];
+    issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    compute(kt & 1);
+    if (nk > 1) issue(1, 1);
+    load_frags(0, 0, fw0, fx0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      // sched_barrier(0) pins the order: the compiler otherwise sinks the register-only MFMAs below the wait and the
+      // barrier, which puts the ds_read latency back on the critical path
+      // F0 was requested before the previous 32 MFMAs: it has landed; the explicit wait (asm = never dropped, builtin
+      // = visible to the compiler's counter model) lets the compiler issue MFMA(F0) without a conservative
+      // lgkmcnt(0) AFTER the F1 loads, which would expose their latency
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(cur, 1, fw1, fx1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(fw0, fx0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < nk) issue(kt + 2, cur);
+      if (kt + 1 < nk) load_frags(cur ^ 1, 0, fw0, fx0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(fw1, fx1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // ---- epilogue in four 64-row chunks: act(acc + bias) -> fp32 rows in LDS -> row-contiguous 16-byte stores ----
@@ -691,10 +753,10 @@ __global__ __launch_bounds__(512) void gemm_dma8(GemmP p) {
   }
 }
 
-template <typename T, typename TOut>
+template <typename T, typename TOut, bool PIPE>
 int launch_dma8(GemmP& p, hipStream_t st) {
   constexpr size_t smem = 2 * (256 + 256) * 128;   // 128 KB: two operand stages (the epilogue chunks reuse them)
-  auto kern = gemm_dma8<T, TOut>;
+  auto kern = gemm_dma8<T, TOut, PIPE>;
   static bool done = false;   // per template instantiation
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -1164,7 +1226,10 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
                                                                  : launch_dma<T, TOut, 64, 64, 4>(p, st);
     if (rc != OMP_OK) return rc;
   } else if (which == 9) {
-    int rc = launch_dma8<T, TOut>(p, st);
+    int rc = launch_dma8<T, TOut, false>(p, st);
+    if (rc != OMP_OK) return rc;
+  } else if (which == 13) {          // experimental: 256x256 / 8 waves with register-pipelined fragments, mid-tile barrier
+    int rc = launch_dma8<T, TOut, true>(p, st);
     if (rc != OMP_OK) return rc;
   } else if (which == 10) {          // experimental: 256x256, 8 waves, 4 half-K stages (128 KB)
     int rc = launch_dmah<T, TOut, 256, 256, 2, 4, 4>(p, st);
