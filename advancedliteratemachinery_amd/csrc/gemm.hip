@@ -421,6 +421,28 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
     st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
   }
 
+  // ---- epilogue phase 0: request this thread's residual rows NOW, so that their memory round trip runs under
+  // phase 1 (every DMA has been waited for, so nothing else is outstanding) ---------------------------------
+  constexpr int CH = 16 / (int)sizeof(TOut);   // output elements per 16-byte chunk
+  constexpr int CPR = BN / CH;                 // chunks per tile row
+  constexpr int RPP = 256 / CPR;               // rows per pass
+  const TOut* res = reinterpret_cast<const TOut*>(p.residual);
+  TOut* C = reinterpret_cast<TOut*>(p.C);
+  const bool vec_ok = p.store_mode == OMP_STORE_PLAIN && !p.trans_out && (p.ldc % CH) == 0 &&
+                      (res == nullptr || (p.ldr % CH) == 0);
+  const int cidx = tid % CPR, rsub = tid / CPR;
+  const int n = n0 + cidx * CH;
+  const bool vec_path = vec_ok && n + CH <= p.N;
+  typename Vec16<TOut>::type rres[BM / RPP];
+  if (vec_path && res != nullptr) {
+#pragma unroll
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+      int64_t m = m0 + pass * RPP + rsub;
+      if (m > p.M - 1) m = p.M - 1;            // clamped rows are loaded but never stored
+      rres[pass] = *reinterpret_cast<const typename Vec16<TOut>::type*>(res + m * p.ldr + n);
+    }
+  }
+
   // ---- epilogue phase 1: act(acc + bias) -> fp32 rows in LDS ------------------------------------
   __builtin_amdgcn_s_barrier();   // all waves are done with the operand stages
   float* E = reinterpret_cast<float*>(smem);
@@ -448,18 +470,9 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
   }
   __syncthreads();
   // ---- phase 2: row-contiguous 16-byte stores ------------------------------------------------------
-  constexpr int CH = 16 / (int)sizeof(TOut);   // output elements per 16-byte chunk
-  constexpr int CPR = BN / CH;                 // chunks per tile row
-  constexpr int RPP = 256 / CPR;               // rows per pass
-  const TOut* res = reinterpret_cast<const TOut*>(p.residual);
-  TOut* C = reinterpret_cast<TOut*>(p.C);
-  const bool vec_ok = p.store_mode == OMP_STORE_PLAIN && !p.trans_out && (p.ldc % CH) == 0 &&
-                      (res == nullptr || (p.ldr % CH) == 0);
-  const int cidx = tid % CPR, rsub = tid / CPR;
-  const int n = n0 + cidx * CH;
   if (n >= p.N) return;
-  if (vec_ok && n + CH <= p.N) {
-#pragma unroll 4
+  if (vec_path) {
+#pragma unroll
     for (int pass = 0; pass < BM / RPP; ++pass) {
       const int r = pass * RPP + rsub;
       const int64_t m = m0 + r;
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
         }
         if (res != nullptr) {
           float rv[CH];
-          unpack16(*reinterpret_cast<const typename Vec16<TOut>::type*>(res + m * p.ldr + n), rv);
+          unpack16(rres[pass], rv);
 #pragma unroll
           for (int q = 0; q < CH; ++q) v[q] += rv[q];
         }
