@@ -527,6 +527,256 @@ int launch_dma(GemmP& p, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemm_dmap<T,TOut>  -- EXPERIMENTAL persistent form of gemm_dma<128,128,2> (selector 14; written at the end of
+// round 1 from the measurement that at K = 128..1024 more than half of a tile's time is prologue + epilogue, and
+// not yet run on the hardware -- excluded from the default parity run, OMP355_EXPERIMENTAL_GEMM=14 adds it).
+//   * the grid is at most 2 workgroups per CU; a workgroup walks its XCD's contiguous chunk of the tile list with
+//     the stride of the workgroups on that XCD, so co-running workgroups share A rows in L2 exactly as before;
+//   * K tiles alternate between the two 32 KB stages and K / 64 is even, so when a tile's main loop ends its last
+//     K tile sits in stage 1 and stage 0 is free (the barrier of the last iteration proved everybody done with it):
+//     the NEXT tile's first K tile is requested into stage 0 BEFORE the epilogue starts -- its DMA round trip, the
+//     exposed prologue of the one-tile kernel, runs under the epilogue;
+//   * the epilogue goes through stage 1 only, in four chunks of 32 rows (16.9 KB each), residual rows requested
+//     up front as in gemm_dma.  LDS stays 64 KB: two workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename TOut>
+__global__ __launch_bounds__(256, 2) void gemm_dmap(GemmP p) {   // 2 waves per SIMD: two workgroups per CU
+  typedef Mma<T> MM;
+  typedef typename MM::frag frag;
+  constexpr int BM = 128, BN = 128;
+  constexpr int ROWB = 128;
+  constexpr int KT = ROWB / (int)sizeof(T);
+  constexpr int STEPS = KT / MM::KSTEP;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int FM = 4, FN = 4;
+  constexpr int AI = 4, WI = 4;
+  constexpr int STAGE = (BM + BN) * ROWB;         // 32 KB
+  constexpr int ES = BN + 4;
+  constexpr int EC = 32;                          // epilogue chunk rows: 32 * 132 * 4 B = 16.9 KB, inside stage 1
+  static_assert(EC * ES * 4 <= STAGE, "an epilogue chunk fits one stage");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+  const int lrow = lane & 15, lg = lane >> 4;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int nk = p.K / KT;                        // even (checked by the launcher)
+
+  // this workgroup's tiles: XCD x = blockIdx % 8 owns the contiguous logical tiles [start, start + cnt) (the
+  // partition of xcd_remap); its workgroups (slot = blockIdx / 8) take them with stride gridDim / 8
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int start = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int cnt = q8 + (xcd < r8 ? 1 : 0);
+  const int per = (G >> 3) + ((xcd < (G & 7)) ? 1 : 0);   // workgroups of this launch that sit on this XCD
+
+  const T* a_src[AI];
+  const T* w_src[WI];
+  int64_t m0 = 0;
+  int n0 = 0;
+  auto set_tile = [&](int lid) {
+    const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+    m0 = (int64_t)tm * BM;
+    n0 = tn * BN;
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      int64_t gm = m0 + wave * (BM / 4) + j * 8 + lr; if (gm > p.M - 1) gm = p.M - 1;
+      a_src[j] = reinterpret_cast<const T*>(p.A) + gm * p.lda + lc * EPC;
+    }
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+      int gn = n0 + wave * (BN / 4) + j * 8 + lr; if (gn > p.N - 1) gn = p.N - 1;
+      w_src[j] = reinterpret_cast<const T*>(p.W) + (int64_t)gn * p.ldw + lc * EPC;
+    }
+  };
+  auto issue = [&](int kt, int buf) {
+    const int koff = kt * KT;
+    char* abase = smem + buf * STAGE + (wave * (BM / 4)) * ROWB;
+    char* wbase = smem + buf * STAGE + BM * ROWB + (wave * (BN / 4)) * ROWB;
+#pragma unroll
+    for (int j = 0; j < AI; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(abase + j * 8 * ROWB), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < WI; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + koff),
+                                       (__attribute__((address_space(3))) void*)(wbase + j * 8 * ROWB), 16, 0, 0);
+  };
+
+  f32x4 acc[FN][FM];
+  auto compute = [&](int buf) {
+    const char* as = smem + buf * STAGE + (wm * (BM / 2)) * ROWB;
+    const char* ws = smem + buf * STAGE + BM * ROWB + (wn * (BN / 2)) * ROWB;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      frag fw[FN], fx[FM];
+      const int c = s * 4 + lg;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int row = i * 16 + lrow;
+        fw[i] = *reinterpret_cast<const frag*>(ws + row * ROWB + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int row = j * 16 + lrow;
+        fx[j] = *reinterpret_cast<const frag*>(as + row * ROWB + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) MM::mma(acc[i][j], fw[i], fx[j]);
+    }
+  };
+
+  constexpr int CH = 16 / (int)sizeof(TOut);
+  constexpr int CPR = BN / CH;
+  constexpr int RPP = 256 / CPR;
+  constexpr int PPC = EC / RPP;                 // store passes per chunk
+  static_assert(EC % RPP == 0, "store passes tile a chunk");
+  const TOut* res = reinterpret_cast<const TOut*>(p.residual);
+  TOut* C = reinterpret_cast<TOut*>(p.C);
+  const bool vec_ok = p.store_mode == OMP_STORE_PLAIN && !p.trans_out && (p.ldc % CH) == 0 &&
+                      (res == nullptr || (p.ldr % CH) == 0);
+  const int cidx = tid % CPR, rsub = tid / CPR;
+  const float* bias = p.bias;
+  if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
+  float* E = reinterpret_cast<float*>(smem + STAGE);   // stage 1
+
+  int idx = slot;
+  if (idx >= cnt) return;                       // whole workgroup: more workgroups than tiles on this XCD
+  set_tile(start + idx);
+  issue(0, 0);
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      compute(kt & 1);
+    }
+    // this tile's output coordinates, then re-aim the DMA pointers at the next tile and request its first K tile
+    const int64_t em0 = m0;
+    const int en0 = n0;
+    const int nxt = idx + per;
+    const bool more = nxt < cnt;
+    if (more) {
+      set_tile(start + nxt);
+      issue(0, 0);                               // stage 0 is free: see the header comment
+    }
+    const int n = en0 + cidx * CH;
+    const bool vec_path = vec_ok && n + CH <= p.N;
+    typename Vec16<TOut>::type rres[BM / RPP];
+    if (vec_path && res != nullptr) {
+#pragma unroll
+      for (int pass = 0; pass < BM / RPP; ++pass) {
+        int64_t m = em0 + pass * RPP + rsub;
+        if (m > p.M - 1) m = p.M - 1;
+        rres[pass] = *reinterpret_cast<const typename Vec16<TOut>::type*>(res + m * p.ldr + n);
+      }
+    }
+#pragma unroll
+    for (int chunk = 0; chunk < BM / EC; ++chunk) {
+      // raw barrier + LDS-only wait: __syncthreads() would also drain the next tile's DMA (vmcnt(0)) right here
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // chunk 0: everybody is done with stage 1; later: the previous chunk has been stored
+      if (wm == (chunk >> 1)) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          const int nl = wn * (BN / 2) + i * 16 + lg * 4;
+          float bn[4] = {0.f, 0.f, 0.f, 0.f};
+          if (bias != nullptr && !p.bias_m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (en0 + nl + r < p.N) bn[r] = bias[en0 + nl + r];
+          }
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = (chunk & 1) * 2 + jj;
+            const int ml = jj * 16 + lrow;
+            const int64_t mg = em0 + chunk * EC + ml;
+            float bm = 0.f;
+            if (bias != nullptr && p.bias_m && mg < p.M) bm = bias[mg];
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[i][j][r] + bn[r] + bm, p.act);
+            *reinterpret_cast<f32x4*>(E + ml * ES + nl) = o;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's rows of the chunk are in LDS
+      __builtin_amdgcn_s_barrier();
+      if (n < p.N) {
+        if (vec_path) {
+#pragma unroll
+          for (int pass = 0; pass < PPC; ++pass) {
+            const int r = pass * RPP + rsub;
+            const int64_t m = em0 + chunk * EC + r;
+            if (m < p.M) {
+              float v[CH];
+#pragma unroll
+              for (int q = 0; q < CH; q += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
+                v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
+              }
+              if (res != nullptr) {
+                float rv[CH];
+                unpack16(rres[chunk * PPC + pass], rv);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) v[q] += rv[q];
+              }
+              typename Vec16<TOut>::type o;
+              pack16(v, o);
+              *reinterpret_cast<typename Vec16<TOut>::type*>(C + m * p.ldc + n) = o;
+            }
+          }
+        } else {
+#pragma unroll 1
+          for (int it = 0; it < PPC * (CH / 4); ++it) {
+            const int pass = it / (CH / 4), q = (it % (CH / 4)) * 4;
+            const int r = pass * RPP + rsub;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
+            const float v[4] = {t[0], t[1], t[2], t[3]};
+            store4<TOut>(p, em0 + chunk * EC + r, n + q, v);
+          }
+        }
+      }
+    }
+    if (!more) break;
+    idx = nxt;
+    // the next main loop's first barrier orders this epilogue's last reads of stage 1 before its refill
+  }
+}
+
+template <typename T, typename TOut>
+int launch_dmap(GemmP& p, hipStream_t st) {
+  constexpr int KT = 128 / (int)sizeof(T);
+  if ((p.K / KT) % 2 != 0) {
+    omp_set_error("omp_gemm_bias_act: the persistent kernel needs an even number of K tiles (K = %d)", p.K);
+    return OMP_ERR_UNSUPPORTED;
+  }
+  constexpr size_t smem = 2 * (128 + 128) * 128;   // 64 KB
+  auto kern = gemm_dmap<T, TOut>;
+  static bool done = false;   // per template instantiation
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      omp_set_error("omp_gemm_bias_act: cannot raise dynamic LDS limit");
+      return OMP_ERR_LAUNCH;
+    }
+    done = true;
+  }
+  p.tiles_m = (int)ceil_div64(p.M, 128); p.tiles_n = (int)ceil_div64(p.N, 128);
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int grid = nwg < 512 ? nwg : 512;          // two workgroups per CU
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p);
+  return OMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // gemm_dma8<T,TOut>: 256x256 tile, 8 waves (2 along M x 4 along N, wave tile 128 x 64 = 32 accumulator
 // fragments), same DMA staging / swizzle / one-barrier-per-K-tile ring as gemm_dma with 2 stages of 64 KB.
 // Per 32-deep k-step a wave issues 12 ds_read_b128 for 32 MFMAs (gemm_dma's 2x2 waves: 8 for 16), and a
@@ -1240,6 +1490,9 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
     if (rc != OMP_OK) return rc;
   } else if (which == 9) {
     int rc = launch_dma8<T, TOut, false>(p, st);
+    if (rc != OMP_OK) return rc;
+  } else if (which == 14) {          // experimental: persistent 128x128 (next tile's first K tile requested before the epilogue)
+    int rc = launch_dmap<T, TOut>(p, st);
     if (rc != OMP_OK) return rc;
   } else if (which == 13) {          // experimental: 256x256 / 8 waves with register-pipelined fragments, mid-tile barrier
     int rc = launch_dma8<T, TOut, true>(p, st);
