@@ -528,8 +528,9 @@ int launch_dma(GemmP& p, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------
 // gemm_dmap<T,TOut>  -- EXPERIMENTAL persistent form of gemm_dma<128,128,2> (selector 14; written at the end of
-// round 1 from the measurement that at K = 128..1024 more than half of a tile's time is prologue + epilogue, and
-// not yet run on the hardware -- excluded from the default parity run, OMP355_EXPERIMENTAL_GEMM=14 adds it).
+// round 1 from the measurement that at K = 128..1024 more than half of a tile's time is prologue + epilogue.
+// Measured: parity-green, 15-60 % slower than gemm_dma (profiles/r01u_kbench_gemm_persistent.txt) -- kept as the
+// base for round 2, excluded from the default parity run, OMP355_EXPERIMENTAL_GEMM=14 adds it).
 //   * the grid is at most 2 workgroups per CU; a workgroup walks its XCD's contiguous chunk of the tile list with
 //     the stride of the workgroups on that XCD, so co-running workgroups share A rows in L2 exactly as before;
 //   * K tiles alternate between the two 32 KB stages and K / 64 is even, so when a tile's main loop ends its last
@@ -1034,8 +1035,9 @@ int launch_dma8(GemmP& p, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// gemm_dmah<T,TOut,BM,BN,NWM,NWN,NS>  -- EXPERIMENTAL (round 2 candidate; reachable only through
-// omp_debug_force_gemm_kernel(10|11|12), not selected automatically, excluded from the default parity run).
+// gemm_dmah<T,TOut,BM,BN,NWM,NWN,NS>  -- EXPERIMENTAL (reachable only through omp_debug_force_gemm_kernel(10|11|12),
+// not selected automatically, excluded from the default parity run; measured parity-green and slower than gemm_dma,
+// profiles/r01r_kbench_gemm_halfk_rings.txt).
 //
 // Diagnosis behind it (DESIGN.md "GEMM diagnosis"): with 64-deep K tiles and a 2-stage ring the DMA round trip
 // (~1 us) is exposed on every K tile; the fix is more bytes in flight per CU, i.e. a deeper ring of SMALLER
