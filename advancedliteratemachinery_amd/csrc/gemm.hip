@@ -19,6 +19,8 @@
 namespace {
 
 int g_prefetch = 1;      // K tiles of register prefetch in gemm_tiled (1 or 2; 2 measured slower: 160 VGPRs)
+unsigned long long* g_trace = nullptr;   // omp_debug_set_gemm_trace: [capacity][8] s_memtime stamps per workgroup
+long long g_trace_cap = 0;
 int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows, 4 small split-K, 5 dma128 (2 stages), 6 dma64 ring, 7/8 dma128 with 3/4 stages, 9 dma 256x256 / 8 waves, 10-12 experimental half-K-stage rings
 
 struct GemmP {
@@ -33,6 +35,7 @@ struct GemmP {
   const float* ln_g; const float* ln_b; float ln_eps;   // optional LayerNorm prologue (A is fp32)
   int store_mode; int bias_m;                           // OMP_STORE_*; bias indexed by m instead of n
   int kv_B, kv_tok, kv_mpad, kv_nH, kv_kb;              // blocked K / V^T destination geometry
+  unsigned long long* trace;                            // debug: per-workgroup phase timestamps (gemm_dma<..., TRACE>)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -318,9 +321,15 @@ __device__ __forceinline__ void wait_dma_tiles(int tiles) {
   }
 }
 
-template <typename T, typename TOut, int BM, int BN, int NS>
+template <typename T, typename TOut, int BM, int BN, int NS, bool TRACE = false>
 __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
   static_assert(NS >= 2 && NS <= 8, "2..8 LDS stages");
+  // TRACE (selector 15, development only): wave 0 / lane 0 stamps s_memtime at the phase boundaries into p.trace[blockIdx][8]
+  unsigned long long tr[6];
+  auto stamp = [&](int i) {
+    if constexpr (TRACE) tr[i] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   typedef Mma<T> MM;
   typedef typename MM::frag frag;
   constexpr int ROWB = 128;                       // bytes of K per LDS row
@@ -415,11 +424,13 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
     const int after = nk - 1 - kt;
     wait_dma_tiles<AI + WI>(after < NS - 2 ? after : NS - 2);
     __builtin_amdgcn_s_barrier();
+    if (kt == 0) stamp(1);                       // first K tile landed everywhere
     if (kt + NS - 1 < nk) issue(kt + NS - 1, st_i);
     compute(st_c);
     st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
     st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
   }
+  stamp(2);                                      // K loop done (this wave)
 
   // ---- epilogue phase 0: request this thread's residual rows NOW, so that their memory round trip runs under
   // phase 1 (every DMA has been waited for, so nothing else is outstanding) ---------------------------------
@@ -469,6 +480,7 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
     }
   }
   __syncthreads();
+  stamp(3);                                      // accumulators of every wave are in LDS
   // ---- phase 2: row-contiguous 16-byte stores ------------------------------------------------------
   if (n >= p.N) return;
   if (vec_path) {
@@ -494,6 +506,15 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
         *reinterpret_cast<typename Vec16<TOut>::type*>(C + m * p.ldc + n) = o;
       }
     }
+    if constexpr (TRACE) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores retired
+      stamp(4);
+      if (tid == 0 && p.trace != nullptr) {
+        unsigned long long* t = p.trace + (long long)blockIdx.x * 8;
+        t[0] = tr[0]; t[1] = tr[1]; t[2] = tr[2]; t[3] = tr[3]; t[4] = tr[4];
+        t[5] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // XCC_ID (HW_REG 20), low 4 bits
+      }
+    }
   } else {
     // ragged N edge, odd pitches and the transposed / blocked K / blocked V^T destinations: 4 values at a time
 #pragma unroll 1
@@ -507,12 +528,12 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
   }
 }
 
-template <typename T, typename TOut, int BM, int BN, int NS>
+template <typename T, typename TOut, int BM, int BN, int NS, bool TRACE = false>
 int launch_dma(GemmP& p, hipStream_t st) {
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int EBYTES = BM * (BN + 4) * 4;
   constexpr size_t smem = (NS * STAGE > EBYTES) ? NS * STAGE : EBYTES;
-  auto kern = gemm_dma<T, TOut, BM, BN, NS>;
+  auto kern = gemm_dma<T, TOut, BM, BN, NS, TRACE>;
   static bool done = false;   // per template instantiation
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -789,7 +810,7 @@ template <typename T, typename TOut, bool PIPE>
 __global__ __launch_bounds__(512) void gemm_dma8(GemmP p) {
   typedef Mma<T> MM;
   typedef typename MM::frag frag;
-  constexpr int BM = 256, BN = 256, NS = 2;
+  constexpr int BM = 256, BN = 256;   // two LDS stages
   constexpr int ROWB = 128;
   constexpr int KT = ROWB / (int)sizeof(T);
   constexpr int STEPS = KT / MM::KSTEP;
@@ -1493,6 +1514,15 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
   } else if (which == 9) {
     int rc = launch_dma8<T, TOut, false>(p, st);
     if (rc != OMP_OK) return rc;
+  } else if (which == 15) {          // development: gemm_dma<128,128,2> with per-workgroup phase timestamps
+    p.tiles_m = (int)ceil_div64(p.M, 128); p.tiles_n = (int)ceil_div64(p.N, 128);
+    if (g_trace == nullptr || (long long)p.tiles_m * p.tiles_n > g_trace_cap) {
+      omp_set_error("omp_gemm_bias_act: selector 15 needs omp_debug_set_gemm_trace(buffer for >= %d workgroups)", p.tiles_m * p.tiles_n);
+      return OMP_ERR_INVALID;
+    }
+    p.trace = g_trace;
+    int rc = launch_dma<T, TOut, 128, 128, 2, true>(p, st);
+    if (rc != OMP_OK) return rc;
   } else if (which == 14) {          // experimental: persistent 128x128 (next tile's first K tile requested before the epilogue)
     int rc = launch_dmap<T, TOut>(p, st);
     if (rc != OMP_OK) return rc;
@@ -1537,6 +1567,12 @@ extern "C" int omp_debug_set_gemm_prefetch(int tiles) {
   return OMP_OK;
 }
 
+extern "C" int omp_debug_set_gemm_trace(void* buffer, int64_t n_workgroups) {
+  g_trace = reinterpret_cast<unsigned long long*>(buffer);
+  g_trace_cap = buffer ? n_workgroups : 0;
+  return OMP_OK;
+}
+
 extern "C" int omp_debug_force_gemm_kernel(int which) {
   g_force_kernel = which;
   return OMP_OK;
@@ -1567,7 +1603,7 @@ extern "C" int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s) {
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act;
   p.trans_out = a->trans_out; p.trans_rows = a->trans_rows; p.trans_ld = a->trans_ld; p.tiles_m = p.tiles_n = 0;
   p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.small_hint = a->small_m_splitk;
-  p.store_mode = a->store_mode; p.bias_m = a->bias_along_m;
+  p.store_mode = a->store_mode; p.bias_m = a->bias_along_m; p.trace = nullptr;
   p.kv_B = a->kv_images; p.kv_tok = a->kv_tokens; p.kv_mpad = a->kv_mpad; p.kv_nH = a->kv_heads; p.kv_kb = a->kv_key_block;
   if (p.store_mode != OMP_STORE_PLAIN) {
     OMP_CHECK_ARG(p.store_mode == OMP_STORE_KBLK || p.store_mode == OMP_STORE_VBLK, "omp_gemm_bias_act: bad store_mode %d", p.store_mode);
