@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
@@ -82,7 +82,6 @@ _SIGS = {
     'omp_decoder_step_logits': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_void_p]),
     'omp_debug_force_gemm_kernel': (c_int, [c_int]),
     'omp_debug_set_gemm_trace': (c_int, [c_void_p, c_int64]),
-    'omp_debug_set_gemm_prefetch': (c_int, [c_int]),
     'omp_debug_swin_attn_impl': (c_int, [c_int]),
     'omp_debug_cross_q4': (c_int, [c_int]),
     'omp_vit_patch_embed': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),

@@ -1,14 +1,15 @@
 // GEMM with fused epilogue for gfx950:  C = act(A @ W^T + bias) + residual
 //
-// Two kernels, both on the 16x16 MFMA (bf16: v_mfma_f32_16x16x32_bf16, f32: v_mfma_f32_16x16x4_f32):
+// Kernels, all on the 16x16 MFMA (bf16: v_mfma_f32_16x16x32_bf16, f32: v_mfma_f32_16x16x4_f32):
 //
-//  gemm_tiled<T,TOut,BM,BN>  LDS-tiled, 4 waves (2x2), register-staged double buffer, one barrier
-//                            per 128-byte K tile, XOR-swizzled LDS rows (conflict-free
-//                            ds_read_b128), XCD-aware tile order.  Used for the big Swin / FPN /
-//                            KV-projection GEMMs (M = tokens).
-//  gemm_rows<T,TOut>         no LDS; each wave streams a 16-row slab of W straight into MFMA
-//                            fragments.  Used for the decoder's small-M (8..64 rows) weight-
-//                            streaming GEMMs where nothing is reused inside a workgroup.
+//  gemm_dma<T,TOut,BM,BN,NS>   LDS-tiled, 4 waves (2x2), operands global -> LDS by DMA into an NS-stage ring,
+//                              one raw barrier per 128-byte K tile, epilogue through LDS.  128x128x2 for the
+//                              big Swin / FPN / K-V projection GEMMs (M = tokens), 64x64 rings for mid sizes.
+//  gemm_rows<T,TOut>           no LDS; each wave streams a 16-row slab of W straight into MFMA
+//                              fragments (decoder GEMMs with <= 64 rows, no LayerNorm prologue).
+//  gemm_small<T,TOut,MF,LN>    split-K over the waves of a workgroup for <= 64 rows with the preceding
+//                              LayerNorm fused into the prologue (decoder steps).
+//  (mlp.hip holds the fused fc1 + GELU + fc2 kernel of the Swin MLP.)
 //
 // Operand orientation: the matrix core computes D[i][j] with i = output feature n (A operand =
 // rows of W) and j = token m (B operand = rows of A).  A lane then owns 4 CONSECUTIVE output
@@ -18,10 +19,9 @@
 
 namespace {
 
-int g_prefetch = 1;      // K tiles of register prefetch in gemm_tiled (1 or 2; 2 measured slower: 160 VGPRs)
 unsigned long long* g_trace = nullptr;   // omp_debug_set_gemm_trace: [capacity][8] s_memtime stamps per workgroup
 long long g_trace_cap = 0;
-int g_force_kernel = 0;  // 0 auto, 1 tiled128, 2 tiled64, 3 rows, 4 small split-K, 5 dma128 (2 stages), 6 dma64 ring, 7/8 dma128 with 3/4 stages, 9 dma 256x256 / 8 waves, 10-12 experimental half-K-stage rings
+int g_force_kernel = 0;  // 0 auto, 3 rows, 4 small split-K, 5 dma 128x128 (2 stages), 6 dma 64x64 ring, 15 = 5 with phase timestamps
 
 struct GemmP {
   const void* A; int64_t lda;
@@ -158,140 +158,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return start + idx;
 }
 
-template <typename T, typename TOut, int BM, int BN, int PF>
-__global__ __launch_bounds__(256) void gemm_tiled(GemmP p) {
-  typedef Mma<T> MM;
-  typedef typename MM::frag frag;
-  constexpr int ROWB = 128;                       // bytes of K per LDS row
-  constexpr int KT = ROWB / (int)sizeof(T);       // k elements per tile
-  constexpr int STEPS = KT / MM::KSTEP;           // 2
-  constexpr int EPC = 16 / (int)sizeof(T);        // elements per 16-byte chunk
-  constexpr int ACH = BM * 8 / 256;               // chunks per thread for the A tile
-  constexpr int WCH = BN * 8 / 256;
-  constexpr int FM = BM / 32, FN = BN / 32;       // frags per wave (wave tile = BM/2 x BN/2)
-
-  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * ROWB];
-  constexpr int BUF = (BM + BN) * ROWB;  // one stage: A tile then W tile
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int lid = xcd_remap(blockIdx.x, nwg);
-  const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
-  const int64_t m0 = (int64_t)tm * BM;
-  const int n0 = tn * BN;
-
-  const T* A = reinterpret_cast<const T*>(p.A);
-  const T* W = reinterpret_cast<const T*>(p.W);
-
-  // per-thread staging coordinates
-  const T* a_src[ACH]; int a_dst[ACH];
-  const T* w_src[WCH]; int w_dst[WCH];
-#pragma unroll
-  for (int i = 0; i < ACH; ++i) {
-    int id = tid + 256 * i, row = id >> 3, c = id & 7;
-    int64_t gm = m0 + row; if (gm > p.M - 1) gm = p.M - 1;
-    a_src[i] = A + gm * p.lda + c * EPC;
-    a_dst[i] = row * ROWB + ((c ^ (row & 7)) << 4);
-  }
-#pragma unroll
-  for (int i = 0; i < WCH; ++i) {
-    int id = tid + 256 * i, row = id >> 3, c = id & 7;
-    int gn = n0 + row; if (gn > p.N - 1) gn = p.N - 1;
-    w_src[i] = W + (int64_t)gn * p.ldw + c * EPC;
-    w_dst[i] = row * ROWB + ((c ^ (row & 7)) << 4);
-  }
-
-  f32x4 acc[FN][FM];
-#pragma unroll
-  for (int i = 0; i < FN; ++i)
-#pragma unroll
-    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // Register prefetch two K tiles ahead (two alternating register sets), LDS double-buffered, ONE barrier
-  // per tile: the global loads of tile t+2 are issued before tile t is computed and are written to LDS only
-  // at the end of iteration t+1, so every load has two compute phases to land (small tiles are otherwise
-  // bound by one memory round trip per K tile).
-  frag ra0[ACH], rw0[WCH], ra1[ACH], rw1[WCH];
-  const int nk = p.K / KT;
-  auto gload = [&](int kt, frag* ra, frag* rw) {
-    const int koff = kt * KT;
-#pragma unroll
-    for (int i = 0; i < ACH; ++i) ra[i] = ld16<T>(a_src[i] + koff);
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) rw[i] = ld16<T>(w_src[i] + koff);
-  };
-  auto lwrite = [&](int buf, const frag* ra, const frag* rw) {
-#pragma unroll
-    for (int i = 0; i < ACH; ++i) *reinterpret_cast<frag*>(smem + buf * BUF + a_dst[i]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) *reinterpret_cast<frag*>(smem + buf * BUF + BM * ROWB + w_dst[i]) = rw[i];
-  };
-  const int lrow = lane & 15, lg = lane >> 4;
-  auto compute = [&](int buf) {
-    const char* as = smem + buf * BUF + (wm * (BM / 2)) * ROWB;
-    const char* ws = smem + buf * BUF + BM * ROWB + (wn * (BN / 2)) * ROWB;
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      frag fw[FN], fx[FM];
-      const int c = s * 4 + lg;
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        int row = i * 16 + lrow;   // (row & 7) == (lrow & 7) because tiles are 16-row aligned
-        fw[i] = *reinterpret_cast<const frag*>(ws + row * ROWB + ((c ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        int row = j * 16 + lrow;
-        fx[j] = *reinterpret_cast<const frag*>(as + row * ROWB + ((c ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) MM::mma(acc[i][j], fw[i], fx[j]);
-    }
-  };
-  if constexpr (PF == 2) {
-    gload(0, ra0, rw0);
-    if (nk > 1) gload(1, ra1, rw1);
-    lwrite(0, ra0, rw0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 2 < nk) gload(kt + 2, ra0, rw0);
-      compute(0);
-      if (kt + 1 < nk) lwrite(1, ra1, rw1);
-      __syncthreads();
-      if (kt + 1 >= nk) break;
-      if (kt + 3 < nk) gload(kt + 3, ra1, rw1);
-      compute(1);
-      if (kt + 2 < nk) lwrite(0, ra0, rw0);
-      __syncthreads();
-    }
-  } else {
-    // one tile ahead (fewer registers -> 2 workgroups per CU for the 128x128 tile)
-    gload(0, ra0, rw0);
-    lwrite(0, ra0, rw0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) gload(kt + 1, ra0, rw0);
-      compute(kt & 1);
-      if (kt + 1 < nk) lwrite((kt + 1) & 1, ra0, rw0);
-      __syncthreads();
-    }
-  }
-
-  const float* bias = p.bias;
-  if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
-#pragma unroll
-  for (int i = 0; i < FN; ++i)
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int n = n0 + wn * (BN / 2) + i * 16 + lg * 4;
-      const int64_t m = m0 + wm * (BM / 2) + j * 16 + lrow;
-      epilogue_store<TOut>(p, bias, m, n, acc[i][j]);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // gemm_dma<T,TOut,BM,BN>: the large-M GEMM (Swin / FPN / projection / K-V slabs).
 //   * operand tiles go global -> LDS by DMA (global_load_lds_dwordx4, no staging registers); the LDS image
@@ -378,6 +244,28 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
                                        (__attribute__((address_space(3))) void*)(wbase + j * 8 * ROWB), 16, 0, 0);
   };
 
+  // this thread's role on the way OUT (epilogue): column chunk cidx of rows rsub, rsub + RPP, ...; its bias
+  // values are requested here, before the first DMA, so they have long arrived when the K loop ends
+  constexpr int CH = 16 / (int)sizeof(TOut);   // output elements per 16-byte chunk
+  constexpr int CPR = BN / CH;                 // chunks per tile row
+  constexpr int RPP = 256 / CPR;               // rows per pass
+  const TOut* res = reinterpret_cast<const TOut*>(p.residual);
+  TOut* C = reinterpret_cast<TOut*>(p.C);
+  const bool vec_ok = p.store_mode == OMP_STORE_PLAIN && !p.trans_out && (p.ldc % CH) == 0 &&
+                      (res == nullptr || (p.ldr % CH) == 0);
+  const int cidx = tid % CPR, rsub = tid / CPR;
+  const int n = n0 + cidx * CH;
+  const bool vec_path = vec_ok && n + CH <= p.N;
+  const float* bias = p.bias;
+  if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
+  // unconditional 16-byte loads (a branch here would make the compiler wait for them on the spot): threads
+  // without a vector-loadable column bias read the first bytes of W instead and discard them
+  const bool bias_vec = bias != nullptr && !p.bias_m && n + CH <= p.N && (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
+  const float* bsrc = bias_vec ? bias + n : reinterpret_cast<const float*>(p.W);
+  f32x4 braw[CH / 4];
+#pragma unroll
+  for (int q = 0; q < CH / 4; ++q) braw[q] = *reinterpret_cast<const f32x4*>(bsrc + 4 * q);
+
   f32x4 acc[FN][FM];
 #pragma unroll
   for (int i = 0; i < FN; ++i)
@@ -432,18 +320,21 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
   }
   stamp(2);                                      // K loop done (this wave)
 
-  // ---- epilogue phase 0: request this thread's residual rows NOW, so that their memory round trip runs under
-  // phase 1 (every DMA has been waited for, so nothing else is outstanding) ---------------------------------
-  constexpr int CH = 16 / (int)sizeof(TOut);   // output elements per 16-byte chunk
-  constexpr int CPR = BN / CH;                 // chunks per tile row
-  constexpr int RPP = 256 / CPR;               // rows per pass
-  const TOut* res = reinterpret_cast<const TOut*>(p.residual);
-  TOut* C = reinterpret_cast<TOut*>(p.C);
-  const bool vec_ok = p.store_mode == OMP_STORE_PLAIN && !p.trans_out && (p.ldc % CH) == 0 &&
-                      (res == nullptr || (p.ldr % CH) == 0);
-  const int cidx = tid % CPR, rsub = tid / CPR;
-  const int n = n0 + cidx * CH;
-  const bool vec_path = vec_ok && n + CH <= p.N;
+  // ---- epilogue ------------------------------------------------------------------------------------------
+  // The accumulators go through LDS RAW; bias, activation and residual are applied on the way out, where a thread
+  // owns one 16-byte column chunk of RPP-strided rows: its CH bias values were requested before the K loop
+  // (round 1 loaded them per fragment between the K loop and the LDS pass -- four serialised memory round trips,
+  // 37 % of a workgroup's life in the stage-2 QKV GEMM, profiles/r02a_gemm_trace.txt), the activation is a
+  // compile-time branch around the whole store loop, and the residual rows are requested before the LDS pass so
+  // that their round trip runs under it.
+  float bcol[CH];
+#pragma unroll
+  for (int q = 0; q < CH; ++q) bcol[q] = bias_vec ? braw[q >> 2][q & 3] : 0.f;
+  if (bias != nullptr && !p.bias_m && !bias_vec) {   // ragged N edge
+#pragma unroll
+    for (int q = 0; q < CH; ++q)
+      if (n + q < p.N) bcol[q] = bias[n + q];
+  }
   typename Vec16<TOut>::type rres[BM / RPP];
   if (vec_path && res != nullptr) {
 #pragma unroll
@@ -453,59 +344,55 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
       rres[pass] = *reinterpret_cast<const typename Vec16<TOut>::type*>(res + m * p.ldr + n);
     }
   }
-
-  // ---- epilogue phase 1: act(acc + bias) -> fp32 rows in LDS ------------------------------------
   __builtin_amdgcn_s_barrier();   // all waves are done with the operand stages
   float* E = reinterpret_cast<float*>(smem);
-  const float* bias = p.bias;
-  if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
 #pragma unroll
   for (int i = 0; i < FN; ++i) {
     const int nl = wn * (BN / 2) + i * 16 + lg * 4;
-    float bn[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias != nullptr && !p.bias_m) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (n0 + nl + r < p.N) bn[r] = bias[n0 + nl + r];
-    }
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
       const int ml = wm * (BM / 2) + j * 16 + lrow;
-      float bm = 0.f;
-      if (bias != nullptr && p.bias_m && m0 + ml < p.M) bm = bias[m0 + ml];
-      f32x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[i][j][r] + bn[r] + bm, p.act);
-      *reinterpret_cast<f32x4*>(E + ml * ES + nl) = o;
+      *reinterpret_cast<f32x4*>(E + ml * ES + nl) = acc[i][j];
     }
   }
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS writes only: the residual loads keep flying
+  __builtin_amdgcn_s_barrier();
   stamp(3);                                      // accumulators of every wave are in LDS
-  // ---- phase 2: row-contiguous 16-byte stores ------------------------------------------------------
   if (n >= p.N) return;
   if (vec_path) {
+    auto store_rows = [&](auto ACT) {
 #pragma unroll
-    for (int pass = 0; pass < BM / RPP; ++pass) {
-      const int r = pass * RPP + rsub;
-      const int64_t m = m0 + r;
-      if (m < p.M) {
-        float v[CH];
+      for (int pass = 0; pass < BM / RPP; ++pass) {
+        const int r = pass * RPP + rsub;
+        const int64_t m = m0 + r;
+        if (m < p.M) {
+          float v[CH];
 #pragma unroll
-        for (int q = 0; q < CH; q += 4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
-          v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
+          for (int q = 0; q < CH; q += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
+            v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
+          }
+#pragma unroll
+          for (int q = 0; q < CH; ++q) {
+            v[q] += bcol[q];
+            if constexpr (decltype(ACT)::value == OMP_ACT_GELU) v[q] = gelu_erf(v[q]);
+            if constexpr (decltype(ACT)::value == OMP_ACT_RELU) v[q] = fmaxf(v[q], 0.0f);
+          }
+          if (res != nullptr) {
+            float rv[CH];
+            unpack16(rres[pass], rv);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) v[q] += rv[q];
+          }
+          typename Vec16<TOut>::type o;
+          pack16(v, o);
+          *reinterpret_cast<typename Vec16<TOut>::type*>(C + m * p.ldc + n) = o;
         }
-        if (res != nullptr) {
-          float rv[CH];
-          unpack16(rres[pass], rv);
-#pragma unroll
-          for (int q = 0; q < CH; ++q) v[q] += rv[q];
-        }
-        typename Vec16<TOut>::type o;
-        pack16(v, o);
-        *reinterpret_cast<typename Vec16<TOut>::type*>(C + m * p.ldc + n) = o;
       }
-    }
+    };
+    if (p.act == OMP_ACT_GELU) store_rows(std::integral_constant<int, OMP_ACT_GELU>());
+    else if (p.act == OMP_ACT_RELU) store_rows(std::integral_constant<int, OMP_ACT_RELU>());
+    else store_rows(std::integral_constant<int, OMP_ACT_NONE>());
     if constexpr (TRACE) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores retired
       stamp(4);
@@ -522,7 +409,11 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
       const int pass = it / (CH / 4), q = (it % (CH / 4)) * 4;
       const int r = pass * RPP + rsub;
       const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
-      const float v[4] = {t[0], t[1], t[2], t[3]};
+      float bm = 0.f;
+      if (bias != nullptr && p.bias_m && m0 + r < p.M) bm = bias[m0 + r];
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = apply_act(t[u] + bcol[q + u] + bm, p.act);
       store4<TOut>(p, m0 + r, n + q, v);
     }
   }
@@ -547,726 +438,6 @@ int launch_dma(GemmP& p, hipStream_t st) {
   return OMP_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// gemm_dmap<T,TOut>  -- EXPERIMENTAL persistent form of gemm_dma<128,128,2> (selector 14; written at the end of
-// round 1 from the measurement that at K = 128..1024 more than half of a tile's time is prologue + epilogue.
-// Measured: parity-green, 15-60 % slower than gemm_dma (profiles/r01u_kbench_gemm_persistent.txt) -- kept as the
-// base for round 2, excluded from the default parity run, OMP355_EXPERIMENTAL_GEMM=14 adds it).
-//   * the grid is at most 2 workgroups per CU; a workgroup walks its XCD's contiguous chunk of the tile list with
-//     the stride of the workgroups on that XCD, so co-running workgroups share A rows in L2 exactly as before;
-//   * K tiles alternate between the two 32 KB stages and K / 64 is even, so when a tile's main loop ends its last
-//     K tile sits in stage 1 and stage 0 is free (the barrier of the last iteration proved everybody done with it):
-//     the NEXT tile's first K tile is requested into stage 0 BEFORE the epilogue starts -- its DMA round trip, the
-//     exposed prologue of the one-tile kernel, runs under the epilogue;
-//   * the epilogue goes through stage 1 only, in four chunks of 32 rows (16.9 KB each), residual rows requested
-//     up front as in gemm_dma.  LDS stays 64 KB: two workgroups per CU.
-// ---------------------------------------------------------------------------------------------
-template <typename T, typename TOut>
-__global__ __launch_bounds__(256, 2) void gemm_dmap(GemmP p) {   // 2 waves per SIMD: two workgroups per CU
-  typedef Mma<T> MM;
-  typedef typename MM::frag frag;
-  constexpr int BM = 128, BN = 128;
-  constexpr int ROWB = 128;
-  constexpr int KT = ROWB / (int)sizeof(T);
-  constexpr int STEPS = KT / MM::KSTEP;
-  constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int FM = 4, FN = 4;
-  constexpr int AI = 4, WI = 4;
-  constexpr int STAGE = (BM + BN) * ROWB;         // 32 KB
-  constexpr int ES = BN + 4;
-  constexpr int EC = 32;                          // epilogue chunk rows: 32 * 132 * 4 B = 16.9 KB, inside stage 1
-  static_assert(EC * ES * 4 <= STAGE, "an epilogue chunk fits one stage");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lr = lane >> 3, lc = (lane & 7) ^ lr;
-  const int lrow = lane & 15, lg = lane >> 4;
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int nk = p.K / KT;                        // even (checked by the launcher)
-
-  // this workgroup's tiles: XCD x = blockIdx % 8 owns the contiguous logical tiles [start, start + cnt) (the
-  // partition of xcd_remap); its workgroups (slot = blockIdx / 8) take them with stride gridDim / 8
-  const int G = gridDim.x;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int q8 = nwg >> 3, r8 = nwg & 7;
-  const int start = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  const int cnt = q8 + (xcd < r8 ? 1 : 0);
-  const int per = (G >> 3) + ((xcd < (G & 7)) ? 1 : 0);   // workgroups of this launch that sit on this XCD
-
-  const T* a_src[AI];
-  const T* w_src[WI];
-  int64_t m0 = 0;
-  int n0 = 0;
-  auto set_tile = [&](int lid) {
-    const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
-    m0 = (int64_t)tm * BM;
-    n0 = tn * BN;
-#pragma unroll
-    for (int j = 0; j < AI; ++j) {
-      int64_t gm = m0 + wave * (BM / 4) + j * 8 + lr; if (gm > p.M - 1) gm = p.M - 1;
-      a_src[j] = reinterpret_cast<const T*>(p.A) + gm * p.lda + lc * EPC;
-    }
-#pragma unroll
-    for (int j = 0; j < WI; ++j) {
-      int gn = n0 + wave * (BN / 4) + j * 8 + lr; if (gn > p.N - 1) gn = p.N - 1;
-      w_src[j] = reinterpret_cast<const T*>(p.W) + (int64_t)gn * p.ldw + lc * EPC;
-    }
-  };
-  auto issue = [&](int kt, int buf) {
-    const int koff = kt * KT;
-    char* abase = smem + buf * STAGE + (wave * (BM / 4)) * ROWB;
-    char* wbase = smem + buf * STAGE + BM * ROWB + (wave * (BN / 4)) * ROWB;
-#pragma unroll
-    for (int j = 0; j < AI; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
-                                       (__attribute__((address_space(3))) void*)(abase + j * 8 * ROWB), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < WI; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + koff),
-                                       (__attribute__((address_space(3))) void*)(wbase + j * 8 * ROWB), 16, 0, 0);
-  };
-
-  f32x4 acc[FN][FM];
-  auto compute = [&](int buf) {
-    const char* as = smem + buf * STAGE + (wm * (BM / 2)) * ROWB;
-    const char* ws = smem + buf * STAGE + BM * ROWB + (wn * (BN / 2)) * ROWB;
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      frag fw[FN], fx[FM];
-      const int c = s * 4 + lg;
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int row = i * 16 + lrow;
-        fw[i] = *reinterpret_cast<const frag*>(ws + row * ROWB + ((c ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int row = j * 16 + lrow;
-        fx[j] = *reinterpret_cast<const frag*>(as + row * ROWB + ((c ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) MM::mma(acc[i][j], fw[i], fx[j]);
-    }
-  };
-
-  constexpr int CH = 16 / (int)sizeof(TOut);
-  constexpr int CPR = BN / CH;
-  constexpr int RPP = 256 / CPR;
-  constexpr int PPC = EC / RPP;                 // store passes per chunk
-  static_assert(EC % RPP == 0, "store passes tile a chunk");
-  const TOut* res = reinterpret_cast<const TOut*>(p.residual);
-  TOut* C = reinterpret_cast<TOut*>(p.C);
-  const bool vec_ok = p.store_mode == OMP_STORE_PLAIN && !p.trans_out && (p.ldc % CH) == 0 &&
-                      (res == nullptr || (p.ldr % CH) == 0);
-  const int cidx = tid % CPR, rsub = tid / CPR;
-  const float* bias = p.bias;
-  if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
-  float* E = reinterpret_cast<float*>(smem + STAGE);   // stage 1
-
-  int idx = slot;
-  if (idx >= cnt) return;                       // whole workgroup: more workgroups than tiles on this XCD
-  set_tile(start + idx);
-  issue(0, 0);
-  while (true) {
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-      compute(kt & 1);
-    }
-    // this tile's output coordinates, then re-aim the DMA pointers at the next tile and request its first K tile
-    const int64_t em0 = m0;
-    const int en0 = n0;
-    const int nxt = idx + per;
-    const bool more = nxt < cnt;
-    if (more) {
-      set_tile(start + nxt);
-      issue(0, 0);                               // stage 0 is free: see the header comment
-    }
-    const int n = en0 + cidx * CH;
-    const bool vec_path = vec_ok && n + CH <= p.N;
-    typename Vec16<TOut>::type rres[BM / RPP];
-    if (vec_path && res != nullptr) {
-#pragma unroll
-      for (int pass = 0; pass < BM / RPP; ++pass) {
-        int64_t m = em0 + pass * RPP + rsub;
-        if (m > p.M - 1) m = p.M - 1;
-        rres[pass] = *reinterpret_cast<const typename Vec16<TOut>::type*>(res + m * p.ldr + n);
-      }
-    }
-#pragma unroll
-    for (int chunk = 0; chunk < BM / EC; ++chunk) {
-      // raw barrier + LDS-only wait: __syncthreads() would also drain the next tile's DMA (vmcnt(0)) right here
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // chunk 0: everybody is done with stage 1; later: the previous chunk has been stored
-      if (wm == (chunk >> 1)) {
-#pragma unroll
-        for (int i = 0; i < FN; ++i) {
-          const int nl = wn * (BN / 2) + i * 16 + lg * 4;
-          float bn[4] = {0.f, 0.f, 0.f, 0.f};
-          if (bias != nullptr && !p.bias_m) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (en0 + nl + r < p.N) bn[r] = bias[en0 + nl + r];
-          }
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const int j = (chunk & 1) * 2 + jj;
-            const int ml = jj * 16 + lrow;
-            const int64_t mg = em0 + chunk * EC + ml;
-            float bm = 0.f;
-            if (bias != nullptr && p.bias_m && mg < p.M) bm = bias[mg];
-            f32x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[i][j][r] + bn[r] + bm, p.act);
-            *reinterpret_cast<f32x4*>(E + ml * ES + nl) = o;
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's rows of the chunk are in LDS
-      __builtin_amdgcn_s_barrier();
-      if (n < p.N) {
-        if (vec_path) {
-#pragma unroll
-          for (int pass = 0; pass < PPC; ++pass) {
-            const int r = pass * RPP + rsub;
-            const int64_t m = em0 + chunk * EC + r;
-            if (m < p.M) {
-              float v[CH];
-#pragma unroll
-              for (int q = 0; q < CH; q += 4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
-                v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
-              }
-              if (res != nullptr) {
-                float rv[CH];
-                unpack16(rres[chunk * PPC + pass], rv);
-#pragma unroll
-                for (int q = 0; q < CH; ++q) v[q] += rv[q];
-              }
-              typename Vec16<TOut>::type o;
-              pack16(v, o);
-              *reinterpret_cast<typename Vec16<TOut>::type*>(C + m * p.ldc + n) = o;
-            }
-          }
-        } else {
-#pragma unroll 1
-          for (int it = 0; it < PPC * (CH / 4); ++it) {
-            const int pass = it / (CH / 4), q = (it % (CH / 4)) * 4;
-            const int r = pass * RPP + rsub;
-            const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
-            const float v[4] = {t[0], t[1], t[2], t[3]};
-            store4<TOut>(p, em0 + chunk * EC + r, n + q, v);
-          }
-        }
-      }
-    }
-    if (!more) break;
-    idx = nxt;
-    // the next main loop's first barrier orders this epilogue's last reads of stage 1 before its refill
-  }
-}
-
-template <typename T, typename TOut>
-int launch_dmap(GemmP& p, hipStream_t st) {
-  constexpr int KT = 128 / (int)sizeof(T);
-  if ((p.K / KT) % 2 != 0) {
-    omp_set_error("omp_gemm_bias_act: the persistent kernel needs an even number of K tiles (K = %d)", p.K);
-    return OMP_ERR_UNSUPPORTED;
-  }
-  constexpr size_t smem = 2 * (128 + 128) * 128;   // 64 KB
-  auto kern = gemm_dmap<T, TOut>;
-  static bool done = false;   // per template instantiation
-  if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      omp_set_error("omp_gemm_bias_act: cannot raise dynamic LDS limit");
-      return OMP_ERR_LAUNCH;
-    }
-    done = true;
-  }
-  p.tiles_m = (int)ceil_div64(p.M, 128); p.tiles_n = (int)ceil_div64(p.N, 128);
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int grid = nwg < 512 ? nwg : 512;          // two workgroups per CU
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p);
-  return OMP_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// gemm_dma8<T,TOut>: 256x256 tile, 8 waves (2 along M x 4 along N, wave tile 128 x 64 = 32 accumulator
-// fragments), same DMA staging / swizzle / one-barrier-per-K-tile ring as gemm_dma with 2 stages of 64 KB.
-// Per 32-deep k-step a wave issues 12 ds_read_b128 for 32 MFMAs (gemm_dma's 2x2 waves: 8 for 16), and a
-// workgroup moves half the operand bytes per flop through L2/LDS.  The 256x256 fp32 tile does not fit in LDS
-// at once, so the epilogue runs in four 64-row chunks through the (then idle) operand stages.
-// Used for the large-M GEMMs whose N is a multiple of 256 (Swin stages 1-3, K/V projection, ViT-B).
-// ---------------------------------------------------------------------------------------------
-template <typename T, typename TOut, bool PIPE>
-__global__ __launch_bounds__(512) void gemm_dma8(GemmP p) {
-  typedef Mma<T> MM;
-  typedef typename MM::frag frag;
-  constexpr int BM = 256, BN = 256;   // two LDS stages
-  constexpr int ROWB = 128;
-  constexpr int KT = ROWB / (int)sizeof(T);
-  constexpr int STEPS = KT / MM::KSTEP;
-  constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int FM = 8, FN = 4;                   // wave tile 128 (m) x 64 (n)
-  constexpr int AI = 4, WI = 4;                   // 32 rows of A and of W per wave per K tile
-  constexpr int STAGE = (BM + BN) * ROWB;         // 64 KB
-  constexpr int ES = BN + 4;
-  constexpr int EC = 64;                          // epilogue chunk rows: 64 * 260 * 4 B = 65 KB <= 2 * STAGE
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int lid = xcd_remap(blockIdx.x, nwg);
-  const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
-  const int64_t m0 = (int64_t)tm * BM;
-  const int n0 = tn * BN;
-
-  const int lr = lane >> 3, lc = (lane & 7) ^ lr;
-  const T* a_src[AI];
-  const T* w_src[WI];
-#pragma unroll
-  for (int j = 0; j < AI; ++j) {
-    int64_t gm = m0 + wave * 32 + j * 8 + lr; if (gm > p.M - 1) gm = p.M - 1;
-    a_src[j] = reinterpret_cast<const T*>(p.A) + gm * p.lda + lc * EPC;
-  }
-#pragma unroll
-  for (int j = 0; j < WI; ++j) {
-    int gn = n0 + wave * 32 + j * 8 + lr; if (gn > p.N - 1) gn = p.N - 1;
-    w_src[j] = reinterpret_cast<const T*>(p.W) + (int64_t)gn * p.ldw + lc * EPC;
-  }
-  auto issue = [&](int kt, int buf) {
-    const int koff = kt * KT;
-    char* abase = smem + buf * STAGE + (wave * 32) * ROWB;
-    char* wbase = smem + buf * STAGE + BM * ROWB + (wave * 32) * ROWB;
-#pragma unroll
-    for (int j = 0; j < AI; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
-                                       (__attribute__((address_space(3))) void*)(abase + j * 8 * ROWB), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < WI; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + koff),
-                                       (__attribute__((address_space(3))) void*)(wbase + j * 8 * ROWB), 16, 0, 0);
-  };
-
-  f32x4 acc[FN][FM];
-#pragma unroll
-  for (int i = 0; i < FN; ++i)
-#pragma unroll
-    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int lrow = lane & 15, lg = lane >> 4;
-  auto compute = [&](int buf) {
-    const char* as = smem + buf * STAGE + (wm * 128) * ROWB;
-    const char* ws = smem + buf * STAGE + BM * ROWB + (wn * 64) * ROWB;
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      frag fw[FN], fx[FM];
-      const int c = s * 4 + lg;
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int row = i * 16 + lrow;
-        fw[i] = *reinterpret_cast<const frag*>(ws + row * ROWB + ((c ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int row = j * 16 + lrow;
-        fx[j] = *reinterpret_cast<const frag*>(as + row * ROWB + ((c ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) MM::mma(acc[i][j], fw[i], fx[j]);
-    }
-  };
-
-  const int nk = p.K / KT;
-  if constexpr (!PIPE) {
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-      compute(kt & 1);
-    }
-  } else {
-    // Software-pipelined variant (EXPERIMENTAL, selector 13): the fragments of the NEXT k-step are loaded from LDS
-    // while the MFMAs of the current one run, and the single barrier per K tile sits in the MIDDLE of the tile:
-    //   F1 <- (tile kt, step 1) | MFMA(F0) | wait own DMA of tile kt+1, own LDS reads; barrier
-    //   DMA tile kt+2 -> the stage just read | F0 <- (tile kt+1, step 0) | MFMA(F1)
-    // so no wave ever stands between a barrier and its first MFMA waiting for ds_reads.  The barrier still orders
-    // both hazards: every wave's reads of the current stage have returned (lgkmcnt(0)) before it is refilled, and
-    // every wave's part of the next tile has landed (vmcnt(0)) before anybody reads it.
-    static_assert(STEPS == 2, "two k-steps per K tile");
-    auto load_frags = [&](int buf, int s, frag* fw, frag* fx) {
-      const char* as = smem + buf * STAGE + (wm * 128) * ROWB;
-      const char* ws = smem + buf * STAGE + BM * ROWB + (wn * 64) * ROWB;
-      const int c = s * 4 + lg;
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int row = i * 16 + lrow;
-        fw[i] = *reinterpret_cast<const frag*>(ws + row * ROWB + ((c ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int row = j * 16 + lrow;
-        fx[j] = *reinterpret_cast<const frag*>(as + row * ROWB + ((c ^ (row & 7)) << 4));
-      }
-    };
-    auto mfmas = [&](const frag* fw, const frag* fx) {
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) MM::mma(acc[i][j], fw[i], fx[j]);
-    };
-    frag fw0[FN], fx0[FM], fw1[FN], fx1[FM];
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (nk > 1) issue(1, 1);
-    load_frags(0, 0, fw0, fx0);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      // sched_barrier(0) pins the order: the compiler otherwise sinks the register-only MFMAs below the wait and the
-      // barrier, which puts the ds_read latency back on the critical path
-      // F0 was requested before the previous 32 MFMAs: it has landed; the explicit wait (asm = never dropped, builtin
-      // = visible to the compiler's counter model) lets the compiler issue MFMA(F0) without a conservative
-      // lgkmcnt(0) AFTER the F1 loads, which would expose their latency
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_sched_barrier(0);
-      load_frags(cur, 1, fw1, fx1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(fw0, fx0);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 2 < nk) issue(kt + 2, cur);
-      if (kt + 1 < nk) load_frags(cur ^ 1, 0, fw0, fx0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(fw1, fx1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-
-  // ---- epilogue in four 64-row chunks: act(acc + bias) -> fp32 rows in LDS -> row-contiguous 16-byte stores ----
-  float* E = reinterpret_cast<float*>(smem);
-  const float* bias = p.bias;
-  if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
-  constexpr int CH = 16 / (int)sizeof(TOut);
-  constexpr int CPR = BN / CH;                 // 32 (bf16 out) / 64 (f32 out) chunks per tile row
-  constexpr int RPP = 512 / CPR;               // rows per pass
-  const TOut* res = reinterpret_cast<const TOut*>(p.residual);
-  TOut* C = reinterpret_cast<TOut*>(p.C);
-  const bool vec_ok = p.store_mode == OMP_STORE_PLAIN && !p.trans_out && (p.ldc % CH) == 0 &&
-                      (res == nullptr || (p.ldr % CH) == 0);
-  const int cidx = tid % CPR, rsub = tid / CPR;
-  const int n = n0 + cidx * CH;
-#pragma unroll
-  for (int chunk = 0; chunk < BM / EC; ++chunk) {
-    __syncthreads();   // chunk 0: everybody is done with the operand stages; later: with the previous chunk's rows
-    if (wm == (chunk >> 1)) {
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int nl = wn * 64 + i * 16 + lg * 4;
-        float bn[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias != nullptr && !p.bias_m) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n0 + nl + r < p.N) bn[r] = bias[n0 + nl + r];
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int j = (chunk & 1) * 4 + jj;
-          const int ml = jj * 16 + lrow;                       // row inside the chunk
-          const int64_t mg = m0 + chunk * EC + ml;
-          float bm = 0.f;
-          if (bias != nullptr && p.bias_m && mg < p.M) bm = bias[mg];
-          f32x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[i][j][r] + bn[r] + bm, p.act);
-          *reinterpret_cast<f32x4*>(E + ml * ES + nl) = o;
-        }
-      }
-    }
-    __syncthreads();
-    if (n < p.N) {
-      if (vec_ok && n + CH <= p.N) {
-#pragma unroll 4
-        for (int pass = 0; pass < EC / RPP; ++pass) {
-          const int r = pass * RPP + rsub;
-          const int64_t m = m0 + chunk * EC + r;
-          if (m < p.M) {
-            float v[CH];
-#pragma unroll
-            for (int q = 0; q < CH; q += 4) {
-              const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
-              v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
-            }
-            if (res != nullptr) {
-              float rv[CH];
-              unpack16(*reinterpret_cast<const typename Vec16<TOut>::type*>(res + m * p.ldr + n), rv);
-#pragma unroll
-              for (int q = 0; q < CH; ++q) v[q] += rv[q];
-            }
-            typename Vec16<TOut>::type o;
-            pack16(v, o);
-            *reinterpret_cast<typename Vec16<TOut>::type*>(C + m * p.ldc + n) = o;
-          }
-        }
-      } else {
-#pragma unroll 1
-        for (int it = 0; it < (EC / RPP) * (CH / 4); ++it) {
-          const int pass = it / (CH / 4), q = (it % (CH / 4)) * 4;
-          const int r = pass * RPP + rsub;
-          const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
-          const float v[4] = {t[0], t[1], t[2], t[3]};
-          store4<TOut>(p, m0 + chunk * EC + r, n + q, v);
-        }
-      }
-    }
-  }
-}
-
-template <typename T, typename TOut, bool PIPE>
-int launch_dma8(GemmP& p, hipStream_t st) {
-  constexpr size_t smem = 2 * (256 + 256) * 128;   // 128 KB: two operand stages (the epilogue chunks reuse them)
-  auto kern = gemm_dma8<T, TOut, PIPE>;
-  static bool done = false;   // per template instantiation
-  if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      omp_set_error("omp_gemm_bias_act: cannot raise dynamic LDS limit");
-      return OMP_ERR_LAUNCH;
-    }
-    done = true;
-  }
-  p.tiles_m = (int)ceil_div64(p.M, 256); p.tiles_n = (int)ceil_div64(p.N, 256);
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
-  return OMP_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// gemm_dmah<T,TOut,BM,BN,NWM,NWN,NS>  -- EXPERIMENTAL (reachable only through omp_debug_force_gemm_kernel(10|11|12),
-// not selected automatically, excluded from the default parity run; measured parity-green and slower than gemm_dma,
-// profiles/r01r_kbench_gemm_halfk_rings.txt).
-//
-// Diagnosis behind it (DESIGN.md "GEMM diagnosis"): with 64-deep K tiles and a 2-stage ring the DMA round trip
-// (~1 us) is exposed on every K tile; the fix is more bytes in flight per CU, i.e. a deeper ring of SMALLER
-// stages.  Here a stage is a HALF K tile (64-byte rows = 32 bf16 / 16 f32 k-elements = one MFMA k-step) and the
-// ring has NS = 4 of them: 3 stages (1.5 K tiles) stay in flight across every barrier, counted with
-// s_waitcnt vmcnt(N).  256x256 tile, 8 waves (2 x 4): stage 32 KB, ring 128 KB, 32 MFMAs per wave per barrier.
-// LDS image: rows of 64 bytes = 4 slots of 16 bytes.  A DMA instruction fills 16 rows lane-linearly (lane l ->
-// row l >> 2, slot l & 3); the fragment ds_read_b128 of a 16-row tile (lane = row + 16 * kchunk) is conflict-free
-// with slot = kchunk ^ F[(row >> 2) & 3], F = {0, 3, 2, 1}: within each of the instruction's four 16-lane service
-// groups the four lanes that share a bank quarter (row & 3) then hit four different slots.  As everywhere, the
-// swizzle is applied to the per-lane SOURCE address of the DMA.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int swz64(int kchunk, int row) { return kchunk ^ ((4 - ((row >> 2) & 3)) & 3); }
-
-template <typename T, typename TOut, int BM, int BN, int NWM, int NWN, int NS>
-__global__ __launch_bounds__(64 * NWM * NWN) void gemm_dmah(GemmP p) {
-  typedef Mma<T> MM;
-  typedef typename MM::frag frag;
-  constexpr int NW = NWM * NWN, NT = 64 * NW;
-  constexpr int ROWB = 64;                          // bytes of K per LDS row = one MFMA k-step
-  constexpr int KT = ROWB / (int)sizeof(T);         // 32 (bf16) / 16 (f32) == MM::KSTEP
-  static_assert(KT == MM::KSTEP, "a stage is exactly one k-step");
-  constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int WTM = BM / NWM, WTN = BN / NWN;     // wave tile
-  constexpr int FM = WTM / 16, FN = WTN / 16;
-  constexpr int AI = BM / NW / 16, WI = BN / NW / 16;   // DMA instructions per wave per stage (16 rows each)
-  static_assert(AI >= 1 && WI >= 1 && (BM / NW) % 16 == 0 && (BN / NW) % 16 == 0, "16-row DMA pieces");
-  constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int ES = BN + 4;
-  constexpr int EC = 64;                            // epilogue chunk rows: a chunk lies inside ONE wave row
-  static_assert(EC * ES * 4 <= NS * STAGE && WTM % EC == 0 && BM % EC == 0, "epilogue chunk fits the ring and divides the wave tile");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / NWN, wn = wave % NWN;
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int lid = xcd_remap(blockIdx.x, nwg);
-  const int tm = lid / p.tiles_n, tn = lid % p.tiles_n;
-  const int64_t m0 = (int64_t)tm * BM;
-  const int n0 = tn * BN;
-
-  // DMA: lane l fills slot (l & 3) of row (l >> 2) of a 16-row piece with source chunk (l & 3) ^ F[l >> 4]
-  const int pr = lane >> 2, pc = swz64(lane & 3, pr);
-  const T* a_src[AI];
-  const T* w_src[WI];
-#pragma unroll
-  for (int j = 0; j < AI; ++j) {
-    int64_t gm = m0 + wave * (BM / NW) + j * 16 + pr; if (gm > p.M - 1) gm = p.M - 1;
-    a_src[j] = reinterpret_cast<const T*>(p.A) + gm * p.lda + pc * EPC;
-  }
-#pragma unroll
-  for (int j = 0; j < WI; ++j) {
-    int gn = n0 + wave * (BN / NW) + j * 16 + pr; if (gn > p.N - 1) gn = p.N - 1;
-    w_src[j] = reinterpret_cast<const T*>(p.W) + (int64_t)gn * p.ldw + pc * EPC;
-  }
-  auto issue = [&](int kt, int buf) {
-    const int koff = kt * KT;
-    char* abase = smem + buf * STAGE + (wave * (BM / NW)) * ROWB;
-    char* wbase = smem + buf * STAGE + BM * ROWB + (wave * (BN / NW)) * ROWB;
-#pragma unroll
-    for (int j = 0; j < AI; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
-                                       (__attribute__((address_space(3))) void*)(abase + j * 16 * ROWB), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < WI; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[j] + koff),
-                                       (__attribute__((address_space(3))) void*)(wbase + j * 16 * ROWB), 16, 0, 0);
-  };
-
-  f32x4 acc[FN][FM];
-#pragma unroll
-  for (int i = 0; i < FN; ++i)
-#pragma unroll
-    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int lrow = lane & 15, lg = lane >> 4;
-  const int foff = lrow * ROWB + (swz64(lg, lrow) << 4);   // fragment tiles are 16-row aligned: (row >> 2) & 3 == (lrow >> 2)
-  auto compute = [&](int buf) {
-    const char* as = smem + buf * STAGE + (wm * WTM) * ROWB + foff;
-    const char* ws = smem + buf * STAGE + BM * ROWB + (wn * WTN) * ROWB + foff;
-    frag fw[FN], fx[FM];
-#pragma unroll
-    for (int i = 0; i < FN; ++i) fw[i] = *reinterpret_cast<const frag*>(ws + i * 16 * ROWB);
-#pragma unroll
-    for (int j = 0; j < FM; ++j) fx[j] = *reinterpret_cast<const frag*>(as + j * 16 * ROWB);
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int j = 0; j < FM; ++j) MM::mma(acc[i][j], fw[i], fx[j]);
-  };
-
-  // ring of NS half-tile stages, protocol of gemm_dma: prologue fills NS-1 stages; iteration kt waits for ITS stage
-  // only (min(nk-1-kt, NS-2) newer stages stay in flight), one barrier, refill of the stage read in iteration kt-1
-  const int nk = p.K / KT;
-#pragma unroll
-  for (int t = 0; t < NS - 1; ++t)
-    if (t < nk) issue(t, t);
-  int st_c = 0, st_i = NS - 1;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int after = nk - 1 - kt;
-    wait_dma_tiles<AI + WI>(after < NS - 2 ? after : NS - 2);
-    __builtin_amdgcn_s_barrier();
-    if (kt + NS - 1 < nk) issue(kt + NS - 1, st_i);
-    compute(st_c);
-    st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
-    st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
-  }
-
-  // ---- epilogue in EC-row chunks through the (then idle) ring: act(acc + bias) -> fp32 rows -> 16-byte stores ----
-  float* E = reinterpret_cast<float*>(smem);
-  const float* bias = p.bias;
-  if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
-  constexpr int CH = 16 / (int)sizeof(TOut);
-  constexpr int CPR = BN / CH;
-  constexpr int RPP = NT / CPR;
-  static_assert(NT % CPR == 0 && EC % RPP == 0, "store passes tile the chunk");
-  constexpr int JPC = EC / 16;                  // m-fragments per chunk (a chunk lies inside one wave row: WTM % EC == 0)
-  const TOut* res = reinterpret_cast<const TOut*>(p.residual);
-  TOut* C = reinterpret_cast<TOut*>(p.C);
-  const bool vec_ok = p.store_mode == OMP_STORE_PLAIN && !p.trans_out && (p.ldc % CH) == 0 &&
-                      (res == nullptr || (p.ldr % CH) == 0);
-  const int cidx = tid % CPR, rsub = tid / CPR;
-  const int n = n0 + cidx * CH;
-#pragma unroll
-  for (int chunk = 0; chunk < BM / EC; ++chunk) {
-    __syncthreads();   // chunk 0: the last stage has been consumed by everybody; later: the previous chunk has been stored
-    if (wm == (chunk * EC) / WTM) {
-      const int j0 = ((chunk * EC) % WTM) / 16;
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int nl = wn * WTN + i * 16 + lg * 4;
-        float bn[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias != nullptr && !p.bias_m) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n0 + nl + r < p.N) bn[r] = bias[n0 + nl + r];
-        }
-#pragma unroll
-        for (int jj = 0; jj < JPC; ++jj) {
-          const int ml = jj * 16 + lrow;
-          const int64_t mg = m0 + chunk * EC + ml;
-          float bm = 0.f;
-          if (bias != nullptr && p.bias_m && mg < p.M) bm = bias[mg];
-          f32x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[i][j0 + jj][r] + bn[r] + bm, p.act);
-          *reinterpret_cast<f32x4*>(E + ml * ES + nl) = o;
-        }
-      }
-    }
-    __syncthreads();
-    if (n < p.N) {
-      if (vec_ok && n + CH <= p.N) {
-#pragma unroll 4
-        for (int pass = 0; pass < EC / RPP; ++pass) {
-          const int r = pass * RPP + rsub;
-          const int64_t m = m0 + chunk * EC + r;
-          if (m < p.M) {
-            float v[CH];
-#pragma unroll
-            for (int q = 0; q < CH; q += 4) {
-              const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
-              v[q] = t[0]; v[q + 1] = t[1]; v[q + 2] = t[2]; v[q + 3] = t[3];
-            }
-            if (res != nullptr) {
-              float rv[CH];
-              unpack16(*reinterpret_cast<const typename Vec16<TOut>::type*>(res + m * p.ldr + n), rv);
-#pragma unroll
-              for (int q = 0; q < CH; ++q) v[q] += rv[q];
-            }
-            typename Vec16<TOut>::type o;
-            pack16(v, o);
-            *reinterpret_cast<typename Vec16<TOut>::type*>(C + m * p.ldc + n) = o;
-          }
-        }
-      } else {
-#pragma unroll 1
-        for (int it = 0; it < (EC / RPP) * (CH / 4); ++it) {
-          const int pass = it / (CH / 4), q = (it % (CH / 4)) * 4;
-          const int r = pass * RPP + rsub;
-          const f32x4 t = *reinterpret_cast<const f32x4*>(E + r * ES + cidx * CH + q);
-          const float v[4] = {t[0], t[1], t[2], t[3]};
-          store4<TOut>(p, m0 + chunk * EC + r, n + q, v);
-        }
-      }
-    }
-  }
-}
-
-template <typename T, typename TOut, int BM, int BN, int NWM, int NWN, int NS>
-int launch_dmah(GemmP& p, hipStream_t st) {
-  constexpr size_t smem = (size_t)NS * (BM + BN) * 64;
-  auto kern = gemm_dmah<T, TOut, BM, BN, NWM, NWN, NS>;
-  static bool done = false;   // per template instantiation
-  if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      omp_set_error("omp_gemm_bias_act: cannot raise dynamic LDS limit");
-      return OMP_ERR_LAUNCH;
-    }
-    done = true;
-  }
-  p.tiles_m = (int)ceil_div64(p.M, BM); p.tiles_n = (int)ceil_div64(p.N, BN);
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * NWM * NWN), smem, st, p);
-  return OMP_OK;
-}
-
-// Small-M path: grid (ceil(N/64), ceil(M/16)), 4 waves, wave w owns output features
-// [bx*64 + 16w, +16) for tokens [by*16, +16).  No LDS, fragments come straight from global.
 template <typename T, typename TOut>
 __global__ __launch_bounds__(256) void gemm_rows(GemmP p) {
   typedef Mma<T> MM;
@@ -1511,9 +682,6 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
     int rc = (ceil_div64(p.M, 64) * ceil_div64(p.N, 64) <= 512) ? launch_dma<T, TOut, 64, 64, 8>(p, st)
                                                                  : launch_dma<T, TOut, 64, 64, 4>(p, st);
     if (rc != OMP_OK) return rc;
-  } else if (which == 9) {
-    int rc = launch_dma8<T, TOut, false>(p, st);
-    if (rc != OMP_OK) return rc;
   } else if (which == 15) {          // development: gemm_dma<128,128,2> with per-workgroup phase timestamps
     p.tiles_m = (int)ceil_div64(p.M, 128); p.tiles_n = (int)ceil_div64(p.N, 128);
     if (g_trace == nullptr || (long long)p.tiles_m * p.tiles_n > g_trace_cap) {
@@ -1523,49 +691,18 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
     p.trace = g_trace;
     int rc = launch_dma<T, TOut, 128, 128, 2, true>(p, st);
     if (rc != OMP_OK) return rc;
-  } else if (which == 14) {          // experimental: persistent 128x128 (next tile's first K tile requested before the epilogue)
-    int rc = launch_dmap<T, TOut>(p, st);
-    if (rc != OMP_OK) return rc;
-  } else if (which == 13) {          // experimental: 256x256 / 8 waves with register-pipelined fragments, mid-tile barrier
-    int rc = launch_dma8<T, TOut, true>(p, st);
-    if (rc != OMP_OK) return rc;
-  } else if (which == 10) {          // experimental: 256x256, 8 waves, 4 half-K stages (128 KB)
-    int rc = launch_dmah<T, TOut, 256, 256, 2, 4, 4>(p, st);
-    if (rc != OMP_OK) return rc;
-  } else if (which == 11) {          // experimental: 128x128, 4 waves, 4 half-K stages (64 KB, two workgroups per CU)
-    int rc = launch_dmah<T, TOut, 128, 128, 2, 2, 4>(p, st);
-    if (rc != OMP_OK) return rc;
-  } else if (which == 12) {          // experimental: 256x128, 8 waves (4 x 2), 6 half-K stages (144 KB)
-    int rc = launch_dmah<T, TOut, 256, 128, 4, 2, 6>(p, st);
-    if (rc != OMP_OK) return rc;
-  } else if (which == 7) {
-    int rc = launch_dma<T, TOut, 128, 128, 3>(p, st);
-    if (rc != OMP_OK) return rc;
-  } else if (which == 8) {
-    int rc = launch_dma<T, TOut, 128, 128, 4>(p, st);
-    if (rc != OMP_OK) return rc;
   } else if (which == 3) {
     dim3 grid((unsigned)ceil_div64(p.N, 64), (unsigned)ceil_div64(p.M, 16));
     hipLaunchKernelGGL((gemm_rows<T, TOut>), grid, dim3(256), 0, st, p);
-  } else if (which == 2) {
-    p.tiles_m = (int)ceil_div64(p.M, 64); p.tiles_n = (int)ceil_div64(p.N, 64);
-    if (g_prefetch == 2) hipLaunchKernelGGL((gemm_tiled<T, TOut, 64, 64, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_tiled<T, TOut, 64, 64, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
   } else {
-    p.tiles_m = (int)ceil_div64(p.M, 128); p.tiles_n = (int)ceil_div64(p.N, 128);
-    if (g_prefetch == 2) hipLaunchKernelGGL((gemm_tiled<T, TOut, 128, 128, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_tiled<T, TOut, 128, 128, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    omp_set_error("omp_gemm_bias_act: unknown kernel selector %d", which);
+    return OMP_ERR_INVALID;
   }
   OMP_CHECK_LAUNCH("omp_gemm_bias_act");
   return OMP_OK;
 }
 
 }  // namespace
-
-extern "C" int omp_debug_set_gemm_prefetch(int tiles) {
-  g_prefetch = tiles == 1 ? 1 : 2;
-  return OMP_OK;
-}
 
 extern "C" int omp_debug_set_gemm_trace(void* buffer, int64_t n_workgroups) {
   g_trace = reinterpret_cast<unsigned long long*>(buffer);

@@ -1,0 +1,63 @@
+"""Weight images for the fused Swin MLP kernel (csrc/mlp.hip): one-off re-layout of fc1 / fc2 at engine build time.
+
+Pure data movement (index permutations of the checkpoint tensors); no arithmetic of the hot path lives here.
+
+The kernel keeps a wave's LayerNorm'ed rows in registers as matrix-core B operands and streams the weights
+through LDS in SUB-CHUNKS of 32 hidden units.  Sub-chunk `hc` is one contiguous block
+
+    [ W1 image : C*64 B ][ W2 image : C*64 B ][ b1 slice : 128 B ][ pad to 1 KB ]          (block = C*128 + 1024 B)
+
+copied to LDS linearly by DMA (global_load_lds_dwordx4), so all layout work happens HERE:
+
+  * W1 image = rows 32*hc .. 32*hc+31 of fc1.weight [4C, C] as C/64 K-tiles of [32 rows][128 B]; inside a row the
+    16-byte chunk c sits in slot c ^ (row & 7), which makes the kernel's fragment ds_read_b128s conflict-free
+    (same swizzle as gemm_dma, there applied to the DMA source address);
+  * W2 image = for every output feature n the 32 hidden units of the sub-chunk in MATRIX-CORE ORDER:
+    position 8g + 4h + r  <-  hidden 32*hc + 16h + 4g + r   (g = 0..3, h = 0..1, r = 0..3).
+    The first product delivers GELU(fc1) as accumulators in which lane group g holds hidden 4g..4g+3 of both
+    16-wide tiles h = 0, 1; in this order those 8 values ARE the B operand fragment of the second product, so the
+    hidden activations never leave registers.  The four 16-byte chunks of a 64-byte row are stored in slot
+    g ^ f(n & 15), f(i) = (-(i >> 2)) & 3 (conflict-free ds_read_b128 over 16 rows x 64 B);
+  * b1 slice = fc1.bias[32*hc .. 32*hc+31] as fp32.
+"""
+import torch
+
+
+def mlp_block_bytes(C):
+    return C * 128 + 1024
+
+
+def pack_mlp(fc1_w, fc1_b, fc2_w):
+    """fc1_w [4C, C], fc1_b [4C] fp32, fc2_w [C, 4C] (matrices already in bf16) -> uint8 [4C/32, C*128 + 1024]."""
+    Hd, C = fc1_w.shape
+    if fc2_w.shape != (C, Hd) or Hd % 32 or C % 64:
+        raise ValueError('pack_mlp: unsupported shapes %s / %s' % (tuple(fc1_w.shape), tuple(fc2_w.shape)))
+    if fc1_w.dtype != torch.bfloat16 or fc2_w.dtype != torch.bfloat16:
+        raise TypeError('pack_mlp packs bf16 matrices (the fused kernel is bf16-only)')
+    dev = fc1_w.device
+    nsub = Hd // 32
+    blk = mlp_block_bytes(C)
+    out = torch.zeros(nsub, blk, dtype=torch.uint8, device=dev)
+    # ---- W1 image: [hc][kt][r][slot][8 elems]  <- chunk (slot ^ (r & 7)) of K-tile kt of row 32*hc + r
+    w1 = fc1_w.reshape(nsub, 32, C // 64, 8, 8)                       # [hc][r][kt][chunk][8]
+    r = torch.arange(32, device=dev)
+    slot = torch.arange(8, device=dev)
+    chunk = slot[None, :] ^ (r[:, None] & 7)                            # [r][slot] -> source chunk
+    w1 = w1.permute(0, 2, 1, 3, 4)                                      # [hc][kt][r][chunk][8]
+    idx = chunk[None, None, :, :, None].expand(nsub, C // 64, 32, 8, 8)
+    w1_img = torch.gather(w1, 3, idx).contiguous()                      # [hc][kt][r][slot][8]
+    out[:, :C * 64] = w1_img.reshape(nsub, -1).view(torch.uint8).reshape(nsub, C * 64)
+    # ---- W2 image: [hc][n][slot][8 elems]; permuted position 8g + 4h + rr <- hidden 16h + 4g + rr; slot = g ^ f(n & 15)
+    w2 = fc2_w.reshape(C, nsub, 2, 4, 4)                                # [n][hc][h][g][rr]
+    w2 = w2.permute(1, 0, 3, 2, 4).reshape(nsub, C, 4, 8)               # [hc][n][g][4h + rr]
+    n = torch.arange(C, device=dev)
+    f = (-((n & 15) >> 2)) & 3
+    s4 = torch.arange(4, device=dev)
+    g_of_slot = s4[None, :] ^ f[:, None]                                # [n][slot] -> source chunk g
+    idx = g_of_slot[None, :, :, None].expand(nsub, C, 4, 8)
+    w2_img = torch.gather(w2, 2, idx).contiguous()
+    out[:, C * 64:C * 128] = w2_img.reshape(nsub, -1).view(torch.uint8).reshape(nsub, C * 64)
+    # ---- b1 slice
+    b1 = fc1_b.detach().float().reshape(nsub, 32).contiguous()
+    out[:, C * 128:C * 128 + 128] = b1.view(torch.uint8).reshape(nsub, 128)
+    return out

@@ -238,8 +238,6 @@ def main():
         dist.init_process_group('nccl', init_method='env://', device_id=device)
 
     from advancedliteratemachinery_amd import _lib
-    if os.environ.get('OMP355_GEMM_PREFETCH'):
-        _lib.lib().omp_debug_set_gemm_prefetch(int(os.environ['OMP355_GEMM_PREFETCH']))
     model, args, sd = build_model(a.dtype, a.graph, device)
     model.overlap_decoders = bool(a.overlap)
     model.engine()   # pack the weights once, before any lane thread asks for them

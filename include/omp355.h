@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 3
+#define OMP_ABI_VERSION 4
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -290,7 +290,6 @@ int omp_debug_force_gemm_kernel(int which);
 /* development: device buffer uint64 [n_workgroups][8] that omp_debug_force_gemm_kernel(15) fills with s_memtime stamps
  * per workgroup: 0 start, 1 first K tile landed, 2 K loop done, 3 accumulators in LDS, 4 stores retired, 5 XCC id */
 int omp_debug_set_gemm_trace(void* buffer, int64_t n_workgroups);
-int omp_debug_set_gemm_prefetch(int tiles);
 int omp_debug_swin_attn_impl(int which); /* 0 = matrix-core kernel (default), 1 = scalar cross-check kernel */
 int omp_debug_cross_q4(int on);          /* 1 = LDS-ring cross-attention for 33..64 rows/image (default), 0 = register-streaming kernel */
 

@@ -22,3 +22,19 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU runs: dump the measured parity errors (tests/gpu_checks.py REPORT) next to the test log, so that the numbers
+    behind the bf16 gates can be committed under profiles/."""
+    mod = sys.modules.get('tests.gpu_checks')
+    rep = getattr(mod, 'REPORT', None) if mod is not None else None
+    if rep:
+        import json
+        out = os.environ.get('OMP355_PARITY_REPORT', os.path.join(ROOT, 'gpurun_out', 'parity_report.json'))
+        try:
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            with open(out, 'w') as f:
+                json.dump(rep, f, indent=1)
+        except OSError:
+            pass

@@ -67,9 +67,7 @@ def check_gemm():
               (64, 512, 512), (2049, 256, 1024), (16, 2048, 512)]
     for dn, dt in DTYPES.items():
         tol = 2e-4 if dt == torch.float32 else 3e-2
-        # OMP355_EXPERIMENTAL_GEMM=10,11,12 adds kernels that are not (yet) reachable without the debug selector
-        extra = tuple(int(v) for v in os.environ.get('OMP355_EXPERIMENTAL_GEMM', '').split(',') if v)
-        for which in (0, 1, 2, 3, 5, 6, 7, 8, 9) + extra:
+        for which in (0, 3, 5, 6):
             ops.force_gemm_kernel(which)
             for (M, N, K) in shapes:
                 if which == 3 and M > 600:
@@ -451,6 +449,46 @@ def check_e2e(name, dtype_name='fp32', graph=False):
     return _check_e2e(name, dtype_name, False)
 
 
+# bf16 gates (round 2; the benchmarked precision).  The reference is fp32, so a bf16 engine cannot be token-exact
+# wherever the reference's own decision margin is thinner than bf16 rounding noise.  What IS demanded:
+#   * every intermediate within BF16_REL of the reference RELATIVE to that tensor's own magnitude
+#     (measured values: profiles/r02_parity_report.json -- the gates sit at ~2-3x the measured maxima);
+#   * teacher-forced logits within BF16_LOGIT_REL of max|logit|;
+#   * at every teacher-forced position whose reference top-1/top-2 margin exceeds MARGIN_K x the measured logit error of
+#     that sequence, the engine's argmax equals the reference's (a decision can only flip inside the noise band);
+#   * free-running tokens: agreement fraction and first divergence are REPORTED (one flipped near-tie changes the rest
+#     of a greedy sequence), and gated exactly when the teacher-forced check saw no position inside the noise band.
+BF16_REL = dict(stage=0.04, fpn=0.04, memory=0.04, pos=0.01)
+BF16_LOGIT_REL = 0.03
+MARGIN_K = 2.0
+REPORT = []   # records of the measured errors (tools/parity_report.py dumps them for profiles/)
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+def _gate(out, name, got, ref, f32, tol32, rel16, note=''):
+    """fp32: absolute tolerance (north_star: 1e-3); bf16: error relative to the reference tensor's magnitude."""
+    if got.shape != ref.shape:
+        out.append(rec(name, float('inf'), tol32 if f32 else rel16, 'shape %s vs %s' % (tuple(got.shape), tuple(ref.shape))))
+        return
+    ab, rl = maxerr(got, ref), _rel(got, ref)
+    REPORT.append(dict(name=name, abs_err=ab, rel_err=rl, ref_absmax=ref.abs().max().item()))
+    if f32:
+        out.append(rec(name, ab, tol32, note))
+    else:
+        out.append(rec(name, rl, rel16, ('abs %.3g ' % ab) + note))
+
+
+def _first_div(a, b):
+    a, b = a.reshape(-1), b.reshape(-1)
+    n = min(a.numel(), b.numel())
+    ne = (a[:n] != b[:n]).nonzero()
+    return int(ne[0]) if ne.numel() else (n if a.numel() == b.numel() else n)
+
+
 def _check_e2e(name, dtype_name, graph):
     dt = DTYPES[dtype_name]
     gold = golden(name)
@@ -460,45 +498,102 @@ def _check_e2e(name, dtype_name, graph):
     fp = maxerr(G.fingerprint(sd), gold['fingerprint'])
     tag = name + (',graph' if graph else '')
     out.append(rec('e2e[%s] weight fingerprint' % name, fp, 1e-6))
-    name = tag
     model = build_model(args, sd, case['depths'], dt, graph)
+    if 'images' in gold:   # padded batch: every image must come out as the reference run on it alone
+        B = img.shape[0]
+        enc, dec = model.engine()
+        e = enc.encode(img.to(DEV), mask.to(DEV), want_intermediates=True)
+        res = model.infer(img.to(DEV), mask.to(DEV), seqs)
+        for b in range(B):
+            out += _compare_image('%s,img%d' % (tag, b), dtype_name, args, gold['images'][b], e, b, B, res[b], dec, model)
+        return out
     enc, dec = model.engine()
-    f32 = dt == torch.float32
     e = enc.encode(img.to(DEV), mask.to(DEV), want_intermediates=True)
+    res = model(type('NT', (), {'tensors': img.to(DEV), 'mask': mask.to(DEV)})(), seqs)
+    return out + _compare_image(tag, dtype_name, args, gold, e, 0, 1, res, dec, model)
+
+
+def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
+    """One image of an engine call against the reference outputs recorded for it."""
+    f32 = dtype_name == 'fp32'
+    out = []
+    fs, ss = gold.get('feat_stride', (8, 3, 3)), gold.get('src_stride', (16, 2, 2))
     for i, ((f, h, w), shp, smp) in enumerate(zip(e['feats'], gold['feat_shapes'], gold['feat_sample'])):
-        fm = f.reshape(1, h, w, -1).permute(0, 3, 1, 2)
-        ok = tuple(fm.shape) == tuple(shp)
-        out.append(rec('e2e[%s,%s] stage%d' % (name, dtype_name, i), maxerr(fm[0, ::8, ::3, ::3], smp) if ok else float('inf'),
-                       5e-4 if f32 else 0.5))
+        fm = f.reshape(B, h, w, -1).permute(0, 3, 1, 2)[b:b + 1]
+        if tuple(fm.shape) != tuple(shp):
+            out.append(rec('e2e[%s,%s] stage%d' % (name, dtype_name, i), float('inf'), 0, 'shape'))
+            continue
+        _gate(out, 'e2e[%s,%s] stage%d' % (name, dtype_name, i), fm[0, ::fs[0], ::fs[1], ::fs[2]], smp, f32, 5e-4, BF16_REL['stage'])
+    M = e['M']
     if args.use_fpn:
         h3, w3 = e['feats'][1][1], e['feats'][1][2]
-        sf = e['src_full'].reshape(1, h3, w3, 1024).permute(0, 3, 1, 2)
-        out.append(rec('e2e[%s,%s] fpn concat' % (name, dtype_name), maxerr(sf[0, ::16, ::2, ::2], gold['src_sample']), 5e-4 if f32 else 0.5))
-    out.append(rec('e2e[%s,%s] memory' % (name, dtype_name), maxerr(e['memory'], gold['memory']), 1e-3 if f32 else 1.0))
-    out.append(rec('e2e[%s,%s] pos' % (name, dtype_name), maxerr(e['pos'].reshape(-1, 512)[::5, ::3], gold['pos_sample']), 2e-5 if f32 else 1e-2))
-    res = model(type('NT', (), {'tensors': img.to(DEV), 'mask': mask.to(DEV)})(), seqs)
+        sf = e['src_full'].reshape(B, h3, w3, 1024).permute(0, 3, 1, 2)[b]
+        _gate(out, 'e2e[%s,%s] fpn concat' % (name, dtype_name), sf[::ss[0], ::ss[1], ::ss[2]], gold['src_sample'], f32, 5e-4, BF16_REL['fpn'])
+    mem = e['memory'].reshape(B, M, -1)[b]
+    if 'memory' in gold:
+        _gate(out, 'e2e[%s,%s] memory' % (name, dtype_name), mem, gold['memory'], f32, 1e-3, BF16_REL['memory'])
+    else:
+        sa, sb = gold['case']['mem_stride']
+        _gate(out, 'e2e[%s,%s] memory' % (name, dtype_name), mem[::sa, ::sb], gold['memory_sample'], f32, 1e-3, BF16_REL['memory'])
+        st = torch.tensor([mem.double().abs().sum().item(), mem.float().abs().max().item()])
+        out.append(rec('e2e[%s,%s] memory |sum|, max' % (name, dtype_name), ((st - gold['memory_stats']).abs() / gold['memory_stats']).max().item(),
+                       1e-5 if f32 else 2e-2))
+    _gate(out, 'e2e[%s,%s] pos' % (name, dtype_name), e['pos'].reshape(B, M, 512)[b][::5, ::3], gold['pos_sample'], f32, 2e-5, BF16_REL['pos'])
+    if 'key_mask' in gold:
+        km = e['key_mask'].reshape(B, M)[b].bool().cpu()
+        out.append(rec('e2e[%s,%s] key padding mask' % (name, dtype_name), float((km != gold['key_mask']).sum()), 0))
     go = gold['out']
     if args.infer_vie:
-        same = res is not None and len(res) == len(go) and all(a[0] == b[0] and a[1] == b[1] and abs(a[2] - b[2]) < 1e-4
-                                                                 and torch.allclose(torch.tensor(a[3]), torch.tensor(b[3]))
-                                                                 for a, b in zip(res, go))
-        out.append(rec('e2e[%s,%s] kie result' % (name, dtype_name), 0 if same else 1, 0 if f32 else 1, str(res)[:120]))
-    else:
-        ids = [t.cpu() for t in res[0]]
-        for key, t in zip(('pt', 'poly', 'rec'), ids):
-            same = t.shape == go[key].shape and bool((t == go[key]).all())
-            frac = float((t.reshape(-1) == go[key].reshape(-1)).float().mean()) if t.shape == go[key].shape else 0.0
-            out.append(rec('e2e[%s,%s] %s tokens' % (name, dtype_name, key), 0 if same else 1, 0 if f32 else 1, 'match=%.3f' % frac))
-        out.append(rec('e2e[%s,%s] rec probs' % (name, dtype_name), maxerr(res[1][0], go['rec_probs']) if res[1][0].shape == go['rec_probs'].shape else float('inf'),
-                       1e-3 if f32 else 1.0))
-        tf = gold['tf']
-        kv = dec.project_memory(e['memory'], e['mem_pos'], 1, e['M'], None)
+        same = res is not None and len(res) == len(go) and all(a[0] == b_[0] and a[1] == b_[1] and abs(a[2] - b_[2]) < 1e-4
+                                                                 and torch.allclose(torch.tensor(a[3]), torch.tensor(b_[3]))
+                                                                 for a, b_ in zip(res, go))
+        if f32:
+            out.append(rec('e2e[%s,%s] kie result' % (name, dtype_name), 0 if same else 1, 0, str(res)[:120]))
+        else:   # reported: the KIE walk is a free-running greedy decode (see the gate description above)
+            REPORT.append(dict(name='e2e[%s,bf16] kie result identical' % name, value=bool(same)))
+        return out
+    # teacher-forced logits (decision-level parity without greedy cascades)
+    tf = gold['tf']
+    noisy_positions = 0
+    if tf:
+        memb = e['memory'].reshape(B, M, -1)[b].contiguous()
+        mpb = e['mem_pos'].reshape(B, M, -1)[b].contiguous()
+        kmb = e['key_mask'].reshape(B, M)[b:b + 1].contiguous() if bool(e['key_mask'].reshape(B, M)[b].any()) else None
+        kv = dec.project_memory(memb, mpb, 1, M, kmb)
         npr = O.prompt_len(args)
         for kind, n_prompt in (('pt', npr), ('poly', 3), ('rec', 3)):
-            s = tf[kind + '_in']
-            lg = dec.teacher_forced_logits(kind, kv, s, [s.shape[0]], n_prompt)
-            out.append(rec('e2e[%s,%s] teacher-forced %s logits' % (name, dtype_name, kind), maxerr(lg, tf[kind + '_logits']),
-                           1e-3 if f32 else 5.0, 'max|logit|=%.1f' % tf[kind + '_logits'].abs().max().item()))
+            s_in, ref = tf[kind + '_in'], tf[kind + '_logits']
+            lg = dec.teacher_forced_logits(kind, kv, s_in, [s_in.shape[0]], n_prompt).float().cpu()
+            scale = ref.abs().max().item()
+            err = (lg - ref).abs().max().item()
+            REPORT.append(dict(name='e2e[%s,%s] teacher-forced %s logits' % (name, dtype_name, kind), abs_err=err, rel_err=err / scale, ref_absmax=scale))
+            out.append(rec('e2e[%s,%s] teacher-forced %s logits' % (name, dtype_name, kind), err if f32 else err / scale,
+                           1e-3 if f32 else BF16_LOGIT_REL, 'max|logit|=%.1f abs err %.3g' % (scale, err)))
+            # decisions: generated positions only (prompt positions are never sampled)
+            top2 = ref[:, n_prompt - 1:].topk(2, dim=-1).values
+            margin = top2[..., 0] - top2[..., 1]
+            agree = lg[:, n_prompt - 1:].argmax(-1) == ref[:, n_prompt - 1:].argmax(-1)
+            clear = margin > MARGIN_K * err
+            noisy_positions += int((~clear).sum())
+            REPORT.append(dict(name='e2e[%s,%s] teacher-forced %s argmax' % (name, dtype_name, kind), agree=float(agree.float().mean()),
+                               positions=int(agree.numel()), inside_noise_band=int((~clear).sum()), min_margin=float(margin.min())))
+            out.append(rec('e2e[%s,%s] teacher-forced %s argmax (margin > %gx err)' % (name, dtype_name, kind, MARGIN_K),
+                           float((clear & ~agree).sum()), 0, 'agree %.3f of %d, %d inside the noise band' % (float(agree.float().mean()), agree.numel(), int((~clear).sum()))))
+    # free-running greedy tokens
+    if res is None or go is None:
+        out.append(rec('e2e[%s,%s] empty result' % (name, dtype_name), 0 if (res is None) == (go is None) else 1, 0))
+        return out
+    ids = [t.cpu() for t in res[0]]
+    exact = f32 or (tf and noisy_positions == 0)
+    for key, t in zip(('pt', 'poly', 'rec'), ids):
+        same = t.shape == go[key].shape and bool((t == go[key]).all())
+        frac = float((t.reshape(-1) == go[key].reshape(-1)).float().mean()) if t.shape == go[key].shape else 0.0
+        REPORT.append(dict(name='e2e[%s,%s] %s tokens' % (name, dtype_name, key), identical=bool(same), match=frac,
+                           first_divergence=_first_div(t, go[key]), n=int(go[key].numel())))
+        if exact:
+            out.append(rec('e2e[%s,%s] %s tokens' % (name, dtype_name, key), 0 if same else 1, 0, 'match=%.3f' % frac))
+    if res[1][0].shape == go['rec_probs'].shape and (f32 or all(bool((t == go[k]).all()) for k, t in zip(('pt', 'poly', 'rec'), ids) if t.shape == go[k].shape)):
+        out.append(rec('e2e[%s,%s] rec probs' % (name, dtype_name), maxerr(res[1][0], go['rec_probs']), 1e-3 if f32 else 5e-2))
     return out
 
 
@@ -540,7 +635,8 @@ def check_batch_equivalence(dtype_name='fp32', graph=False):
     # fp32: identical tokens.  bf16: the cross-attention key split and the GEMM kernel choice depend on
     # the number of rows in flight, so summation order (not the math) differs -> near-tie flips allowed.
     frac = same / max(1, tot)
-    return [rec('batch_equivalence[%s,graph=%s]' % (dtype_name, graph), 1.0 - frac, 0.0 if dtype_name == 'fp32' else 0.25,
+    REPORT.append(dict(name='batch_equivalence[%s,graph=%s]' % (dtype_name, graph), match=frac, tokens=tot))
+    return [rec('batch_equivalence[%s,graph=%s]' % (dtype_name, graph), 1.0 - frac, 0.0 if dtype_name == 'fp32' else 0.05,
                 'token agreement %.3f' % frac)]
 
 

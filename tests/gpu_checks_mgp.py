@@ -133,3 +133,41 @@ def check_mgp_golden():
         out.append(rec('mgp_golden %s ids' % name, float((got[name + '_ids'] != ref[name + '_ids']).sum()), 0))
         out.append(rec('mgp_golden %s prob' % name, maxerr(got[name + '_prob'], ref[name + '_prob']), 1e-4))
     return out
+
+
+def check_mgp_b512(dtype_name='fp32', B=512, probe=(0, 1, 63, 64, 255, 256, 300, 511)):
+    """BASELINE config 5 at its stated shape: full ViT-B (12 blocks, full vocabularies), batch 512.  Words are independent,
+    so the oracle (CPU fp32) is run on a probe set of batch positions (first / last / tile edges) and compared with
+    the engine's rows of the 512-batch: logits, attention maps and greedy ids of all three heads.
+    bf16 (the benchmarked precision of config 5): errors relative to max|logit|, measured values in
+    profiles/r02_parity_report.json; ids must agree wherever the oracle's top-1/top-2 margin exceeds 2x the logit error."""
+    from tests.gpu_checks import REPORT
+    dt = DTYPES[dtype_name]
+    f32 = dt == torch.float32
+    c = R.cfg()
+    sd = R.make_state_dict(c, seed=33)
+    model = build(c, sd, dt)
+    img = rnd(B, 3, 32, 128, seed=77).clamp(-1, 1)
+    idx = torch.tensor([p for p in probe if p < B])
+    with torch.no_grad():
+        ratt, rch, rbp, rwp = R.forward(sd, c, img[idx])
+    att, ch, bp, wp = model(img.to(DEV), is_eval=True)
+    out = []
+    for name, a, b in (('char', ch, rch), ('bpe', bp, rbp), ('wp', wp, rwp)):
+        a = a.float().cpu()[idx]
+        scale = b.abs().max().item()
+        err = (a - b).abs().max().item()
+        REPORT.append(dict(name='mgp_b%d[%s] %s logits' % (B, dtype_name, name), abs_err=err, rel_err=err / scale, ref_absmax=scale))
+        out.append(rec('mgp_b%d[%s] %s logits' % (B, dtype_name, name), err if f32 else err / scale, 1e-3 if f32 else 0.03,
+                       'max|logit|=%.1f abs %.3g' % (scale, err)))
+        top2 = b.topk(2, dim=-1).values
+        margin = top2[..., 0] - top2[..., 1]
+        agree = a.argmax(-1) == b.argmax(-1)
+        clear = margin > 2.0 * err
+        REPORT.append(dict(name='mgp_b%d[%s] %s argmax' % (B, dtype_name, name), agree=float(agree.float().mean()), positions=int(agree.numel()),
+                           inside_noise_band=int((~clear).sum())))
+        out.append(rec('mgp_b%d[%s] %s ids (margin > 2x err)' % (B, dtype_name, name), float((clear & ~agree).sum()), 0,
+                       'agree %.4f of %d' % (float(agree.float().mean()), agree.numel())))
+    for name, a, b in zip(('char', 'bpe', 'wp'), att, ratt):
+        out.append(rec('mgp_b%d[%s] %s attention maps' % (B, dtype_name, name), maxerr(a.float().cpu()[idx], b), 2e-5 if f32 else 2e-2))
+    return out

@@ -26,8 +26,28 @@ def test_golden_fp32(C, name):
 
 @pytest.mark.parametrize('name', ['spot_odd', 'spot_224'])
 def test_golden_bf16(C, name):
-    """bf16 engine (the benchmarked precision): loose bounds; token agreement is reported, not gated."""
+    """bf16 engine (the benchmarked precision): relative-error gates on every intermediate and on the teacher-forced
+    logits, argmax agreement wherever the reference's margin exceeds the noise band (tests/gpu_checks.py, BF16_*)."""
     _assert_all(C.check_e2e(name, 'bf16'))
+
+
+# BASELINE.json configurations at their stated shapes (fixtures written by the REAL reference, oracle/gen_golden.py
+# BIG_CASES): c2 1024x1024 (M = 4096, the bench shape), c1 640x640, c3 960x1280 --infer_vie, and a padded two-size batch
+@pytest.mark.parametrize('name', ['spot_1024', 'spot_640', 'kie_960x1280', 'spot_padded'])
+def test_config_shapes_fp32(C, name):
+    """fp32 engine at the benchmarked shapes: memory / logits within 1e-3, decoded token ids identical."""
+    _assert_all(C.check_e2e(name, 'fp32'))
+
+
+@pytest.mark.parametrize('name', ['spot_1024', 'spot_640', 'kie_960x1280', 'spot_padded'])
+def test_config_shapes_bf16(C, name):
+    """the benchmarked precision at the benchmarked shapes (same gates as test_golden_bf16)."""
+    _assert_all(C.check_e2e(name, 'bf16'))
+
+
+def test_config2_shape_graph_lanes_bf16(C):
+    """1024x1024 through the path bench.py times: hipGraph replay + polygon || recognition on side streams."""
+    _assert_all(C.check_e2e('spot_1024', 'bf16', graph=True))
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])

@@ -36,3 +36,9 @@ def test_mgp_end_to_end(C, dtype):
 
 def test_mgp_golden_fp32(C):
     _assert_all(C.check_mgp_golden())
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_mgp_batch512_config5(C, dtype):
+    """BASELINE config 5 at its stated shape (ViT-B, batch 512) against the oracle on probe rows."""
+    _assert_all(C.check_mgp_b512(dtype))
