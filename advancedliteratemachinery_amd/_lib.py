@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 6
 STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
@@ -65,6 +65,10 @@ _SIGS = {
     'omp_layernorm': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64,
                               c_int, c_float, c_void_p]),
     'omp_gemm_bias_act': (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
+    'omp_swin_mlp_fused': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                   c_int, c_int, c_void_p]),
+    'omp_debug_swin_mlp_variant': (c_int, [c_int]),
+    'omp_debug_swin_mlp_trace': (c_int, [c_void_p]),
     'omp_patch_embed_ln': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p]),
     'omp_swin_window_attn': (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
     'omp_patch_merge_gather_ln': (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_void_p]),
@@ -91,6 +95,7 @@ _SIGS = {
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_prof_enable': (c_int, [c_int]),
     'omp_prof_read': (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
+    'omp_prof_read_class': (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double)]),
 }
 EXPORTS = sorted(list(_SIGS) + ['omp_last_error'])
 

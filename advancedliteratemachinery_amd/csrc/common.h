@@ -46,6 +46,12 @@ void omp_set_error(const char* fmt, ...);
     }                                                                            \
   } while (0)
 
+// measurement hooks (api.hip): hipEvent brackets around the eagerly launched kernels of one class
+enum { OMP_PROF_CROSS = 0, OMP_PROF_GEMM = 1, OMP_PROF_MLP = 2, OMP_PROF_NCLASS = 3 };
+bool omp_prof_active(int cls);
+int omp_prof_begin(int cls, hipStream_t st, double work);   // -> slot
+void omp_prof_end(int cls, int slot, hipStream_t st);
+
 // ---------------------------------------------------------------------------------------------
 // scalar conversions
 // ---------------------------------------------------------------------------------------------

@@ -683,10 +683,7 @@ __global__ void advance_pos_kernel(int32_t* d_pos) { *d_pos += 1; }
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------------
 // optional hipEvent bracketing of the cross-attention kernel (bench.py's roofline measurement)
-bool g_prof = false;
 thread_local bool g_capturing = false;   // one host thread per pipeline lane may be capturing
-std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev;
-size_t g_prof_used = 0;
 
 template <typename T, int QT, int PD>
 int launch_cross_t(const CrossP& cp, int n_groups, int S, hipStream_t st) {
@@ -751,14 +748,10 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   const bool q4 = g_cross_q4 != 0 && dtype == OMP_BF16 && qt == 4;   // waves own query tiles, not key slices
   const int slices = q4 ? S : S * 4;
   cp.kpw = (((cp.M + slices - 1) / slices + KB - 1) / KB) * KB;
-  const bool prof = g_prof && !g_capturing;
+  const bool prof = omp_prof_active(OMP_PROF_CROSS) && !g_capturing;
+  int prof_slot = -1;
   if (prof) {
-    if (g_prof_used == g_prof_ev.size()) {
-      hipEvent_t a, b;
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { omp_set_error("hipEventCreate failed"); return OMP_ERR_LAUNCH; }
-      g_prof_ev.emplace_back(a, b);
-    }
-    (void)hipEventRecord(g_prof_ev[g_prof_used].first, st);
+    prof_slot = omp_prof_begin(OMP_PROF_CROSS, st, 0.0);   // the caller knows how many images share the launch: bytes are computed there
   }
   int rc;
   const bool f = dtype == OMP_F32;
@@ -768,7 +761,7 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   else if (qt == 2) rc = f ? launch_cross_t<float, 2, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 2, 2>(cp, n_groups, S, st);
   else rc = f ? launch_cross_t<float, 4, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 4, 2>(cp, n_groups, S, st);
   if (rc != OMP_OK) return rc;
-  if (prof) (void)hipEventRecord(g_prof_ev[g_prof_used++].second, st);
+  if (prof) omp_prof_end(OMP_PROF_CROSS, prof_slot, st);
   OMP_CHECK_LAUNCH("omp_dec_cross_attn_step");
   if (S > 1) {
     rc = f ? launch_merge<float>(cp, S, st) : launch_merge<bf16_t>(cp, S, st);
@@ -947,29 +940,6 @@ int sample_and_advance(const omp_decoder_plan* P, hipStream_t st) {
 }
 
 }  // namespace
-
-/* bench instrumentation: bracket every (non-captured) cross-attention launch with hipEvents on the
- * launch stream; omp_prof_read synchronises those events and returns total ms / launch count. */
-extern "C" int omp_prof_enable(int on) {
-  g_prof = on != 0;
-  g_prof_used = 0;
-  return OMP_OK;
-}
-extern "C" int omp_prof_read(double* total_ms, int64_t* count) {
-  double tot = 0.0;
-  for (size_t i = 0; i < g_prof_used; ++i) {
-    float ms = 0.f;
-    if (hipEventSynchronize(g_prof_ev[i].second) != hipSuccess ||
-        hipEventElapsedTime(&ms, g_prof_ev[i].first, g_prof_ev[i].second) != hipSuccess) {
-      omp_set_error("omp_prof_read: event query failed");
-      return OMP_ERR_LAUNCH;
-    }
-    tot += ms;
-  }
-  if (total_ms) *total_ms = tot;
-  if (count) *count = (int64_t)g_prof_used;
-  return OMP_OK;
-}
 
 extern "C" int omp_debug_cross_q4(int on) {
   g_cross_q4 = on ? 1 : 0;

@@ -15,13 +15,15 @@
 // rows of W) and j = token m (B operand = rows of A).  A lane then owns 4 CONSECUTIVE output
 // features of one token (acc[r] <-> n = 4*(lane>>4)+r, m = lane&15), so bias loads and C stores
 // are 8/16-byte vectors instead of 4 scalar stores.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
 
 unsigned long long* g_trace = nullptr;   // omp_debug_set_gemm_trace: [capacity][8] s_memtime stamps per workgroup
 long long g_trace_cap = 0;
-int g_force_kernel = 0;  // 0 auto, 3 rows, 4 small split-K, 5 dma 128x128 (2 stages), 6 dma 64x64 ring, 15 = 5 with phase timestamps
+int g_force_kernel = 0;  // 0 auto, 3 rows, 4 small split-K, 5 dma 128x128 (2 stages), 6 dma 64x64 ring, 9 = 256x256 phase-interleaved, 15 = 5 with phase timestamps
 
 struct GemmP {
   const void* A; int64_t lda;
@@ -438,6 +440,8 @@ int launch_dma(GemmP& p, hipStream_t st) {
   return OMP_OK;
 }
 
+#include "gemm256.inc"
+
 template <typename T, typename TOut>
 __global__ __launch_bounds__(256) void gemm_rows(GemmP p) {
   typedef Mma<T> MM;
@@ -671,9 +675,18 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
     if (p.M <= 64) which = 3;
     else if (ceil_div64(p.M, 128) * ceil_div64(p.N, 128) < 512) which = 6;
     else which = 5;
+    // 256x256 phase-interleaved tiles once they fill the chip (>= one tile per CU) and the output is wide enough for a
+    // 256-column tile to pay (profiles/r02g_kbench_gemm_256.txt: wins on every Swin qkv / fc1 / fc2 / proj shape of
+    // stages 1-3 with >= 256 tiles, loses at N = 128 and on half-empty grids)
+    if constexpr (std::is_same<T, bf16_t>::value && std::is_same<TOut, bf16_t>::value) {
+      if (which == 5 && p.N >= 256 && ceil_div64(p.M, 256) * ceil_div64(p.N, 256) >= 256 && gemm256_ok(p, true, true)) which = 9;
+    }
   }
   if (which == 5) {
+    // bench.py's matrix-core roofline leg: hipEvent bracket + flop count of the large-M GEMMs
+    const int slot = omp_prof_active(OMP_PROF_GEMM) ? omp_prof_begin(OMP_PROF_GEMM, st, 2.0 * (double)p.M * p.N * p.K) : -1;
     int rc = launch_dma<T, TOut, 128, 128, 2>(p, st);
+    if (slot >= 0) omp_prof_end(OMP_PROF_GEMM, slot, st);
     if (rc != OMP_OK) return rc;
   } else if (which == 6) {
     // mid-size problems (decoder phases with 65..~4000 rows, small-image encoders): 64x64 tiles and a deep
@@ -682,6 +695,20 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
     int rc = (ceil_div64(p.M, 64) * ceil_div64(p.N, 64) <= 512) ? launch_dma<T, TOut, 64, 64, 8>(p, st)
                                                                  : launch_dma<T, TOut, 64, 64, 4>(p, st);
     if (rc != OMP_OK) return rc;
+  } else if (which == 9) {           // 256x256 phase-interleaved kernel (gemm256.inc)
+    if constexpr (std::is_same<T, bf16_t>::value && std::is_same<TOut, bf16_t>::value) {
+      if (!gemm256_ok(p, true, true)) {
+        omp_set_error("omp_gemm_bias_act: selector 9 (256x256 tiles) needs bf16 in/out, plain store, K %% 64 == 0, K >= 128, N %% 8 == 0");
+        return OMP_ERR_UNSUPPORTED;
+      }
+      const int slot = omp_prof_active(OMP_PROF_GEMM) ? omp_prof_begin(OMP_PROF_GEMM, st, 2.0 * (double)p.M * p.N * p.K) : -1;
+      int rc = launch_256<TOut>(p, st);
+      if (slot >= 0) omp_prof_end(OMP_PROF_GEMM, slot, st);
+      if (rc != OMP_OK) return rc;
+    } else {
+      omp_set_error("omp_gemm_bias_act: selector 9 (256x256 tiles) is bf16-only");
+      return OMP_ERR_UNSUPPORTED;
+    }
   } else if (which == 15) {          // development: gemm_dma<128,128,2> with per-workgroup phase timestamps
     p.tiles_m = (int)ceil_div64(p.M, 128); p.tiles_n = (int)ceil_div64(p.N, 128);
     if (g_trace == nullptr || (long long)p.tiles_m * p.tiles_n > g_trace_cap) {

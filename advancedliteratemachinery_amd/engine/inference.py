@@ -2,14 +2,19 @@
 (OCR/OmniParser/engine/val.py:11-100), plus a `predict()` convenience API.
 
   * prompts are built exactly like val.py:25-33;
-  * B images per call (the reference asserts 1), optionally image-sharded over ranks with one
-    all-gather of the decoded sequences (utils/dist.py);
-  * results are formatted like decode_pred_seq (val.py:70-100): {image_id, pts, score, polys, rec}.
+  * B images per call (the reference asserts 1);
+  * `validate` is image-sharded: under torch.distributed every rank decodes a contiguous shard of the dataloader's
+    items (utils/dist.py::shard_range), the decoded token tensors meet in ONE all-gather per tensor at the end
+    (pack_results / all_gather_results: RCCL over xGMI on MI355X, gloo in the CPU tests) and rank 0 alone writes the
+    JSON -- the reference writes the same file from every rank (val.py:64-68);
+  * results are formatted like decode_pred_seq (val.py:70-100): {image_id, pts, score, polys, rec}; KIE results
+    (`vie_categories > 0`) go to one <file_name>.json per image like val.py:39-43.
 """
 import json
 import os
 
 import torch
+import torch.distributed as tdist
 
 from ..utils import dist as udist
 from ..utils.misc import decode_seq
@@ -48,16 +53,24 @@ def decode_pred_seq(index_seqs, prob_seqs, target, args):
     return out
 
 
+def _as_nested(images):
+    """NestedTensor from whatever the caller has: anything with .tensors / .mask (ours OR the reference's class, as its
+    dataloader collates), a (B,3,H,W) tensor, or a list of (3,H,W) tensors of possibly different sizes."""
+    if hasattr(images, 'tensors'):
+        mask = images.mask
+        if mask is None:
+            t = images.tensors
+            mask = torch.zeros(t.shape[0], t.shape[2], t.shape[3], dtype=torch.bool, device=t.device)
+        return NestedTensor(images.tensors, mask)
+    if isinstance(images, torch.Tensor):
+        return NestedTensor(images, torch.zeros(images.shape[0], images.shape[2], images.shape[3], dtype=torch.bool, device=images.device))
+    return nested_tensor_from_tensor_list(list(images))
+
+
 @torch.no_grad()
-def predict(model, images, args, targets=None, orig_sizes=None):
-    """images: list of (3,H,W) tensors, a (B,3,H,W) tensor or a NestedTensor.
-    Returns one entry per image: list of records (text spotting), list of tuples (KIE) or []."""
-    if isinstance(images, NestedTensor):
-        nt = images
-    elif isinstance(images, torch.Tensor):
-        nt = NestedTensor(images, torch.zeros(images.shape[0], images.shape[2], images.shape[3], dtype=torch.bool))
-    else:
-        nt = nested_tensor_from_tensor_list(list(images))
+def predict_raw(model, images, args, orig_sizes=None):
+    """-> (per-image raw model outputs exactly as the reference's forward returns them, NestedTensor on the device)."""
+    nt = _as_nested(images)
     dev = next(model.parameters()).device
     B = nt.tensors.shape[0]
     has_padding = bool(nt.mask.any())
@@ -66,8 +79,17 @@ def predict(model, images, args, targets=None, orig_sizes=None):
     if args.infer_vie:
         if orig_sizes is None:
             orig_sizes = [(int(nt.tensors.shape[2]), int(nt.tensors.shape[3]))] * B
-        seqs.append([torch.tensor(s) for s in orig_sizes])
-    raw = model.infer(nt.tensors, nt.mask, seqs, has_padding=has_padding)
+        seqs.append([torch.as_tensor(s) for s in orig_sizes])
+    return model.infer(nt.tensors, nt.mask, seqs, has_padding=has_padding), nt
+
+
+@torch.no_grad()
+def predict(model, images, args, targets=None, orig_sizes=None):
+    """images: list of (3,H,W) tensors, a (B,3,H,W) tensor or a NestedTensor (this package's or the reference's).
+    Returns one entry per image: list of records (text spotting), list of tuples (KIE) or []."""
+    if orig_sizes is None and targets is not None and args.infer_vie:
+        orig_sizes = [t['orig_size'] for t in targets]
+    raw, nt = predict_raw(model, images, args, orig_sizes)
     if args.infer_vie:
         return [r if r is not None else [] for r in raw]
     out = []
@@ -99,23 +121,98 @@ def predict_images(model, images_u8, args, file_names=None, preprocessor=None):
     return predict(model, nt, args, targets=targets, orig_sizes=[t['orig_size'] for t in targets]), preprocessor
 
 
+def _meta(t):
+    """the (small, picklable) part of a dataloader target that result formatting needs"""
+    h, w = t['orig_size']
+    return {'file_name': t['file_name'], 'orig_size': (float(h), float(w)), 'dataset_name': t.get('dataset_name', 'results')}
+
+
 @torch.no_grad()
-def validate(model, dataloader, epoch, args, batch_size=None):
-    """Drop-in for engine.validate: iterates (samples, targets) like the reference dataloader yields them,
-    writes <output_folder>/results/epXXX/<dataset>.json on rank 0 (the reference writes from every rank)."""
+def validate(model, dataloader, epoch, args, batch_size=1):
+    """Drop-in for engine.validate (val.py:11-68), image-sharded over the ranks of torch.distributed.
+
+    dataloader yields (samples, targets) as the reference's does (samples: NestedTensor of 1 or more images, targets:
+    list of dicts with file_name / orig_size / dataset_name).  Rank r decodes items [lo, hi) = shard_range(len, r, W)
+    -- a loader that is already rank-sharded (DistributedSampler: `args.dataloader_is_sharded`) is consumed whole --
+    `batch_size` consecutive items are merged into one engine call (different sizes are padded and masked exactly as the
+    reference's collate would), decoded token tensors are packed to fixed size and all-gathered ONCE at the end, and
+    rank 0 formats and writes <output_folder>/results/epXXX/<dataset>.json (text spotting) or one <file_name>.json per
+    image (KIE).  Returns the records on rank 0 (a list; per-image lists for KIE) and [] elsewhere."""
     model.eval()
     rank, ws = udist.world()
-    results = []
-    last = None
-    for samples, targets in dataloader:
-        recs = predict(model, samples, args, targets=targets,
-                       orig_sizes=[t['orig_size'] for t in targets] if args.infer_vie else None)
-        for r in recs:
-            results.extend(r)
-        last = targets[0]
-    if rank == 0 and last is not None and args.vie_categories == 0 and args.output_folder:
-        folder = os.path.join(args.output_folder, 'results', 'ep%03d' % epoch)
+    dev = next(model.parameters()).device
+    items = list(dataloader) if not hasattr(dataloader, '__len__') else dataloader
+    n_items = len(items)
+    sharded = bool(getattr(args, 'dataloader_is_sharded', False))
+    lo, hi = (0, n_items) if (ws == 1 or sharded) else udist.shard_range(n_items, rank, ws)
+    kie = args.vie_categories > 0
+    local_raw, local_meta = [], []
+    pend_imgs, pend_tg = [], []
+
+    def flush():
+        if not pend_imgs:
+            return
+        raw, _ = predict_raw(model, list(pend_imgs), args, [t['orig_size'] for t in pend_tg] if args.infer_vie else None)
+        local_raw.extend(raw)
+        local_meta.extend(_meta(t) for t in pend_tg)
+        del pend_imgs[:], pend_tg[:]
+
+    for i, (samples, targets) in enumerate(items):
+        if i < lo or i >= hi:
+            continue
+        nt = _as_nested(samples)
+        for img, t in zip(nt.unpad_tensors(), targets):
+            pend_imgs.append(img)
+            pend_tg.append(t)
+            if len(pend_imgs) >= max(1, int(batch_size)):
+                flush()
+    flush()
+
+    folder = os.path.join(args.output_folder, 'results', 'ep%03d' % epoch) if getattr(args, 'output_folder', None) else None
+    if kie:
+        # results are host objects (strings, class names): small, gathered as objects
+        pairs = [(m, r) for m, r in zip(local_meta, local_raw) if r]
+        if ws > 1:
+            allp = [None] * ws
+            tdist.all_gather_object(allp, pairs)
+            pairs = [p for part in allp for p in part]
+        if rank != 0:
+            return []
+        if folder is not None:
+            for m, r in pairs:
+                path = os.path.join(folder, m['file_name'] + '.json')
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                with open(path, 'w') as f:
+                    json.dump(r, f)
+        return [r for _, r in pairs]
+
+    # text spotting: fixed-size token tensors, one all-gather per tensor for the whole validation set
+    n_loc = torch.tensor([len(local_raw), max([0] + [r[0][0].numel() // 2 for r in local_raw if r is not None])], dtype=torch.int64, device=dev)
+    if ws > 1:
+        tdist.all_reduce(n_loc, op=tdist.ReduceOp.MAX)
+    n_max, inst_max = int(n_loc[0]), max(1, int(n_loc[1]))
+    padded = list(local_raw) + [None] * (n_max - len(local_raw))
+    ids, probs, n_inst = udist.pack_results(padded, inst_max, args.rec_length, dev)
+    ids, probs, n_inst = udist.all_gather_results(ids, probs, n_inst)
+    metas = local_meta
+    if ws > 1:
+        allm = [None] * ws
+        tdist.all_gather_object(allm, local_meta)
+        metas = allm
+    if rank != 0:
+        return []
+    results, last = [], None
+    per_rank = [metas] if ws == 1 else metas
+    for r_, ms in enumerate(per_rank):
+        outs = udist.unpack_results(ids[r_ * n_max:r_ * n_max + len(ms)].cpu(), probs[r_ * n_max:r_ * n_max + len(ms)].cpu(),
+                                    n_inst[r_ * n_max:r_ * n_max + len(ms)].cpu())
+        for m, o in zip(ms, outs):
+            last = m
+            if o is None:       # the reference skips empty outputs (val.py:36-37)
+                continue
+            results.extend(decode_pred_seq([t[0] for t in o[0]], o[1][0], m, args))
+    if folder is not None and last is not None:
         os.makedirs(folder, exist_ok=True)
-        with open(os.path.join(folder, last.get('dataset_name', 'results') + '.json'), 'w') as f:
+        with open(os.path.join(folder, last['dataset_name'] + '.json'), 'w') as f:
             f.write(json.dumps(results, indent=4))
     return results

@@ -10,7 +10,8 @@ from .params import SWIN_B, expected_state_dict
 def load_swin_pretrained(model, path):
     """ImageNet Swin-B init by key intersection, like build_swin_transformer_model
     (reference backbone/swin_transformer.py:636-656): file = {'model': {un-prefixed keys}}."""
-    saved = torch.load(path, map_location='cpu')['model']
+    from ..utils.checkpointer import load_checkpoint_file
+    saved = load_checkpoint_file(path)['model']
     own = model.state_dict()
     hit = {}
     for k in own:

@@ -14,13 +14,17 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
+from .packing import pack_mlp
 
 LN_EPS = 1e-5
+# stages whose MLP runs as ONE fused launch in the bf16 engine (csrc/mlp.hip); at C >= 512 the row-stationary kernel is
+# bound by its weight stream and the two GEMMs win (profiles/r02c_kbench_mlp.txt)
+FUSED_MLP_WIDTHS = (128, 256)
 
 
 class _Block(object):
     __slots__ = ('n1g', 'n1b', 'qkv_w', 'qkv_b', 'table', 'proj_w', 'proj_b', 'n2g', 'n2b', 'fc1_w',
-                 'fc1_b', 'fc2_w', 'fc2_b', 'shift')
+                 'fc1_b', 'fc2_w', 'fc2_b', 'shift', 'mlp_pack')
 
 
 class _Stage(object):
@@ -61,6 +65,9 @@ class Encoder(object):
                 blk.fc1_w, blk.fc1_b = mat(p + 'mlp.fc1.weight'), f32(p + 'mlp.fc1.bias')
                 blk.fc2_w, blk.fc2_b = mat(p + 'mlp.fc2.weight'), f32(p + 'mlp.fc2.bias')
                 blk.shift = 0 if b % 2 == 0 else self.window // 2
+                fuse = (dtype == torch.bfloat16 and st.C in FUSED_MLP_WIDTHS and blk.fc1_w.shape[0] % 32 == 0
+                        and getattr(args, 'fused_mlp', True))
+                blk.mlp_pack = pack_mlp(blk.fc1_w, blk.fc1_b, blk.fc2_w) if fuse else None
                 st.blocks.append(blk)
             if s + 1 < len(depths):
                 p = '%slayers.%d.downsample.' % (bb, s)
@@ -94,9 +101,12 @@ class Encoder(object):
                 att = ops.swin_window_attn(qkv, blk.qkv_b, blk.table, B, H, W, C, st.nH, blk.shift, out=y,
                                            window=self.window)
                 ops.gemm(att, blk.proj_w, blk.proj_b, residual=x, out=x)
-                y = ops.layernorm(x, blk.n2g, blk.n2b, out=y, eps=LN_EPS)
-                h = ops.gemm(y, blk.fc1_w, blk.fc1_b, act=ops.ACT_GELU)
-                ops.gemm(h, blk.fc2_w, blk.fc2_b, residual=x, out=x)
+                if blk.mlp_pack is not None:   # norm2 + fc1 + GELU + fc2 + residual in one launch, in place
+                    ops.swin_mlp_fused(x, blk.n2g, blk.n2b, blk.mlp_pack, blk.fc2_b, out=x, eps=LN_EPS)
+                else:
+                    y = ops.layernorm(x, blk.n2g, blk.n2b, out=y, eps=LN_EPS)
+                    h = ops.gemm(y, blk.fc1_w, blk.fc1_b, act=ops.ACT_GELU)
+                    ops.gemm(h, blk.fc2_w, blk.fc2_b, residual=x, out=x)
             outs.append((ops.layernorm(x, st.out_g, st.out_b, eps=LN_EPS), H, W))
             if st.down_w is not None:
                 y, H2, W2 = ops.patch_merge_gather_ln(x, st.down_g, st.down_b, B, H, W, C, LN_EPS)

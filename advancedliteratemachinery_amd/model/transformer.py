@@ -12,8 +12,9 @@ the point decoder) and once per phase (results).
 """
 import copy
 import ctypes
-import itertools
 import os
+import threading
+from collections import OrderedDict
 
 import torch
 
@@ -49,6 +50,43 @@ def _round_up(a, b):
     return (a + b - 1) // b * b
 
 
+class _GraphSlots(object):
+    """Process-wide allocator of the library's hipGraph slots (csrc/decoder.hip holds a fixed table): ids are handed out
+    from a free list and RECYCLED -- releasing a slot destroys its graph -- so a long evaluation with many distinct
+    (decoder, shape) plans neither leaks graph executables nor silently falls back to eager launches."""
+    _lock = threading.Lock()
+    _free = []
+    _next = 0
+
+    @classmethod
+    def acquire(cls):
+        with cls._lock:
+            if cls._free:
+                return cls._free.pop()
+            if cls._next < _lib.MAX_GRAPH_SLOTS:
+                cls._next += 1
+                return cls._next - 1
+        return -1
+
+    @classmethod
+    def release(cls, slot):
+        if slot is None or slot < 0:
+            return
+        try:
+            _lib.lib().omp_decoder_graph_reset(slot)
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            return
+        with cls._lock:
+            cls._free.append(slot)
+
+
+# bounds of the per-decoder caches (ADVICE r1): a real evaluation has variable image sizes and instance counts, so
+# K/V slabs (100-200 MB per image size), phase buffers (KV caches, scratch) and captured graphs are LRU-evicted
+MAX_KV_ENTRIES = 3
+MAX_PHASES = 12
+MAX_SLOTS_PER_PHASE = 2
+
+
 class _Phase(object):
     """Device state + ctypes plan of one decoder kind for R rows (buffers are reused across calls
     so that pointers stay stable and captured graphs remain valid)."""
@@ -70,6 +108,12 @@ class _Phase(object):
         self.vc = [e(R, Lmax, d) for _ in range(L)]
         self.plan = _lib.DecoderPlan()
         self.n_tiles = 0
+        self.slots = OrderedDict()   # plan bytes -> graph slot (a phase re-bound to other K/V slabs is another graph)
+
+    def release_graphs(self):
+        for slot in self.slots.values():
+            _GraphSlots.release(slot)
+        self.slots.clear()
 
 
 class Decoder(object):
@@ -83,9 +127,8 @@ class Decoder(object):
             raise ValueError('too many decoder layers')
         self.use_graph = False
         self.n_split_override = int(os.environ.get('OMP355_CROSS_SPLIT', '0'))
-        self._graph_slots = {}
-        self._phases = {}
-        self._kv = {}
+        self._phases = OrderedDict()
+        self._kv = OrderedDict()
         d = self.d
         f32 = lambda k: sd[k].detach().float().contiguous()      # noqa: E731
         mat = lambda t: t.detach().to(dtype).contiguous()        # noqa: E731
@@ -138,9 +181,17 @@ class Decoder(object):
         Mpad = _round_up(M, KB)
         key = (B, M)
         if key not in self._kv:
+            while len(self._kv) >= MAX_KV_ENTRIES:
+                self._kv.popitem(last=False)   # plans bound to these slabs keep them alive until their phase goes too
             self._kv[key] = (torch.zeros(self.NL, B, self.nH, Mpad, 64, dtype=self.dtype, device=self.device),
-                             torch.zeros(self.NL, B, self.nH, Mpad // KB, 64, KB, dtype=self.dtype, device=self.device))
-        K_all, Vt_all = self._kv[key]
+                             torch.zeros(self.NL, B, self.nH, Mpad // KB, 64, KB, dtype=self.dtype, device=self.device),
+                             torch.zeros(B, M, dtype=torch.uint8, device=self.device))
+        self._kv.move_to_end(key)
+        K_all, Vt_all, mask_buf = self._kv[key]
+        if key_mask is not None:
+            # a STABLE buffer: the plan (and the graph captured from it) holds this pointer, not the caller's tensor
+            mask_buf.copy_(key_mask.reshape(B, M))
+            key_mask = mask_buf
         geom = (B, M, Mpad, self.nH, KB)
         ops.gemm(mem_pos, self.Wk_all, self.bk_all, out=K_all, store_mode=_lib.STORE_KBLK, kv=geom)
         # swapped operands: rows = value features, columns = memory tokens, so a lane owns 4 consecutive keys
@@ -152,7 +203,11 @@ class Decoder(object):
     def _phase(self, kind, R, Lmax, seq_ld, n_split):
         key = (kind, R, Lmax, seq_ld, n_split)
         if key not in self._phases:
+            while len(self._phases) >= MAX_PHASES:
+                _, old = self._phases.popitem(last=False)
+                old.release_graphs()
             self._phases[key] = _Phase(self, kind, R, Lmax, seq_ld, n_split)
+        self._phases.move_to_end(key)
         return self._phases[key]
 
     @staticmethod
@@ -210,39 +265,46 @@ class Decoder(object):
         ph._keepalive = (kv['K'], kv['Vt'], kv['key_mask'])
         return P
 
-    _slot_ids = itertools.count()   # graph slots live in the shared library: ids must be unique per PROCESS
-
     def fork(self):
         """A decoder that shares the packed weights but owns its phase buffers, K/V slabs and graph slots:
         one per pipeline lane (engine/pipeline.py), so lanes can be in different phases at the same time."""
         other = copy.copy(self)
-        other._graph_slots, other._phases, other._kv = {}, {}, {}
+        other._phases, other._kv = OrderedDict(), OrderedDict()
         return other
+
+    def release(self):
+        for ph in self._phases.values():
+            ph.release_graphs()
+        self._phases.clear()
+        self._kv.clear()
 
     def __del__(self):
         try:
-            for slot in self._graph_slots.values():
-                _lib.lib().omp_decoder_graph_reset(slot)
-        except Exception:
+            self.release()
+        except Exception:   # noqa: BLE001
             pass
 
-    def _slot(self, plan):
+    def _slot(self, ph):
         # stream capture is illegal on the legacy null stream: graphs only when the caller runs us on a
         # real stream (bench / predict do), eager launches otherwise
         if not self.use_graph or torch.cuda.current_stream().cuda_stream == 0:
             return -1
-        key = bytes(plan)
-        if key not in self._graph_slots:
-            self._graph_slots[key] = next(Decoder._slot_ids)
-        slot = self._graph_slots[key]
-        # the library holds a fixed table of graph slots; a process that has seen more (decoder, shape) plans than
-        # that keeps working with eager launches for the new ones
-        return slot if slot < _lib.MAX_GRAPH_SLOTS else -1
+        key = bytes(ph.plan)
+        if key in ph.slots:
+            ph.slots.move_to_end(key)
+            return ph.slots[key]
+        while len(ph.slots) >= MAX_SLOTS_PER_PHASE:
+            _, old = ph.slots.popitem(last=False)
+            _GraphSlots.release(old)
+        slot = _GraphSlots.acquire()   # -1 (eager launches) only when every slot of the library's table is live
+        if slot >= 0:
+            ph.slots[key] = slot
+        return slot
 
     def _run(self, ph, first_pos, n_steps):
         if n_steps <= 0:
             return
-        rc = _lib.lib().omp_decoder_run(ctypes.byref(ph.plan), first_pos, n_steps, self._slot(ph.plan), ops.stream())
+        rc = _lib.lib().omp_decoder_run(ctypes.byref(ph.plan), first_pos, n_steps, self._slot(ph), ops.stream())
         _lib.check(rc, 'omp_decoder_run')
 
     def _n_split(self, tiles, M):

@@ -86,6 +86,20 @@ def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     return out
 
 
+def swin_mlp_fused(x, ln_g, ln_b, wpack, b2, out=None, eps=1e-5):
+    """x [M, C] bf16 -> x + fc2(GELU(fc1(LN(x)))) in one launch; wpack from model.packing.pack_mlp.  out may be x."""
+    _c(x, 'x')
+    if x.dtype != torch.bfloat16:
+        raise TypeError('swin_mlp_fused is the bf16 engine path')
+    M, C = x.numel() // x.shape[-1], x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    rc = _lib.lib().omp_swin_mlp_fused(ptr(x), C, ptr(ln_g), ptr(ln_b), float(eps), ptr(wpack), ptr(b2), ptr(out), C, M, C,
+                                       wpack.shape[0] * 32, stream())
+    _lib.check(rc, 'omp_swin_mlp_fused')
+    return out
+
+
 def patch_embed_ln(img, w, b, gamma, beta, out_dtype, eps=1e-5):
     _c(img, 'img')
     B, _, H, W = img.shape
@@ -216,3 +230,8 @@ def cross_q4(on):
 def swin_attn_impl(which):
     """debug/testing: 0 = matrix-core window attention (default), 1 = scalar cross-check kernel."""
     _lib.check(_lib.lib().omp_debug_swin_attn_impl(which), 'omp_debug_swin_attn_impl')
+
+
+def swin_mlp_variant(v):
+    """debug/testing: alternative (rows per wave, waves per workgroup, ring depth) instantiations of the fused MLP kernel."""
+    _lib.check(_lib.lib().omp_debug_swin_mlp_variant(int(v)), 'omp_debug_swin_mlp_variant')

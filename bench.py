@@ -2,7 +2,8 @@
 """OmniParser text-spotting throughput on MI355X (BASELINE.json config 2).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+  (N > 1: one rank per GPU over RCCL -- under torch.distributed.run when RANK / WORLD_SIZE are set, otherwise bench.py
+   re-launches itself under torch.distributed.run with N ranks; it refuses to run if RCCL does not see exactly N)
 
 Workload ("step" = one batch through the whole hot path): Swin-B -> FPN -> input_proj ->
 memory K/V projection -> point decoder -> polygon decoder -> recognition decoder on a batch of
@@ -19,10 +20,18 @@ and `--lanes` such groups are in flight at once on separate HIP streams (engine/
 Scaling is weak: every rank processes its own `--batch` images per step; ranks exchange one all-gather
 of the decoded (padded) sequences per engine call, as a real image-sharded deployment would.
 
-One JSON line on rank 0: images/s (whole job), chars/s, ms per step, the roofline record of the
-dominant HBM-bound kernel (decoder cross-attention, timed with HIP events on its launch stream)
-and the CPU baseline (the oracle = reference algorithm restated on CPU, timed on a bounded sample
-of the same workload and scaled as described in its `sample` field).
+Timing: W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs, MAX over ranks.  A K-step region
+shorter than --min-seconds is REPEATED (each repetition bracketed the same way) until that much time has been
+measured; `value` comes from the MEDIAN repetition and the spread is reported (`timing`).  Every engine call is also
+bracketed with HIP events on its lane stream (`engine_call_ms`: median / p10 / p90).  Steps use DISTINCT images (a
+resident pool of `coalesce` batches).  Two more measured legs on rank 0: `batch8` = the same steps with coalesce 1
+(every 8-image batch its own engine call: BASELINE config 2's literal batch), and `eos_run` = EOS honoured instead of
+forced instance counts.
+
+One JSON line on rank 0: images/s (whole job), chars/s, ms per step, `roofline` = the dominant kernel class by GPU time
+(large-M GEMMs against the 2.5 PFLOP/s bf16 matrix-core peak, or the decoder cross-attention against 8 TB/s), the other
+classes under `roofline_other`, all timed live with HIP events on their launch streams, and the CPU baseline (the oracle
+= reference algorithm restated on CPU, timed on a bounded sample of the same workload, scaled as its `sample` says).
 """
 import argparse
 import ctypes
@@ -37,14 +46,19 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+MFMA_PEAK_TFS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix-core peak
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=64)
-    p.add_argument('--warmup', type=int, default=16)
+    p.add_argument('--steps', type=int, default=192)
+    p.add_argument('--warmup', type=int, default=32)
+    p.add_argument('--min-seconds', type=float, default=5.0, help='repeat the K-step timed region until this much time is measured')
+    p.add_argument('--no-batch8', action='store_true', help='skip the coalesce-1 (true batch-8 engine calls) leg')
+    p.add_argument('--no-eos-run', action='store_true', help='skip the EOS-honouring leg')
+    p.add_argument('--eos-pt-len', type=int, default=130, help='pt_seq_length of the EOS-honouring leg (<= 64 instances per image)')
     p.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     p.add_argument('--size', type=int, default=1024)
     p.add_argument('--instances', type=int, default=64, help='forced text instances per image')
@@ -116,17 +130,45 @@ def gather_results(results, B, N, rec_len, world, device):
 
 def pmc_traffic(images_per_launch):
     """HBM bytes per cross-attention launch from the rocprofv3 PMC passes (separate runs; tools/pmc_cross_json.py
-    turns their summaries into profiles/pmc_cross_attn.json).  FETCH_SIZE is in KiB and counts 16-byte/lane
-    streaming reads at half their size on gfx950 (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE is in KiB."""
+    turns their summaries into profiles/pmc_cross_attn.json, one record per images-per-launch).  FETCH_SIZE is in KiB
+    and counts 16-byte/lane streaming reads at half their size on gfx950 (MI355X_MICROARCH.md, HBM) -> x2;
+    WRITE_SIZE is in KiB."""
     path = os.environ.get('OMP355_PMC_JSON', os.path.join(ROOT, 'profiles', 'pmc_cross_attn.json'))
     try:
         with open(path) as f:
             rec = json.load(f)
-        if int(rec['images_per_launch']) != int(images_per_launch):
+        if 'images_per_launch' in rec:          # single record (round-1 format)
+            rec = {str(rec['images_per_launch']): rec}
+        r = rec.get(str(int(images_per_launch)))
+        if r is None:
             return None
-        return float(rec['fetch_kib_mean']) * 1024.0 * 2.0 + float(rec['write_kib_mean']) * 1024.0
+        return float(r['fetch_kib_mean']) * 1024.0 * 2.0 + float(r['write_kib_mean']) * 1024.0
     except (OSError, ValueError, KeyError):
         return None
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this script under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def pct(xs, f):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    i = f * (len(xs) - 1)
+    lo, hi = int(i), min(int(i) + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (i - lo)
 
 
 def host_cores():
@@ -224,27 +266,34 @@ def cpu_baseline(args, sd, size, instances, pt_steps, budget_s=40.0):
 
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the hot path)')
+    if torch.cuda.device_count() < world:
+        raise SystemExit('--gpus %d but only %d GPUs are visible' % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', init_method='env://', device_id=device)
+        # RCCL must see exactly N ranks on N distinct devices
+        seen = torch.zeros(world, dtype=torch.int32, device=device)
+        seen[rank] = 1 + local
+        dist.all_reduce(seen)
+        if dist.get_world_size() != a.gpus or int((seen > 0).sum()) != a.gpus or len(set(seen.tolist())) != a.gpus:
+            raise SystemExit('RCCL sees %d ranks / devices %s, expected %d distinct' % (dist.get_world_size(), seen.tolist(), a.gpus))
 
     from advancedliteratemachinery_amd import _lib
     model, args, sd = build_model(a.dtype, a.graph, device)
     model.overlap_decoders = bool(a.overlap)
     model.engine()   # pack the weights once, before any lane thread asks for them
     B, N = a.batch, a.instances
-    g = torch.Generator(device='cpu').manual_seed(1234 + rank)
-    img = torch.randn(B, 3, a.size, a.size, generator=g).to(device)   # resident in HBM before timing
-    mask = torch.zeros(B, a.size, a.size, dtype=torch.bool, device=device)
     seqs = prompts(args)
     stream = torch.cuda.Stream(device=device)
 
@@ -254,74 +303,107 @@ def main():
 
     # steps per engine call: `coalesce`, but never so many that a lane would stay idle in a short run
     G = max(1, min(a.coalesce, -(-a.steps // lanes)))
+    # resident pool of DISTINCT batches (step s uses batch s % POOL); in HBM before the timed region starts
+    POOL = max(G, 1)
+    g = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    batches = [torch.randn(B, 3, a.size, a.size, generator=g).to(device) for _ in range(POOL)]
+    mask1 = torch.zeros(B, a.size, a.size, dtype=torch.bool, device=device)
+    calls = []   # (start event, end event, images) of every engine call, recorded on its lane stream
 
-    def group_input(g):
-        """g consecutive steps as one engine call: the g batches are concatenated inside the timed region (a serving
-        engine receives them as separate tensors)."""
-        if g == 1:
-            return img, mask
-        return torch.cat([img] * g, 0), torch.cat([mask] * g, 0)
-
-    def one_step():
-        """synchronous form (phase breakdown, roofline leg): ONE batch on the current stream"""
-        res = model.infer(img, mask, seqs, forced_instances=N, has_padding=False)
-        return gather_results(res, B, N, args.rec_length, world, device)
-
-    def run_group(g, lane=None):
-        gi, gm = group_input(g)
-        res = model.infer(gi, gm, seqs, forced_instances=N, has_padding=False, lane=lane)
-        return gather_results(res, B * g, N, args.rec_length, 1, device)
-
-    def run_steps(k):
-        """k steps = k batches through the whole hot path, in groups of `coalesce` consecutive steps per engine call.
-        With lanes > 1 consecutive groups are in flight on different HIP streams (lane threads enqueue them); the
-        all-gather of the decoded sequences (one per group) is issued from THIS thread in step order, after the
-        lane's completion event, so every rank calls the collectives in the same order."""
-        sizes = [G] * (k // G) + ([k % G] if k % G else [])
-        out = None
-        if pool is None:
-            for g in sizes:
-                ids, probs = run_group(g)
-                out = exchange(ids, probs, g)
-            return out
-        futs = [pool.submit(lambda lane, g=g: run_group(g, lane)) for g in sizes]
-        for f, g in zip(futs, sizes):
-            (ids, probs), ev = f.result()
-            torch.cuda.current_stream().wait_event(ev)
-            out = exchange(ids, probs, g)
+    def run_group(first_step, g_, lane=None, forced=N):
+        """steps first_step .. first_step+g_-1 as ONE engine call: their batches arrive as separate tensors and are
+        concatenated here, inside the timed region, as a serving engine would have to."""
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        if g_ == 1:
+            gi, gm = batches[first_step % POOL], mask1
+        else:
+            gi = torch.cat([batches[(first_step + i) % POOL] for i in range(g_)], 0)
+            gm = mask1.expand(g_, B, a.size, a.size).reshape(g_ * B, a.size, a.size)
+        res = model.infer(gi, gm, seqs, forced_instances=forced, has_padding=False, lane=lane)
+        out = gather_results(res, B * g_, N, args.rec_length, 1, device)
+        ev1.record()
+        calls.append((ev0, ev1, B * g_))
         return out
 
-    def exchange(ids, probs, g):
+    def exchange(ids, probs, g_):
         if world == 1:
             return ids, probs
-        all_ids = torch.empty(world * B * g, N, ids.shape[2], dtype=torch.int32, device=device)
-        all_pr = torch.empty(world * B * g, N, args.rec_length, dtype=torch.float32, device=device)
+        # results were produced on a lane stream and are consumed by RCCL on this one: tell the caching allocator
+        ids.record_stream(torch.cuda.current_stream())
+        probs.record_stream(torch.cuda.current_stream())
+        all_ids = torch.empty(world * B * g_, N, ids.shape[2], dtype=torch.int32, device=device)
+        all_pr = torch.empty(world * B * g_, N, args.rec_length, dtype=torch.float32, device=device)
         dist.all_gather_into_tensor(all_ids, ids)
         dist.all_gather_into_tensor(all_pr, probs)
         return all_ids, all_pr
+
+    def run_steps(k, group=None, forced=N):
+        """k steps = k batches through the whole hot path, in groups of `group` consecutive steps per engine call.
+        With lanes > 1 consecutive groups are in flight on different HIP streams (lane threads enqueue them); the
+        all-gather of the decoded sequences (one per group) is issued from THIS thread in step order, after the
+        lane's completion event, so every rank calls the collectives in the same order."""
+        group = group or G
+        sizes = [group] * (k // group) + ([k % group] if k % group else [])
+        firsts = [sum(sizes[:i]) for i in range(len(sizes))]
+        out = None
+        if pool is None:
+            for f0, g_ in zip(firsts, sizes):
+                ids, probs = run_group(f0, g_, forced=forced)
+                out = exchange(ids, probs, g_)
+            return out
+        futs = [pool.submit(lambda lane, f0=f0, g_=g_: run_group(f0, g_, lane, forced)) for f0, g_ in zip(firsts, sizes)]
+        for f, g_ in zip(futs, sizes):
+            (ids, probs), ev = f.result()
+            torch.cuda.current_stream().wait_event(ev)
+            out = exchange(ids, probs, g_)
+        return out
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    with torch.cuda.stream(stream):
-        # untimed set-up: every lane (or the model itself) allocates its buffers and captures its graphs for
-        # both group sizes the timed region will use (full groups and the remainder group)
-        for g in sorted({G, a.steps % G, a.warmup % G} - {0}):
-            for _ in range(lanes):
-                run_steps(g)
-        run_steps(a.warmup)
+    def timed(k, group=None, forced=N):
+        """EXACTLY k steps between barrier + synchronize pairs; MAX over ranks."""
         torch.cuda.synchronize()
         barrier()
         t0 = time.perf_counter()
-        out = run_steps(a.steps)
+        out = run_steps(k, group, forced)
         torch.cuda.synchronize()
         barrier()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    with torch.cuda.stream(stream):
+        # untimed set-up: every lane (or the model itself) allocates its buffers and captures its graphs for
+        # both group sizes the timed region will use (full groups and the remainder group)
+        for g_ in sorted({G, a.steps % G, a.warmup % G} - {0}):
+            for _ in range(lanes):
+                run_steps(g_)
+        run_steps(a.warmup)
+        torch.cuda.synchronize()
+        del calls[:]
+        reps = []
+        budget_reps = 64
+        while True:
+            el, out = timed(a.steps)
+            reps.append(el)
+            spent = sum(reps)
+            stop = spent >= a.min_seconds or len(reps) >= budget_reps
+            if world > 1:   # every rank must take the same decision
+                t = torch.tensor([1.0 if stop else 0.0], device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                stop = bool(t.item() > 0)
+            if stop:
+                break
+        torch.cuda.synchronize()
+        call_ms = [e0.elapsed_time(e1) for e0, e1, _ in calls]
+        call_imgs = calls[0][2] if calls else B * G
+    elapsed = pct(reps, 0.5)
     total_images = world * B * a.steps
     ips = total_images / elapsed
     # sanity: the forced workload really produced N instances x rec_length chars per image
@@ -329,58 +411,147 @@ def main():
     last_g = a.steps % G or G
     assert ids.shape[0] == world * B * last_g and int((ids[:, :, 34:] >= args.num_bins).all()), 'decode output malformed'
 
+    extra = {}
+    def leg(name, fn):
+        try:
+            extra[name] = fn()
+        except Exception as e:  # noqa: BLE001 -- a failed side leg is reported, it must not lose the headline
+            extra[name] = dict(error='%s: %s' % (type(e).__name__, e))
+
+    def batch8_leg():
+        # BASELINE config 2 literally: every batch of 8 images its own engine call (no cross-step coalescing)
+        with torch.cuda.stream(stream):
+            for _ in range(lanes):
+                run_steps(2, group=1)
+            k8 = min(a.steps, 64)
+            r8 = []
+            while sum(r8) < min(a.min_seconds, 3.0) and len(r8) < 16:
+                r8.append(timed(k8, group=1)[0])
+        e8 = pct(r8, 0.5)
+        return dict(images_per_sec=B * k8 / e8, ms_per_step=e8 / k8 * 1e3, steps=k8, repeats=len(r8),
+                               note='coalesce 1: one engine call per 8-image batch, %d lanes' % lanes)
+    def eos_leg():
+        # EOS honoured (no forced instance count) on the sharpened synthetic checkpoint; the point sequence is
+        # capped at --eos-pt-len tokens so that an image yields at most 64 instances, as in the forced workload
+        keep = args.pt_seq_length
+        args.pt_seq_length = a.eos_pt_len
+        try:
+            with torch.cuda.stream(stream):
+                ke = min(a.steps, 16)
+                run_steps(min(ke, lanes), group=1, forced=None)
+                t0 = time.perf_counter()
+                torch.cuda.synchronize()
+                n_inst = []
+                for s_ in range(ke):
+                    res = model.infer(batches[s_ % POOL], mask1, seqs, forced_instances=None, has_padding=False)
+                    n_inst += [0 if r is None else r[0][0].numel() // 2 for r in res]
+                torch.cuda.synchronize()
+                ee = time.perf_counter() - t0
+            return dict(images_per_sec=B * ke / ee, steps=ke, mean_instances_per_image=sum(n_inst) / max(1, len(n_inst)),
+                                    chars_per_sec=sum(n_inst) * args.rec_length / ee,
+                                    note='EOS honoured, pt_seq_length %d, synchronous 8-image engine calls (no lanes)' % a.eos_pt_len)
+        finally:
+            args.pt_seq_length = keep
+
+    if rank == 0 and world == 1 and not a.no_batch8:
+        leg('batch8', batch8_leg)
+    if rank == 0 and world == 1 and not a.no_eos_run:
+        leg('eos_run', eos_leg)
+
     if a.phase_times and rank == 0:
+        def one_step():
+            res = model.infer(batches[0], mask1, seqs, forced_instances=N, has_padding=False)
+            return gather_results(res, B, N, args.rec_length, 1, device)
         print('phase ms: %s' % json.dumps(phase_breakdown(model, one_step, stream)), file=sys.stderr, flush=True)
 
-    roof = None
+        def one_call():
+            gi = torch.cat([batches[i % POOL] for i in range(G)], 0)
+            gm = mask1.expand(G, B, a.size, a.size).reshape(G * B, a.size, a.size)
+            return model.infer(gi, gm, seqs, forced_instances=N, has_padding=False)
+        print('phase ms (one synchronous engine call of %d images): %s' % (B * G, json.dumps(phase_breakdown(model, one_call, stream))),
+              file=sys.stderr, flush=True)
+
+    roof, roof_other = None, []
     if rank == 0 and not a.no_roofline:
-        # Dominant HBM-bound kernel: decoder cross-attention (streams K and V^T of every image once per
-        # launch, shared by all query rows).  Timed with HIP events on the launch stream over the same
-        # K steps, eager launches (events cannot bracket kernels inside a graph replay).
-        enc, dec = model.engine()
+        # Kernel classes timed with HIP events on their launch streams over the same engine calls as the timed region,
+        # launched eagerly on one stream (events cannot bracket kernels inside a graph replay; one lane so that a
+        # kernel's duration is its own): large-M GEMMs and the fused MLP (matrix-core bound, flops counted by the
+        # library per launch) and the decoder cross-attention (HBM bound: streams K and V^T of every image once per
+        # launch, shared by all query rows).
         was = model.use_graph
         model.use_graph = False
         h = _lib.lib()
-        n_groups = (a.steps + G - 1) // G
+        n_groups = max(1, min(4, (a.steps + G - 1) // G))
         with torch.cuda.stream(stream):
-            run_group(G)
+            run_group(0, G)
             torch.cuda.synchronize()
-            h.omp_prof_enable(1)
-            for _ in range(n_groups):   # the same engine calls as the timed region (groups of G steps), eagerly
-                run_group(G)
+            h.omp_prof_enable(7)
+            for i in range(n_groups):
+                run_group(i * G, G)
             torch.cuda.synchronize()
-        tot, cnt = ctypes.c_double(0), ctypes.c_int64(0)
-        h.omp_prof_read(ctypes.byref(tot), ctypes.byref(cnt))
+
+        def read(cls):
+            tot, cnt, work = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+            h.omp_prof_read_class(cls, ctypes.byref(tot), ctypes.byref(cnt), ctypes.byref(work))
+            return tot.value, cnt.value, work.value
+        t_cross, n_cross, _ = read(0)
+        t_gemm, n_gemm, f_gemm = read(1)
+        t_mlp, n_mlp, f_mlp = read(2)
         h.omp_prof_enable(0)
         model.use_graph = was
         M = (a.size // 16) ** 2
         esz = 2 if a.dtype == 'bf16' else 4
         BI = B * G   # images per launch
-        # algorithmic bytes per launch: K + V^T of the images in the call (d = 512) + q in / o out of
-        # the rows (launch-weighted: 1 row/image in the point phase, N rows/image in polygon / recognition)
-        rows_avg = BI * (1 * (2 * N + 6) + N * (34 + 27)) / float((2 * N + 6) + 34 + 27)
-        alg = BI * 2 * M * 512 * esz + rows_avg * 2 * 512 * esz
-        avg_s = (tot.value / 1e3) / max(1, cnt.value)
-        ach = alg / avg_s / 1e9
-        roof = dict(bound='hbm', kernel='dec_cross_attn_kernel / dec_cross_attn_q4_kernel', achieved=ach, peak=HBM_PEAK_GBS,
-                    unit='GB/s', frac=ach / HBM_PEAK_GBS, traffic=pmc_traffic(BI), launches=int(cnt.value),
-                    avg_us=avg_s * 1e6, alg_bytes_per_launch=alg, images_per_launch=BI,
-                    note='hipEvent-bracketed eager launches of the same %d engine calls (graph replay cannot be bracketed); '
-                         'traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch from the committed PMC passes '
-                         '(profiles/), null when they were taken at another images-per-launch' % n_groups)
+        recs = []
+        if n_gemm:
+            tf = f_gemm / (t_gemm / 1e3) / 1e12
+            recs.append((t_gemm, dict(bound='mfma', kernel='gemm_dma<128,128,2> (Swin qkv / proj / fc1 / fc2 / merge, FPN, input_proj, K-V projection)',
+                                      achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None,
+                                      launches=int(n_gemm), avg_us=t_gemm / n_gemm * 1e3, flops_per_launch=f_gemm / n_gemm,
+                                      gpu_ms_per_image=t_gemm / (n_groups * BI))))
+        if n_mlp:
+            tf = f_mlp / (t_mlp / 1e3) / 1e12
+            recs.append((t_mlp, dict(bound='mfma', kernel='mlp_fused_kernel (Swin stages 0/1: LayerNorm + fc1 + GELU + fc2 + residual)',
+                                     achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None,
+                                     launches=int(n_mlp), avg_us=t_mlp / n_mlp * 1e3, flops_per_launch=f_mlp / n_mlp,
+                                     gpu_ms_per_image=t_mlp / (n_groups * BI))))
+        if n_cross:
+            # algorithmic bytes per launch: K + V^T of the images in the call (d = 512) + q in / o out of the
+            # rows (launch-weighted: 1 row/image in the point phase, N rows/image in polygon / recognition)
+            rows_avg = BI * (1 * (2 * N + 6) + N * (34 + 27)) / float((2 * N + 6) + 34 + 27)
+            alg = BI * 2 * M * 512 * esz + rows_avg * 2 * 512 * esz
+            avg_s = (t_cross / 1e3) / n_cross
+            ach = alg / avg_s / 1e9
+            recs.append((t_cross, dict(bound='hbm', kernel='dec_cross_attn_kernel / dec_cross_attn_q4_kernel', achieved=ach, peak=HBM_PEAK_GBS,
+                                       unit='GB/s', frac=ach / HBM_PEAK_GBS, traffic=pmc_traffic(BI), launches=int(n_cross),
+                                       avg_us=avg_s * 1e6, alg_bytes_per_launch=alg, images_per_launch=BI,
+                                       gpu_ms_per_image=t_cross / (n_groups * BI))))
+        recs.sort(key=lambda r: -r[0])
+        note = ('hipEvent-bracketed eager launches of %d engine calls of %d images on one stream (graph replay cannot be bracketed); '
+                'ordered by GPU time; traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch from the committed '
+                'PMC passes (profiles/pmc_cross_attn.json), null for classes / sizes without a pass' % (n_groups, BI))
+        if recs:
+            roof = dict(recs[0][1], note=note)
+            roof_other = [r for _, r in recs[1:]]
 
     if rank == 0:
         rec = dict(metric='images/sec (1024x1024) + chars/sec decoded, OmniParser text-spotting', value=ips, unit='images/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=elapsed / a.steps * 1e3,
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype=a.dtype, data='synthetic',
                    chars_per_sec=ips * N * args.rec_length,
+                   timing=dict(repeats=len(reps), seconds_measured=sum(reps), ms_per_step_median=elapsed / a.steps * 1e3,
+                               ms_per_step_p10=pct(reps, 0.1) / a.steps * 1e3, ms_per_step_p90=pct(reps, 0.9) / a.steps * 1e3,
+                               note='each repetition = exactly %d steps between barrier+synchronize pairs, max over ranks; value from the median' % a.steps),
+                   engine_call_ms=dict(images_per_call=call_imgs, calls=len(call_ms), median=pct(call_ms, 0.5), p10=pct(call_ms, 0.1),
+                                       p90=pct(call_ms, 0.9), note='HIP events on the lane stream around every engine call of the timed region (latency, lanes overlap)'),
                    config=dict(workload='OmniParser text-spotting, Swin-B, batch %d/GPU @ %dx%d, forced %d instances/image '
                                         '(%d pt + 34 poly + 27 rec decoder steps), %s' % (B, a.size, a.size, N, 2 * N + 6, a.dtype),
                                global_batch=world * B, image_size=a.size, instances_per_image=N, parallelism='image-sharded dp%d' % world,
-                               hip_graph=bool(a.graph), lanes=lanes, coalesce=G,
-                               images_per_engine_call=B * G))
+                               hip_graph=bool(a.graph), lanes=lanes, coalesce=G, images_per_engine_call=B * G, distinct_batches=POOL))
+        rec.update(extra)
         if roof is not None:
             rec['roofline'] = roof
+            rec['roofline_other'] = roof_other
         if not a.no_cpu_baseline and world == 1:
             rec['cpu_baseline'] = cpu_baseline(args, sd, a.size, N, 2 * N + 1)
         print(json.dumps(rec), flush=True)

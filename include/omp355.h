@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 4
+#define OMP_ABI_VERSION 6
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -99,6 +99,18 @@ typedef struct {
   int32_t kv_images, kv_tokens, kv_mpad, kv_heads, kv_key_block;
 } omp_gemm_args;
 int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s);
+
+/* ---- Fused Swin MLP (bf16 engine):  y = x + fc2(GELU(fc1(LayerNorm(x)))) ---------------------------------------
+ * Replaces `x = x + self.drop_path(self.mlp(self.norm2(x)))`, swin_transformer.py:250, with Mlp.forward (:30-36)
+ * inlined: one launch, the [tokens, hidden] activation never reaches HBM.  x, y: bf16 [M, C] with row pitches
+ * ldx / ldy (y may alias x); ln_gamma / ln_beta / b2 (= fc2.bias): fp32 [C]; wpack: fc1.weight, fc1.bias and
+ * fc2.weight re-laid out once per checkpoint by model/packing.py::pack_mlp (hidden / 32 sub-chunk images of
+ * C*128 + 1024 bytes; layout documented there and in csrc/mlp.hip).  C in {128, 256, 512}, hidden % 32 == 0. */
+int omp_swin_mlp_fused(const void* x, int64_t ldx, const float* ln_gamma, const float* ln_beta, float eps,
+                       const void* wpack, const float* b2, void* y, int64_t ldy, int64_t M, int C, int hidden,
+                       omp_stream_t s);
+int omp_debug_swin_mlp_variant(int v); /* development: alternative (rows per wave, waves, ring depth) instantiations; 100 = traced default */
+int omp_debug_swin_mlp_trace(void* buffer); /* development: uint64 [workgroups][8] cycle sums written by variant 100 (csrc/mlp.hip) */
 
 /* ---- Swin patch embedding: zero-pad to x4, 4x4/4 conv (as K=48 dot products), LayerNorm -----
  * Replaces PatchEmbed.forward, swin_transformer.py:427-443.  img is NCHW fp32 (as the reference
@@ -282,10 +294,14 @@ int omp_resize_normalize_pad(const uint8_t* src, int64_t src_pitch, int in_h, in
                              const float* lut, float* dst, uint8_t* mask, int out_h, int out_w, int dst_h,
                              int dst_w, omp_stream_t s);
 
-/* Measurement hooks (bench.py roofline leg): hipEvent-bracket every eagerly launched decoder
- * cross-attention kernel on its launch stream; read back total milliseconds and launch count. */
-int omp_prof_enable(int on);
+/* Measurement hooks (bench.py roofline legs): hipEvent-bracket every EAGERLY launched kernel of a class on its launch
+ * stream.  Classes (bit c of `mask`): 0 = decoder cross-attention kernels, 1 = large-M GEMMs (gemm_dma 128x128),
+ * 2 = fused Swin MLP.  omp_prof_read_class returns total milliseconds, launch count and the summed work of the
+ * bracketed launches (flops for classes 1 and 2; 0 for class 0, whose bytes the caller computes).  omp_prof_read =
+ * class 0 (kept for round-1 callers). */
+int omp_prof_enable(int mask);
 int omp_prof_read(double* total_ms, int64_t* count);
+int omp_prof_read_class(int cls, double* total_ms, int64_t* count, double* work);
 int omp_debug_force_gemm_kernel(int which);
 /* development: device buffer uint64 [n_workgroups][8] that omp_debug_force_gemm_kernel(15) fills with s_memtime stamps
  * per workgroup: 0 start, 1 first K tile landed, 2 K loop done, 3 accumulators in LDS, 4 stores retired, 5 XCC id */

@@ -102,3 +102,14 @@ def build_reference_model(args, state_dict, embed_dim=128, depths=(2, 2, 18, 2),
 
 def nested(tensors, mask):
     return ref_modules()['nested'].NestedTensor(tensors, mask)
+
+
+def ref_module(name):
+    """Import one more module of the reference tree by its dotted name (e.g. 'utils.checkpointer')."""
+    ref_modules()
+    import importlib
+    sys.path.insert(0, REF_ROOT)
+    try:
+        return importlib.import_module(name)
+    finally:
+        sys.path.remove(REF_ROOT)

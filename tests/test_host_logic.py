@@ -214,3 +214,29 @@ def test_encoder_chunking_concatenates_memory_in_image_order():
     assert out['memory'][:, 0].tolist() == [float(i) for i in range(8) for _ in range(4)]
     assert out['key_mask'].shape == (8, 4) and out['key_mask'][5].all() and not out['key_mask'][4].any()
     assert out['M'] == 4 and out['hw'] == (2, 2)
+
+
+def test_graph_slots_are_recycled():
+    """graph slot ids come from a free list and are reused after release (the library's table is finite)."""
+    from advancedliteratemachinery_amd import _lib
+    from advancedliteratemachinery_amd.model.transformer import _GraphSlots
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('libomp355.so not built')
+    a, b = _GraphSlots.acquire(), _GraphSlots.acquire()
+    assert a >= 0 and b >= 0 and a != b
+    _GraphSlots.release(a)
+    c = _GraphSlots.acquire()
+    assert c == a
+    _GraphSlots.release(b)
+    _GraphSlots.release(c)
+    # exhausting the table yields -1 (eager launches), never an out-of-range id
+    got = []
+    while True:
+        s = _GraphSlots.acquire()
+        if s < 0:
+            break
+        got.append(s)
+    assert len(set(got)) == len(got) and max(got) < _lib.MAX_GRAPH_SLOTS
+    for s in got:
+        _GraphSlots.release(s)
+    assert _GraphSlots.acquire() >= 0

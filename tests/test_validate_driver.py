@@ -1,0 +1,157 @@
+"""engine/inference.py::validate / predict end to end on the CPU with a STUB model (deterministic fake decodes keyed by
+image content): the drop-in for the reference's engine.validate (OCR/OmniParser/engine/val.py:11-100) -- batching of
+dataloader items, padding of mixed sizes, record formatting, the JSON files, and the image-sharded path: world-size-2
+gloo, shard_range split, one all-gather, rank 0 writes.  The model arithmetic is out of scope here (tests/test_gpu_*)."""
+import json
+import os
+
+import torch
+import torch.multiprocessing as mp
+
+from advancedliteratemachinery_amd.engine import inference as inf
+from advancedliteratemachinery_amd.utils import dist as udist
+from advancedliteratemachinery_amd.utils.parser import make_args
+
+REC = 25
+
+
+class RefStyleNested(object):
+    """what the REFERENCE's collate hands over: its own NestedTensor class (utils/nested_tensor.py:7-35), not ours"""
+
+    def __init__(self, tensors, mask):
+        self.tensors, self.mask = tensors, mask
+
+    def to(self, device):
+        return RefStyleNested(self.tensors.to(device), self.mask.to(device))
+
+
+def _key(img, mask):
+    """content key of the UNPADDED image (so batching / padding cannot change it)"""
+    h = int((~mask[:, 0]).sum())
+    w = int((~mask[0, :]).sum())
+    return int(img[:, :h, :w].abs().sum().item() * 10) % 997
+
+
+def _fake(key, kie):
+    n = key % 4     # 0 instances -> None, exercised on purpose
+    if n == 0:
+        return None
+    if kie:
+        return [('w%d' % key, 'total', 0.5, [[1.0, 2.0, 3.0, 4.0]])] * n
+    g = torch.Generator().manual_seed(key)
+    return ([torch.randint(0, 1000, (1, 2 * n), generator=g), torch.randint(0, 1000, (1, 32 * n), generator=g),
+             torch.randint(1000, 1096, (1, n, REC), generator=g)], [torch.rand(n, REC, generator=g)])
+
+
+class StubModel(torch.nn.Module):
+    def __init__(self, kie=False):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.zeros(1))
+        self.kie = kie
+        self.calls = []
+
+    def infer(self, img, mask, seqs, has_padding=None, **kw):
+        self.calls.append((tuple(img.shape), bool(has_padding)))
+        assert seqs[0].tolist() == [[0, 0, 999, 999, 1000, 1095, 1100]]
+        return [_fake(_key(img[b], mask[b]), self.kie) for b in range(img.shape[0])]
+
+
+def _loader(n, ref_style=True):
+    """batch-1 items of different sizes, like the reference's val dataloader"""
+    items = []
+    for i in range(n):
+        g = torch.Generator().manual_seed(50 + i)
+        h, w = 32 + 8 * (i % 3), 40 + 8 * (i % 2)
+        img = torch.randn(1, 3, h, w, generator=g)
+        nt = RefStyleNested(img, torch.zeros(1, h, w, dtype=torch.bool))
+        if not ref_style:
+            from advancedliteratemachinery_amd.utils.nested_tensor import NestedTensor
+            nt = NestedTensor(nt.tensors, nt.mask)
+        items.append((nt, [{'file_name': 'img_%02d.jpg' % i, 'orig_size': torch.tensor([h * 2, w * 2]), 'dataset_name': 'unit_val'}]))
+    return items
+
+
+def _expected(n, args):
+    out = []
+    for samples, targets in _loader(n):
+        r = _fake(_key(samples.tensors[0], samples.mask[0]), False)
+        if r is None:
+            continue
+        out.extend(inf.decode_pred_seq([t[0] for t in r[0]], r[1][0], targets[0], args))
+    return out
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x['image_id'] == y['image_id'] and x['rec'] == y['rec'] and abs(x['score'] - y['score']) < 1e-6
+        assert torch.allclose(torch.tensor(x['polys']), torch.tensor(y['polys'])) and torch.allclose(torch.tensor(x['pts']), torch.tensor(y['pts']))
+
+
+def test_validate_single_process_batches_and_writes_json(tmp_path):
+    args = make_args(use_char_window_prompt=True, output_folder=str(tmp_path))
+    for bs, ref_style in ((1, True), (3, True), (4, False)):
+        model = StubModel()
+        got = inf.validate(model, _loader(7, ref_style), 3, args, batch_size=bs)
+        _same(got, _expected(7, args))
+        assert len(model.calls) == -(-7 // bs)
+        if bs > 1:   # mixed sizes were padded and flagged
+            assert any(pad for _, pad in model.calls)
+        path = os.path.join(str(tmp_path), 'results', 'ep003', 'unit_val.json')
+        _same(json.load(open(path)), _expected(7, args))
+
+
+def test_predict_accepts_reference_nested_tensor():
+    args = make_args(use_char_window_prompt=True)
+    samples, targets = _loader(3)[2]
+    recs = inf.predict(StubModel(), samples, args, targets=targets)
+    assert len(recs) == 1
+    r = _fake(_key(samples.tensors[0], samples.mask[0]), False)
+    if r is not None:
+        _same(recs[0], inf.decode_pred_seq([t[0] for t in r[0]], r[1][0], targets[0], args))
+
+
+def test_validate_kie_writes_one_json_per_image(tmp_path):
+    args = make_args(use_char_window_prompt=True, output_folder=str(tmp_path), vie_categories=4, infer_vie=True, val_dataset=['sroie_val'])
+    got = inf.validate(StubModel(kie=True), _loader(6), 0, args, batch_size=2)
+    folder = os.path.join(str(tmp_path), 'results', 'ep000')
+    n_files = 0
+    for samples, targets in _loader(6):
+        r = _fake(_key(samples.tensors[0], samples.mask[0]), True)
+        path = os.path.join(folder, targets[0]['file_name'] + '.json')
+        if r is None:
+            assert not os.path.exists(path)      # the reference skips empty outputs (val.py:36-37)
+            continue
+        n_files += 1
+        assert json.load(open(path)) == json.loads(json.dumps(r))
+    assert len(got) == n_files
+
+
+def _worker(rank, world, port, folder, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    assert udist.init_distributed_mode(backend='gloo')
+    args = make_args(use_char_window_prompt=True, output_folder=folder)
+    model = StubModel()
+    got = inf.validate(model, _loader(7), 1, args, batch_size=2)
+    lo, hi = udist.shard_range(7, rank, world)
+    q.put((rank, len(got), sum(b for (b, _, _, _), _ in model.calls), hi - lo))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_validate_world2_gloo_shards_gathers_and_rank0_writes(tmp_path):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    args = make_args(use_char_window_prompt=True)
+    exp = _expected(7, args)
+    (r0, n0, imgs0, shard0), (r1, n1, imgs1, shard1) = got
+    assert (n0, n1) == (len(exp), 0)                       # only rank 0 returns / writes
+    assert (imgs0, imgs1) == (shard0, shard1) and shard0 + shard1 == 7   # every rank decoded exactly its shard
+    _same(json.load(open(os.path.join(str(tmp_path), 'results', 'ep001', 'unit_val.json'))), exp)

@@ -89,9 +89,39 @@ def bench_gemm(dtype=torch.bfloat16):
         ops.force_gemm_kernel(0)
 
 
+def bench_mlp(dtype=torch.bfloat16):
+    """Swin MLP per stage at B=8 1024x1024: LayerNorm + fc1(GELU) + fc2(+residual) as three launches vs omp_swin_mlp_fused."""
+    from advancedliteratemachinery_amd.model.packing import pack_mlp
+    for (M, C) in ((524288, 128), (131072, 256), (32768, 512)):
+        Hd = 4 * C
+        x = torch.randn(M, C, device=DEV).to(dtype)
+        g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        w1 = (torch.randn(Hd, C, device=DEV) / C ** 0.5).to(dtype)
+        w2 = (torch.randn(C, Hd, device=DEV) / Hd ** 0.5).to(dtype)
+        b1, b2 = torch.randn(Hd, device=DEV) * 0.1, torch.randn(C, device=DEV) * 0.1
+        pack = pack_mlp(w1, b1, w2)
+        y = torch.empty_like(x)
+        hbuf = torch.empty(M, Hd, device=DEV, dtype=dtype)
+        out = torch.empty_like(x)
+        fl = 2.0 * M * C * Hd * 2
+
+        def unfused():
+            ops.layernorm(x, g, b, out=y)
+            ops.gemm(y, w1, b1, act=ops.ACT_GELU, out=hbuf)
+            ops.gemm(hbuf, w2, b2, residual=x, out=out)
+        us = timeit(unfused, iters=10, warm=2)
+        print('mlp[C=%d] M=%d unfused (3 launches) : %8.1f us  %6.1f TF/s' % (C, M, us, fl / us / 1e6), flush=True)
+        for v in range(4 if C == 128 else (3 if C == 256 else 2)):
+            ops.swin_mlp_variant(v)
+            us = timeit(lambda: ops.swin_mlp_fused(x, g, b, pack, b2, out=out), iters=10, warm=2)
+            print('mlp[C=%d] M=%d fused v%d            : %8.1f us  %6.1f TF/s  %6.0f GB/s (x in + y out)'
+                  % (C, M, v, us, fl / us / 1e6, 2 * M * C * 2 / us / 1e3), flush=True)
+        ops.swin_mlp_variant(0)
+
+
 def bench_dec_gemm(dtype=torch.bfloat16):
     """decoder-step GEMMs: weight streaming at R = 8 rows (point decoder) and R = 512 (polygon / recognition)."""
-    for R, which in ((8, 0), (64, 0), (512, 2), (512, 6), (2048, 2), (2048, 6)):
+    for R, which in ((8, 0), (64, 0), (128, 0), (512, 6), (2048, 6), (8192, 6), (8192, 5)):
         ops.force_gemm_kernel(which if R > 64 else 0)
         for (N, K, ln) in ((1536, 512, 1), (512, 512, 0), (2048, 512, 1), (512, 2048, 0), (1104, 512, 0)):
             W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(dtype)
@@ -120,14 +150,15 @@ def bench_dec_gemm(dtype=torch.bfloat16):
 def bench_selfattn(dtype=torch.bfloat16):
     ops.force_gemm_kernel(0)
     d, nH = 512, 8
-    for (R, Lmax, pos) in ((8, 140, 70), (8, 140, 135), (512, 40, 20), (512, 40, 34), (2048, 40, 34)):
+    for (R, Lmax, pos) in ((8, 140, 70), (128, 140, 70), (128, 140, 135), (512, 40, 20), (512, 40, 34), (2048, 40, 34), (8192, 36, 17), (8192, 36, 34)):
         qkv = torch.randn(R, 3 * d, device=DEV).to(dtype)
         kc = torch.randn(R, Lmax, d, device=DEV).to(dtype)
         vc = torch.randn(R, Lmax, d, device=DEV).to(dtype)
         out = torch.empty(R, d, device=DEV, dtype=dtype)
         dp = torch.tensor([pos], dtype=torch.int32, device=DEV)
         us = timeit(lambda: ops.dec_self_attn_step(qkv, kc, vc, out, dp, nH), iters=100)
-        print('selfattn[%s] R=%-3d pos=%-3d : %6.1f us' % (str(dtype)[6:], R, pos, us), flush=True)
+        by = R * (pos + 1) * d * 2 * 2
+        print('selfattn[%s] R=%-4d pos=%-3d : %6.1f us  %6.0f GB/s' % (str(dtype)[6:], R, pos, us, by / us / 1e3), flush=True)
 
 
 def bench_misc(dtype=torch.bfloat16):
@@ -162,3 +193,5 @@ if __name__ == '__main__':
         bench_gemm()
     if 'misc' in what or 'all' in what:
         bench_misc()
+    if 'mlp' in what or 'all' in what:
+        bench_mlp()
