@@ -137,7 +137,27 @@ __global__ __launch_bounds__(256) void sine_pos_kernel(const uint8_t* __restrict
   }
 }
 
+__global__ __launch_bounds__(256) void mask_nearest_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int H,
+                                                           int W, int h, int w) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * h * w) return;
+  const int x = (int)(idx % w), y = (int)((idx / w) % h), b = (int)(idx / ((int64_t)w * h));
+  const float sy = (float)H / (float)h, sx = (float)W / (float)w;   // ATen: compute_scales_value<float>
+  int yy = (int)floorf((float)y * sy); if (yy > H - 1) yy = H - 1;
+  int xx = (int)floorf((float)x * sx); if (xx > W - 1) xx = W - 1;
+  out[idx] = in[((int64_t)b * H + yy) * W + xx] ? 1 : 0;
+}
+
 }  // namespace
+
+extern "C" int omp_mask_nearest(const uint8_t* in, uint8_t* out, int B, int H, int W, int h, int w, omp_stream_t s) {
+  OMP_CHECK_ARG(in && out, "omp_mask_nearest: null pointer");
+  OMP_CHECK_ARG(B > 0 && H > 0 && W > 0 && h > 0 && w > 0, "omp_mask_nearest: bad shape");
+  const int64_t total = (int64_t)B * h * w;
+  hipLaunchKernelGGL(mask_nearest_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)s, in, out, B, H, W, h, w);
+  OMP_CHECK_LAUNCH("omp_mask_nearest");
+  return OMP_OK;
+}
 
 extern "C" int omp_fpn_fuse(const void* l2, const void* l3, const void* l4, const void* l5, void* out,
                             int dtype, int B, int h2, int w2, int h3, int w3, int h4, int w4, int h5,

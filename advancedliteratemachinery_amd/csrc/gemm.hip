@@ -37,6 +37,7 @@ struct GemmP {
   const float* ln_g; const float* ln_b; float ln_eps;   // optional LayerNorm prologue (A is fp32)
   int store_mode; int bias_m;                           // OMP_STORE_*; bias indexed by m instead of n
   int kv_B, kv_tok, kv_mpad, kv_nH, kv_kb;              // blocked K / V^T destination geometry
+  void* C2; int64_t ldc2;                               // optional second destination without the residual
   unsigned long long* trace;                            // debug: per-workgroup phase timestamps (gemm_dma<..., TRACE>)
 };
 
@@ -381,6 +382,11 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
             if constexpr (decltype(ACT)::value == OMP_ACT_RELU) v[q] = fmaxf(v[q], 0.0f);
           }
           if (res != nullptr) {
+            if (p.C2 != nullptr) {   // memory and memory + pos from one product
+              typename Vec16<TOut>::type o2;
+              pack16(v, o2);
+              *reinterpret_cast<typename Vec16<TOut>::type*>(reinterpret_cast<TOut*>(p.C2) + m * p.ldc2 + n) = o2;
+            }
             float rv[CH];
             unpack16(rres[pass], rv);
 #pragma unroll
@@ -768,6 +774,14 @@ extern "C" int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s) {
   p.trans_out = a->trans_out; p.trans_rows = a->trans_rows; p.trans_ld = a->trans_ld; p.tiles_m = p.tiles_n = 0;
   p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.small_hint = a->small_m_splitk;
   p.store_mode = a->store_mode; p.bias_m = a->bias_along_m; p.trace = nullptr;
+  p.C2 = a->C2; p.ldc2 = a->ldc2;
+  if (p.C2 != nullptr) {
+    OMP_CHECK_ARG(a->residual != nullptr && a->store_mode == OMP_STORE_PLAIN && !a->trans_out && a->ln_gamma == nullptr && a->M > 64 &&
+                      a->N % (16 / (a->out_dtype == OMP_F32 ? 4 : 2)) == 0 && a->ldc2 % (16 / (a->out_dtype == OMP_F32 ? 4 : 2)) == 0 &&
+                      a->ldc % (16 / (a->out_dtype == OMP_F32 ? 4 : 2)) == 0 && a->ldr % (16 / (a->out_dtype == OMP_F32 ? 4 : 2)) == 0 &&
+                      ((uintptr_t)a->C2 % 16) == 0,
+                  "omp_gemm_bias_act: C2 needs a residual, a plain 16-byte-aligned destination, M > 64 and N a multiple of the 16-byte chunk");
+  }
   p.kv_B = a->kv_images; p.kv_tok = a->kv_tokens; p.kv_mpad = a->kv_mpad; p.kv_nH = a->kv_heads; p.kv_kb = a->kv_key_block;
   if (p.store_mode != OMP_STORE_PLAIN) {
     OMP_CHECK_ARG(p.store_mode == OMP_STORE_KBLK || p.store_mode == OMP_STORE_VBLK, "omp_gemm_bias_act: bad store_mode %d", p.store_mode);

@@ -11,7 +11,6 @@ Layout: activations stay token-major [B*H*W, C] in the engine dtype for the whol
 reference's NCHW permutes, window partition/reverse copies, rolls and pads never materialise.
 """
 import torch
-import torch.nn.functional as F
 
 from .. import ops
 from .packing import pack_mlp
@@ -116,8 +115,9 @@ class Encoder(object):
 
     @staticmethod
     def level_mask(mask, h, w):
-        """Padding mask at a feature level: nearest resize exactly as swin_transformer.py:621."""
-        return F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]
+        """Padding mask (uint8, 1 = padding) at a feature level: nearest resize exactly as swin_transformer.py:621."""
+        m8 = mask if mask.dtype == torch.uint8 else mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+        return ops.mask_nearest(m8.contiguous(), h, w)
 
     # -- full encode ----------------------------------------------------------------------------
     def encode(self, img, mask, want_intermediates=False):
@@ -139,13 +139,17 @@ class Encoder(object):
             src, ho, wo = feats[-1]
             lvl = (ho, wo)
         lm = self.level_mask(mask, *lvl)
-        pos = ops.sine_posembed(lm.to(torch.uint8).contiguous(), self.args.tfm_hidden_dim // 2, self.dtype)
+        pos = ops.sine_posembed(lm, self.args.tfm_hidden_dim // 2, self.dtype)
         M = ho * wo
         pos = pos.view(B * M, -1)
-        memory = ops.gemm(src, self.proj_w, self.proj_b)
-        mem_pos = ops.gemm(src, self.proj_w, self.proj_b, residual=pos)
-        out = dict(memory=memory, mem_pos=mem_pos, M=M, hw=(ho, wo), pos=pos,
-                   key_mask=lm.reshape(B, M).to(torch.uint8).contiguous())
+        # ONE product, two destinations: memory = src W^T + b and memory + pos (the key input of every decoder layer)
+        memory = torch.empty((B * M, self.proj_w.shape[0]), dtype=self.dtype, device=src.device)
+        if B * M > 64:
+            mem_pos = ops.gemm(src, self.proj_w, self.proj_b, residual=pos, out_noresidual=memory)
+        else:   # tiny inputs run on the small-M kernels, which have no second destination
+            ops.gemm(src, self.proj_w, self.proj_b, out=memory)
+            mem_pos = ops.gemm(src, self.proj_w, self.proj_b, residual=pos)
+        out = dict(memory=memory, mem_pos=mem_pos, M=M, hw=(ho, wo), pos=pos, key_mask=lm.reshape(B, M))
         if want_intermediates:
             out['feats'] = feats
             out['src'] = src

@@ -54,8 +54,9 @@ def layernorm(x, gamma, beta, out_dtype=None, out=None, out_f32=None, eps=1e-5, 
 
 def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None, M=None, lda=None,
          ldw=None, ldc=None, N=None, K=None, bias_row=None, bias_row_stride=0, trans_rows=0, trans_ld=0,
-         ln=None, ln_eps=1e-5, small_m=False, store_mode=0, kv=None, bias_along_m=False):
-    """out[M,N] = act(A[M,K] @ W[N,K]^T + bias) + residual.  A/W may be strided row views (lda/ldw)."""
+         ln=None, ln_eps=1e-5, small_m=False, store_mode=0, kv=None, bias_along_m=False, out_noresidual=None):
+    """out[M,N] = act(A[M,K] @ W[N,K]^T + bias) + residual.  A/W may be strided row views (lda/ldw).
+    out_noresidual (optional, with a residual): also receives act(A W^T + bias) without the residual."""
     K = K or A.shape[-1]
     N = N or W.shape[0]
     M = M or A.numel() // A.shape[-1]
@@ -81,6 +82,8 @@ def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     if kv is not None:  # (images, tokens per image, padded tokens, heads, key block) of the blocked K / V^T slabs
         a.kv_images, a.kv_tokens, a.kv_mpad, a.kv_heads, a.kv_key_block = kv
     a.trans_out, a.trans_rows, a.trans_ld = (1 if trans_rows else 0), trans_rows, trans_ld
+    if out_noresidual is not None:
+        a.C2, a.ldc2 = ptr(out_noresidual), out_noresidual.stride(-2)
     rc = _lib.lib().omp_gemm_bias_act(ctypes.byref(a), stream())
     _lib.check(rc, 'omp_gemm_bias_act')
     return out
@@ -140,6 +143,16 @@ def fpn_fuse(l2, l3, l4, l5, B, sizes, stride):
                                  h4, w4, h5, w5, stride, stream())
     _lib.check(rc, 'omp_fpn_fuse')
     return out, ho, wo
+
+
+def mask_nearest(mask_u8, h, w):
+    """uint8 [B,H,W] -> uint8 [B,h,w]: F.interpolate(..., mode='nearest') of the reference (swin_transformer.py:621)."""
+    _c(mask_u8, 'mask')
+    B, H, W = mask_u8.shape
+    out = torch.empty((B, h, w), dtype=torch.uint8, device=mask_u8.device)
+    rc = _lib.lib().omp_mask_nearest(ptr(mask_u8), ptr(out), B, H, W, h, w, stream())
+    _lib.check(rc, 'omp_mask_nearest')
+    return out
 
 
 def sine_posembed(mask_u8, npf, out_dtype, temperature=10000.0):

@@ -39,14 +39,28 @@ def get_size_with_aspect_ratio(image_size, size, max_size=None):
     return (oh, ow)
 
 
-def resize_coeffs(in_size, out_size):
-    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bilinear (triangle) filter over a whole axis,
-    vectorised over the output positions; every floating-point operation happens in the order Resample.c performs
-    it (double precision; the row sum is accumulated left to right), so the tables are bit-identical.
+def _filter_weights(a, filt):
+    """Resample.c bilinear_filter / bicubic_filter (a = -0.5) on an array of (already scaled) distances."""
+    a = np.abs(a)
+    if filt == 'bilinear':
+        return np.where(a < 1.0, 1.0 - a, 0.0)
+    if filt == 'bicubic':
+        c = -0.5
+        inner = ((c + 2.0) * a - (c + 3.0)) * a * a + 1
+        outer = (((a - 5) * a + 8) * a - 4) * c
+        return np.where(a < 1.0, inner, np.where(a < 2.0, outer, 0.0))
+    raise ValueError(filt)
+
+
+def resize_coeffs(in_size, out_size, filt='bilinear'):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bilinear (triangle, the OmniParser val transform) or
+    bicubic (MGP-STR's word-crop resize) filter over a whole axis, vectorised over the output positions; every
+    floating-point operation happens in the order Resample.c performs it (double precision; the row sum is accumulated
+    left to right), so the tables are bit-identical.
     -> (ksize, bounds int32 [out, 2] = (first source index, count), coefficients int32 [out, ksize])."""
     scale = float(np.float32(in_size) - np.float32(0.0)) / out_size
     filterscale = max(scale, 1.0)
-    support = 1.0 * filterscale
+    support = (1.0 if filt == 'bilinear' else 2.0) * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     ss = 1.0 / filterscale
     xx = np.arange(out_size, dtype=np.float64)
@@ -54,8 +68,7 @@ def resize_coeffs(in_size, out_size):
     xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)          # C (int) cast: truncation
     xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
     x = np.arange(ksize, dtype=np.int64)[None, :]
-    a = np.abs(((x + xmin[:, None]).astype(np.float64) - center[:, None] + 0.5) * ss)
-    w = np.where(a < 1.0, 1.0 - a, 0.0)
+    w = _filter_weights(((x + xmin[:, None]).astype(np.float64) - center[:, None] + 0.5) * ss, filt)
     w = np.where(x < xmax[:, None], w, 0.0)
     ww = np.zeros(out_size, dtype=np.float64)
     for j in range(ksize):                                                    # sequential, like the C loop
@@ -119,3 +132,58 @@ class DevicePreprocessor(object):
                                             oh, ow, Hm, Wm, ops.stream())
             _lib.check(rc, 'omp_resize_normalize_pad')
         return NestedTensor(out, mask.to(torch.bool)), sizes
+
+
+class CropResizer(object):
+    """Word crops for the recogniser: axis-aligned boxes of uint8 [H, W, 3] device images -> fp32
+    [N, 3, out_h, out_w] in [0, 1], exactly what MGP-STR's AlignCollate feeds its model for each crop
+    (OCR/MGP-STR/dataset.py:462: image.resize((imgW, imgH), Image.BICUBIC) then ToTensor), bit for bit: Pillow's
+    bicubic coefficient tables are built here, omp_resize_normalize_pad applies them to the crop in place (the
+    source pointer is offset to the box, the pitch stays the image's) -- no crop copy, no host round trip."""
+
+    def __init__(self, device, out_h=32, out_w=128, filt='bicubic'):
+        self.device = torch.device(device)
+        self.out_h, self.out_w, self.filt = out_h, out_w, filt
+        p = torch.arange(256, dtype=torch.uint8).to(torch.float32).div(255)     # ToTensor: p / 255 in float32
+        self.lut = p[None, :].expand(3, 256).contiguous().to(self.device)
+        self._tables = {}
+
+    def _axis(self, n_in, n_out):
+        key = (n_in, n_out)
+        if key not in self._tables:
+            if len(self._tables) > 4096:
+                self._tables.clear()
+            if n_in == n_out:
+                self._tables[key] = (0, None, None)
+            else:
+                ks, b, k = resize_coeffs(n_in, n_out, self.filt)
+                self._tables[key] = (ks, torch.from_numpy(b).to(self.device), torch.from_numpy(k).to(self.device))
+        return self._tables[key]
+
+    @torch.no_grad()
+    def __call__(self, images, boxes):
+        """images: list of uint8 [H, W, 3] device tensors; boxes: list of (image index, x0, y0, x1, y1) integer pixel
+        boxes (x1, y1 exclusive, already clipped, at least 1 x 1).  -> fp32 [N, 3, out_h, out_w]."""
+        N = len(boxes)
+        out = torch.empty(N, 3, self.out_h, self.out_w, dtype=torch.float32, device=self.device)
+        h = _lib.lib()
+        for n, (bi, x0, y0, x1, y1) in enumerate(boxes):
+            im = images[bi]
+            if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3 or not im.is_cuda or not im.is_contiguous():
+                raise ValueError('CropResizer takes contiguous uint8 [H, W, 3] device tensors')
+            cw, ch = x1 - x0, y1 - y0
+            if cw < 1 or ch < 1 or x0 < 0 or y0 < 0 or x1 > im.shape[1] or y1 > im.shape[0]:
+                raise ValueError('bad crop box %s for image %s' % ((x0, y0, x1, y1), tuple(im.shape)))
+            ksx, xb, kx = self._axis(cw, self.out_w)
+            ksy, yb, ky = self._axis(ch, self.out_h)
+            src = ctypes_ptr(im, (y0 * im.shape[1] + x0) * 3)
+            rc = h.omp_resize_normalize_pad(src, im.stride(0), ch, cw, ops.ptr(xb), ops.ptr(kx), ksx, ops.ptr(yb), ops.ptr(ky), ksy,
+                                            ops.ptr(self.lut), ops.ptr(out[n]), None, self.out_h, self.out_w, self.out_h, self.out_w,
+                                            ops.stream())
+            _lib.check(rc, 'omp_resize_normalize_pad')
+        return out
+
+
+def ctypes_ptr(t, byte_offset=0):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + byte_offset)

@@ -505,7 +505,7 @@ def main():
         recs = []
         if n_gemm:
             tf = f_gemm / (t_gemm / 1e3) / 1e12
-            recs.append((t_gemm, dict(bound='mfma', kernel='gemm_dma<128,128,2> (Swin qkv / proj / fc1 / fc2 / merge, FPN, input_proj, K-V projection)',
+            recs.append((t_gemm, dict(bound='mfma', kernel='gemm_256 + gemm_dma<128,128,2> (Swin qkv / proj / fc1 / fc2 / merge, FPN, input_proj, K-V projection)',
                                       achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None,
                                       launches=int(n_gemm), avg_us=t_gemm / n_gemm * 1e3, flops_per_launch=f_gemm / n_gemm,
                                       gpu_ms_per_image=t_gemm / (n_groups * BI))))

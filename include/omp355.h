@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 6
+#define OMP_ABI_VERSION 7
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -97,6 +97,11 @@ typedef struct {
   int32_t store_mode;
   int32_t bias_along_m; /* bias[m] instead of bias[n] */
   int32_t kv_images, kv_tokens, kv_mpad, kv_heads, kv_key_block;
+  /* optional second destination (plain row-major, pitch ldc2, same dtype as C): act(A W^T + bias) WITHOUT the residual.
+   * One GEMM then yields both `memory` and `memory + pos` of omniparser.py:31 / transformer.py:88-96 (the reference
+   * adds pos inside nn.MultiheadAttention's key path); requires a residual, OMP_STORE_PLAIN, no trans_out. */
+  void* C2;
+  int64_t ldc2;
 } omp_gemm_args;
 int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s);
 
@@ -144,6 +149,11 @@ int omp_patch_merge_gather_ln(const void* x, const float* gamma, const float* be
 int omp_fpn_fuse(const void* l2, const void* l3, const void* l4, const void* l5, void* out,
                  int dtype, int B, int h2, int w2, int h3, int w3, int h4, int w4, int h5, int w5,
                  int stride, omp_stream_t s);
+
+/* ---- Padding mask at a feature level: nearest-neighbour resize, exactly F.interpolate(mask[None].float(), size=(h, w))
+ * .to(torch.bool)[0] of swin_transformer.py:621 (source index = min(floor(dst * (float)H / h), H - 1)).
+ * in: uint8 [B,H,W] (1 = padding), out: uint8 [B,h,w]. */
+int omp_mask_nearest(const uint8_t* in, uint8_t* out, int B, int H, int W, int h, int w, omp_stream_t s);
 
 /* ---- Sine position embedding ---------------------------------------------------------------------
  * Replaces PositionEmbeddingSine.forward (normalize=True), backbone/position_embedding.py:24-44.

@@ -41,12 +41,33 @@ def get_size_with_aspect_ratio(image_size, size, max_size=None):
     return (oh, ow)
 
 
-def precompute_coeffs(in_size, out_size):
-    """Resample.c precompute_coeffs + normalize_coeffs_8bpc for the bilinear filter over the whole axis.
+def _bilinear(a):
+    a = -a if a < 0.0 else a
+    return 1.0 - a if a < 1.0 else 0.0
+
+
+def _bicubic(x):
+    """Resample.c bicubic_filter (a = -0.5), the filter MGP-STR's AlignCollate resizes word crops with
+    (OCR/MGP-STR/dataset.py:454,462: image.resize(..., Image.BICUBIC))."""
+    a = -0.5
+    x = -x if x < 0.0 else x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+FILTERS = {'bilinear': (_bilinear, 1.0), 'bicubic': (_bicubic, 2.0)}
+
+
+def precompute_coeffs(in_size, out_size, filt='bilinear'):
+    """Resample.c precompute_coeffs + normalize_coeffs_8bpc over the whole axis.
     -> (ksize, bounds int32 [out, 2] = (first source index, count), kk int32 [out, ksize])."""
+    fn, fsupport = FILTERS[filt]
     scale = float(np.float32(in_size) - np.float32(0.0)) / out_size
     filterscale = max(scale, 1.0)
-    support = 1.0 * filterscale
+    support = fsupport * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     bounds = np.zeros((out_size, 2), dtype=np.int32)
     kk = np.zeros((out_size, ksize), dtype=np.int32)
@@ -63,9 +84,7 @@ def precompute_coeffs(in_size, out_size):
         k = np.zeros(ksize, dtype=np.float64)
         ww = 0.0
         for x in range(xmax):
-            a = (x + xmin - center + 0.5) * ss
-            a = -a if a < 0.0 else a
-            w = 1.0 - a if a < 1.0 else 0.0
+            w = fn((x + xmin - center + 0.5) * ss)
             k[x] = w
             ww += w
         if ww != 0.0:
@@ -83,12 +102,17 @@ def _clip8(acc):
 
 def resize_bilinear_u8(img, oh, ow):
     """img uint8 [H, W, C] -> uint8 [oh, ow, C], bit-identical to PIL.Image.fromarray(img).resize((ow, oh), BILINEAR)."""
+    return resize_u8(img, oh, ow, 'bilinear')
+
+
+def resize_u8(img, oh, ow, filt='bilinear'):
+    """Pillow's two-pass 8-bit resampler with the given filter ('bilinear' | 'bicubic')."""
     H, W, _ = img.shape
     if (H, W) == (oh, ow):
         return img.copy()          # Image.resize returns a copy when nothing changes
     need_h, need_v = ow != W, oh != H
-    _, bh, kh = precompute_coeffs(W, ow)
-    _, bv, kv = precompute_coeffs(H, oh)
+    _, bh, kh = precompute_coeffs(W, ow, filt)
+    _, bv, kv = precompute_coeffs(H, oh, filt)
     src = img.astype(np.int64)
     half = 1 << (PRECISION_BITS - 1)
     if need_h:

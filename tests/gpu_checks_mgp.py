@@ -171,3 +171,69 @@ def check_mgp_b512(dtype_name='fp32', B=512, probe=(0, 1, 63, 64, 255, 256, 300,
     for name, a, b in zip(('char', 'bpe', 'wp'), att, ratt):
         out.append(rec('mgp_b%d[%s] %s attention maps' % (B, dtype_name, name), maxerr(a.float().cpu()[idx], b), 2e-5 if f32 else 2e-2))
     return out
+
+
+def check_two_stage():
+    """SURVEY 8f row 4 end to end in fp32: uint8 images -> device pre-processing -> OmniParser -> polygon boxes -> device
+    bicubic crops -> MGP-STR -> fused decoding, against the oracle chain built from the reference's pieces and the real
+    Pillow (oracle/two_stage_ref.py).  Demands identical boxes, identical greedy ids of all three heads, identical fused
+    choice, confidences within 1e-4."""
+    import numpy as np
+    from advancedliteratemachinery_amd.engine.two_stage import spot_and_recognize
+    from advancedliteratemachinery_amd.utils.parser import make_args
+    from oracle import two_stage_ref as T
+    from oracle import weights
+    from tests.gpu_checks import build_model
+    depths = (2, 2, 2, 2)
+    args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=6, test_min_size=64, test_max_size=112)
+    sd = weights.make_state_dict(args, seed=5, depths=depths)
+    omni = build_model(args, sd, depths, torch.float32)
+    c = R.cfg(depth=2)
+    sdm = R.make_state_dict(c, seed=17)
+    mgp = build(c, sdm, torch.float32)
+    rng = np.random.RandomState(3)
+    images = [rng.randint(0, 256, (90, 140, 3), dtype=np.uint8), rng.randint(0, 256, (70, 100, 3), dtype=np.uint8)]
+    got, _, _ = spot_and_recognize(omni, mgp, [torch.from_numpy(i) for i in images], args)
+    want = T.chain(sd, args, depths, sdm, c, images, args.test_min_size, args.test_max_size)
+    out = []
+    n_words = 0
+    for b, (g, w) in enumerate(zip(got, want)):
+        out.append(rec('two_stage img%d: detections' % b, abs(len(g) - len(w)), 0, '%d vs %d' % (len(g), len(w))))
+        for i, (rg, rw) in enumerate(zip(g, w)):
+            n_words += 1
+            tag = 'two_stage img%d word%d' % (b, i)
+            out.append(rec(tag + ' box', 0 if tuple(rg['box']) == tuple(rw['box']) else 1, 0, '%s vs %s' % (rg['box'], rw['box'])))
+            # the OmniParser record itself (predict_images -> decode_pred_seq, engine/val.py:70-100) against the oracle's
+            out.append(rec(tag + ' polygon (original-image pixels)', (torch.tensor(rg['polys']) - torch.tensor(rw['polys'])).abs().max().item(), 1e-3))
+            chars = []
+            for t in rw['rec_ids']:
+                if t == args.recog_pad_index or t == args.rec_eos_index:
+                    break
+                if t == args.recog_pad_index - 1:
+                    continue
+                chars.append(args.chars[t - args.num_bins])
+            out.append(rec(tag + ' OmniParser text', 0 if rg['rec'] == ''.join(chars) else 1, 0, '%r' % rg['rec']))
+            for k in ('char', 'bpe', 'wp'):
+                out.append(rec(tag + ' %s ids' % k, sum(int(x != y) for x, y in zip(rg['mgp_ids'][k], rw[k + '_ids'])), 0))
+            out.append(rec(tag + ' choice', 0 if rg['mgp_choice'] == rw['choice'] else 1, 0))
+            out.append(rec(tag + ' confidences', max(abs(x - y) for x, y in zip(rg['mgp_conf'], rw['conf'])), 1e-4))
+            out.append(rec(tag + ' text', 0 if rg['mgp_text'] == rw['char_text'] else 1, 0))
+    out.append(rec('two_stage: words recognised', 0 if n_words > 0 else 1, 0, '%d words' % n_words))
+    return out
+
+
+def check_crop_resizer():
+    """device bicubic crops == PIL crop + resize(BICUBIC) + ToTensor, every float equal"""
+    import numpy as np
+    from PIL import Image
+    from advancedliteratemachinery_amd.utils.preprocess import CropResizer
+    rng = np.random.RandomState(9)
+    imgs = [rng.randint(0, 256, (120, 200, 3), dtype=np.uint8), rng.randint(0, 256, (64, 48, 3), dtype=np.uint8)]
+    boxes = [(0, 0, 0, 200, 120), (0, 17, 5, 150, 37), (0, 100, 60, 101, 61), (1, 3, 2, 47, 60), (1, 0, 0, 48, 64), (0, 10, 10, 138, 42)]
+    cr = CropResizer(DEV)
+    got = cr([torch.from_numpy(i).to(DEV) for i in imgs], boxes).cpu()
+    worst = 0.0
+    for n, (bi, x0, y0, x1, y1) in enumerate(boxes):
+        ref = np.asarray(Image.fromarray(imgs[bi]).crop((x0, y0, x1, y1)).resize((128, 32), Image.BICUBIC)).astype(np.float32) / np.float32(255.0)
+        worst = max(worst, float((got[n] - torch.from_numpy(ref).permute(2, 0, 1)).abs().max()))
+    return [rec('crop_resizer == Pillow bicubic', worst, 0.0)]

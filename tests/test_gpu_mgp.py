@@ -42,3 +42,12 @@ def test_mgp_golden_fp32(C):
 def test_mgp_batch512_config5(C, dtype):
     """BASELINE config 5 at its stated shape (ViT-B, batch 512) against the oracle on probe rows."""
     _assert_all(C.check_mgp_b512(dtype))
+
+
+def test_crop_resizer_bit_exact_with_pillow(C):
+    _assert_all(C.check_crop_resizer())
+
+
+def test_two_stage_pipeline_matches_oracle_chain(C):
+    """OmniParser detections -> device crops -> MGP-STR -> fused decoding."""
+    _assert_all(C.check_two_stage())
