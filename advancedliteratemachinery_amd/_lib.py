@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
@@ -71,6 +71,8 @@ _SIGS = {
     'omp_debug_swin_mlp_trace': (c_int, [c_void_p]),
     'omp_patch_embed_ln': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p]),
     'omp_swin_window_attn': (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
+    'omp_swin_window_attn2': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    'omp_swin_expand_bias': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     'omp_patch_merge_gather_ln': (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_void_p]),
     'omp_fpn_fuse': (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p]),
     'omp_mask_nearest': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -89,6 +91,7 @@ _SIGS = {
     'omp_debug_set_gemm_trace': (c_int, [c_void_p, c_int64]),
     'omp_debug_swin_attn_impl': (c_int, [c_int]),
     'omp_debug_cross_q4': (c_int, [c_int]),
+    'omp_debug_cross_nt': (c_int, [c_int]),
     'omp_vit_patch_embed': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     'omp_a3_pool': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_row_argmax_prob': (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -254,7 +254,7 @@ __device__ __forceinline__ void wait_dma_blocks(int blocks) {
   }
 }
 
-template <typename T, int NW, int QT, int PD>
+template <typename T, int NW, int QT, int PD, bool NT = false>
 __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
   typedef Mma<T> MM;
   typedef CrossTraits<T> CT;
@@ -280,15 +280,20 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
   const uint8_t* km = p.kmask ? p.kmask + (int64_t)img * p.M : nullptr;
 
   frag kr[PD][NKF], vr[PD][4];
+  // the K / V^T slabs are streamed exactly once per launch: NT = non-temporal loads (no L2 / MALL allocation)
+  auto ldkv = [](const T* ptr) -> frag {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const frag*>(ptr));
+    else return ld16<T>(ptr);
+  };
   auto load_block = [&](int k0, frag* kf, frag* vf) {
     const T* kp = Kb + (int64_t)k0 * 64;
 #pragma unroll
     for (int sb = 0; sb < CT::NSB; ++sb)
 #pragma unroll
-      for (int s = 0; s < CT::DSTEPS; ++s) kf[sb * CT::DSTEPS + s] = ld16<T>(kp + sb * 16 * 64 + s * MM::KSTEP);
+      for (int s = 0; s < CT::DSTEPS; ++s) kf[sb * CT::DSTEPS + s] = ldkv(kp + sb * 16 * 64 + s * MM::KSTEP);
     const T* vp = Vb + (int64_t)k0 * 64;   // block k0/KB starts at element (k0/KB) * 64 * KB = k0 * 64
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) vf[dt] = ld16<T>(vp + dt * 16 * KB);
+    for (int dt = 0; dt < 4; ++dt) vf[dt] = ldkv(vp + dt * 16 * KB);
   };
   // the K/V stream depends on nothing computed here: put PD key blocks in flight before touching Q
 #pragma unroll
@@ -685,11 +690,13 @@ __global__ void advance_pos_kernel(int32_t* d_pos) { *d_pos += 1; }
 // optional hipEvent bracketing of the cross-attention kernel (bench.py's roofline measurement)
 thread_local bool g_capturing = false;   // one host thread per pipeline lane may be capturing
 
-template <typename T, int QT, int PD>
+int g_cross_nt = 1;   // non-temporal K / V^T loads in the 1-query-tile kernel (+3-5 %, profiles/r02j_kbench_cross128.txt); omp_debug_cross_nt(0) = plain
+
+template <typename T, int QT, int PD, bool NT = false>
 int launch_cross_t(const CrossP& cp, int n_groups, int S, hipStream_t st) {
   constexpr int NW = 4;
   const size_t smem = (size_t)NW * QT * 16 * CROSS_PSTR * sizeof(float);
-  auto kern = dec_cross_attn_kernel<T, NW, QT, PD>;
+  auto kern = dec_cross_attn_kernel<T, NW, QT, PD, NT>;
   if (smem > 48 * 1024) {
     static bool done = false;   // per template instantiation
     if (!done) {
@@ -757,7 +764,7 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   const bool f = dtype == OMP_F32;
   // PD key blocks in flight per wave: with one query tile a wave's whole slice is usually 4 blocks -> all of it
   if (q4) rc = launch_cross_q4<8>(cp, n_groups, S, st);
-  else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st);
+  else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : (g_cross_nt ? launch_cross_t<bf16_t, 1, 4, true>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st));
   else if (qt == 2) rc = f ? launch_cross_t<float, 2, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 2, 2>(cp, n_groups, S, st);
   else rc = f ? launch_cross_t<float, 4, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 4, 2>(cp, n_groups, S, st);
   if (rc != OMP_OK) return rc;
@@ -940,6 +947,11 @@ int sample_and_advance(const omp_decoder_plan* P, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int omp_debug_cross_nt(int on) {
+  g_cross_nt = on ? 1 : 0;
+  return OMP_OK;
+}
 
 extern "C" int omp_debug_cross_q4(int on) {
   g_cross_q4 = on ? 1 : 0;

@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256) void swin_attn_kernel(const T* __restrict__ qk
   const bool qvalid = py < H && px < W;
   const int64_t tok = ((int64_t)b * H + py) * W + px;
   const float scale = 0.17677669529663687f;  // 32^-0.5
+  const float scale2 = 0.17677669529663687f * 1.4426950408889634f;   // scale * log2(e): base-2 softmax (EXPB)
+  // SW-MSA: only the last window row / column of the padded grid mixes regions (swin_transformer.py:369-387)
+  const bool edge = shift > 0 && (wy == nWy - 1 || wx == nWx - 1);
   float q[HD];
   if (qvalid) {
     const T* row = qkv + tok * C3 + head * HD;
@@ -201,8 +204,13 @@ struct SwinTraits<float> {
   __device__ static __forceinline__ f32x4 pfrag(const float* a, const float*) { return f32x4{a[0], a[1], a[2], a[3]}; }
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const T* __restrict__ qkv,
+// EXPB: the relative-position bias arrives EXPANDED per head as fp32 [64 queries][64 keys] (omp_swin_expand_bias: bias / scale,
+// -inf on the 15 padding key slots), so it seeds the S^T accumulators as 16-byte loads instead of 64 per-score table
+// lookups; the softmax then runs in base 2 (one v_exp_f32 per score) and the SW-MSA mask arithmetic is skipped for the
+// interior windows, whose tokens all sit in region 0.  (Round 1 measured this kernel at 0.29 of the HBM roofline with
+// ~2000 VALU / LDS instructions per (window, head); these three changes remove about half of them.)
+template <typename T, bool EXPB>
+__global__ __launch_bounds__(256, (EXPB && sizeof(T) == 2) ? 4 : 2) void swin_attn_mfma_kernel(const T* __restrict__ qkv,
                                                               const float* __restrict__ qkv_bias,
                                                               const float* __restrict__ table,
                                                               T* __restrict__ out, int B, int H, int W, int C,
@@ -236,13 +244,20 @@ __global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const T* __restrict
     return (py < H && px < W) ? ((int64_t)b * H + py) * W + px : (int64_t)-1;
   };
   // 16 bytes of q (sel 0) / k (1) / v (2) of token tok at head dims [d0, d0 + NV)
+  // Windows without padding tokens (all but the last window row / column of an image whose size is not a multiple of
+  // 7) take none of the bias-substitution code: the test is wave-uniform (the whole window is real or not).
+  const int sy_hi = wy * WS + WS - 1 + shift, sx_hi = wx * WS + WS - 1 + shift;
+  const bool all_real = (sy_hi < Hp ? sy_hi : Hp - 1) < H && (sx_hi < Wp ? sx_hi : Wp - 1) < W;
   auto load_chunk = [&](int64_t tok, int sel, int d0) -> frag {
-    if (tok >= 0) return ld16<T>(qkv + tok * C3 + sel * C + head * HD + d0);
-    float t[NV];
+    frag f = ld16<T>(qkv + (tok >= 0 ? tok : 0) * C3 + sel * C + head * HD + d0);
+    if (!all_real) {
+      if (tok < 0) {
+        float t[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) t[i] = qkv_bias[sel * C + head * HD + d0 + i];
-    frag f;
-    pack16(t, f);
+        for (int i = 0; i < NV; ++i) t[i] = qkv_bias[sel * C + head * HD + d0 + i];
+        pack16(t, f);
+      }
+    }
     return f;
   };
 
@@ -281,7 +296,15 @@ __global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const T* __restrict
       pack16(z, vchunk[it]);
     }
   }
-  for (int idx = lane; idx < 169; idx += 64) tab[wave][idx] = table[idx * nH + head];
+  // expanded bias of query tile t4 (4 key tiles): requested one query tile ahead, 2 x 16 registers instead of 64
+  const float* be = table + (int64_t)head * 4096 + li * 64 + g * 4;   // [query][key] of this head (EXPB)
+  f32x4 bnext[4];
+  if constexpr (EXPB) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) bnext[kt] = *reinterpret_cast<const f32x4*>(be + kt * 16);
+  } else {
+    for (int idx = lane; idx < 169; idx += 64) tab[wave][idx] = table[idx * nH + head];
+  }
 
   // ---- V^T -> LDS -----------------------------------------------------------------------------------
 #pragma unroll
@@ -294,6 +317,9 @@ __global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const T* __restrict
 
   // ---- S^T = K Q^T; the reference's q * scale (swin_transformer.py:130) is applied to the fp32 products ----
   const float scale = 0.17677669529663687f;  // 32^-0.5
+  const float scale2 = 0.17677669529663687f * 1.4426950408889634f;   // scale * log2(e): base-2 softmax (EXPB)
+  // SW-MSA: only the last window row / column of the padded grid mixes regions (swin_transformer.py:369-387)
+  const bool edge = shift > 0 && (wy == nWy - 1 || wx == nWx - 1);
   // per-lane key geometry: acc[r] of key tile kt is key j = kt*16 + 4g + r
   int kty[16], ktx[16], krid[16];
 #pragma unroll
@@ -304,7 +330,7 @@ __global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const T* __restrict
       const int ty = (j * 37) >> 8, tx = j - ty * WS;
       kty[kt * 4 + r] = ty; ktx[kt * 4 + r] = tx;
       int rid = 0;
-      if (shift > 0) {
+      if (EXPB ? edge : shift > 0) {
         const int ssy = wy * WS + ty, ssx = wx * WS + tx;
         const int ry = ssy < Hp - WS ? 0 : (ssy < Hp - shift ? 1 : 2);
         const int rx = ssx < Wp - WS ? 0 : (ssx < Wp - shift ? 1 : 2);
@@ -326,27 +352,43 @@ __global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const T* __restrict
     const int i = t4 * 16 + li;
     const int ity = (i * 37) >> 8, itx = i - ity * WS;
     int rid_i = 0;
-    if (shift > 0) {
+    if (EXPB ? edge : shift > 0) {
       const int ry = qsy[t4] < Hp - WS ? 0 : (qsy[t4] < Hp - shift ? 1 : 2);
       const int rx = qsx[t4] < Wp - WS ? 0 : (qsx[t4] < Wp - shift ? 1 : 2);
       rid_i = ry * 3 + rx;
     }
     float sc[16];
     float mx = -INFINITY;
+    f32x4 bcur[4];
+    if constexpr (EXPB) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) bcur[kt] = bnext[kt];
+      if (t4 < 3) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) bnext[kt] = *reinterpret_cast<const f32x4*>(be + (t4 + 1) * 16 * 64 + kt * 16);
+      }
+    }
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       f32x4 st = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (EXPB) st = bcur[kt];
 #pragma unroll
       for (int s = 0; s < ST::QS; ++s) MM::mma(st, kf[kt][s], qf[t4][s]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = kt * 16 + g * 4 + r;
-        float a = st[r] * scale;
-        if (j < WT && i < WT) {
-          a += tab[wave][(ity - kty[kt * 4 + r] + WS - 1) * (2 * WS - 1) + (itx - ktx[kt * 4 + r] + WS - 1)];
-          if (shift > 0 && krid[kt * 4 + r] != rid_i) a += -100.0f;
-        } else if (j >= WT) {
-          a = -INFINITY;
+        float a;
+        if constexpr (EXPB) {
+          a = st[r] * scale2;   // (q.k + bias / scale) * scale * log2 e; padding keys are -inf through the seed
+          if (edge && krid[kt * 4 + r] != rid_i) a += -100.0f * 1.4426950408889634f;
+        } else {
+          a = st[r] * scale;
+          if (j < WT && i < WT) {
+            a += tab[wave][(ity - kty[kt * 4 + r] + WS - 1) * (2 * WS - 1) + (itx - ktx[kt * 4 + r] + WS - 1)];
+            if (shift > 0 && krid[kt * 4 + r] != rid_i) a += -100.0f;
+          } else if (j >= WT) {
+            a = -INFINITY;
+          }
         }
         sc[kt * 4 + r] = a;
         mx = fmaxf(mx, a);
@@ -356,7 +398,11 @@ __global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const T* __restrict
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float l = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { sc[k] = expf(sc[k] - mx); l += sc[k]; }
+    for (int k = 0; k < 16; ++k) {
+      if constexpr (EXPB) sc[k] = __builtin_amdgcn_exp2f(sc[k] - mx);
+      else sc[k] = expf(sc[k] - mx);
+      l += sc[k];
+    }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
@@ -393,14 +439,43 @@ __global__ __launch_bounds__(256) void swin_attn_mfma_kernel(const T* __restrict
   }
 }
 
-int g_swin_impl = 0;   // 0 = matrix cores, 1 = scalar cross-check kernel
+int g_swin_impl = 0;   // 0 = matrix cores, 1 = scalar cross-check kernel, 2 = matrix cores with per-score table lookups (round-1 path)
+
+// relative_position_bias_table [169, nH] -> per head [64 queries][64 keys] fp32: bias[(dy + 6) * 13 + (dx + 6)] / scale for
+// real tokens, -inf for the 15 padding key slots, 0 for padding query rows (never stored)
+__global__ __launch_bounds__(256) void swin_expand_bias_kernel(const float* __restrict__ table, float* __restrict__ out, int nH) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nH * 4096) return;
+  const int j = idx & 63, i = (idx >> 6) & 63, h = idx >> 12;
+  float v;
+  if (j >= WT) v = -INFINITY;
+  else if (i >= WT) v = 0.f;
+  else {
+    const int iy = i / WS, ix = i % WS, jy = j / WS, jx = j % WS;
+    v = table[((iy - jy + WS - 1) * (2 * WS - 1) + (ix - jx + WS - 1)) * nH + h] / 0.17677669529663687f;
+  }
+  out[idx] = v;
+}
 
 }  // namespace
+
+extern "C" int omp_swin_expand_bias(const float* rel_bias_table, int nH, float* out, omp_stream_t s) {
+  OMP_CHECK_ARG(rel_bias_table && out && nH > 0, "omp_swin_expand_bias: bad arguments");
+  hipLaunchKernelGGL(swin_expand_bias_kernel, dim3((nH * 4096 + 255) / 256), dim3(256), 0, (hipStream_t)s, rel_bias_table, out, nH);
+  OMP_CHECK_LAUNCH("omp_swin_expand_bias");
+  return OMP_OK;
+}
 
 extern "C" int omp_swin_window_attn(const void* qkv, const float* qkv_bias, const float* rel_bias_table,
                                     void* out, int dtype, int B, int H, int W, int C, int nH, int window,
                                     int shift, omp_stream_t s) {
-  OMP_CHECK_ARG(qkv && qkv_bias && rel_bias_table && out, "omp_swin_window_attn: null pointer");
+  return omp_swin_window_attn2(qkv, qkv_bias, rel_bias_table, nullptr, out, dtype, B, H, W, C, nH, window, shift, s);
+}
+
+extern "C" int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, const float* rel_bias_table,
+                                     const float* bias_expanded, void* out, int dtype, int B, int H, int W, int C, int nH,
+                                     int window, int shift, omp_stream_t s) {
+  OMP_CHECK_ARG(qkv && qkv_bias && (rel_bias_table || bias_expanded) && out, "omp_swin_window_attn: null pointer");
   OMP_CHECK_ARG(window == WS, "omp_swin_window_attn: only window 7 is built (got %d)", window);
   OMP_CHECK_ARG(shift >= 0 && shift < WS, "omp_swin_window_attn: bad shift %d", shift);
   OMP_CHECK_ARG(nH > 0 && C == nH * HD, "omp_swin_window_attn: head_dim must be 32 (C=%d nH=%d)", C, nH);
@@ -416,18 +491,22 @@ extern "C" int omp_swin_window_attn(const void* qkv, const float* qkv_bias, cons
       hipLaunchKernelGGL((swin_attn_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv,
                          qkv_bias, rel_bias_table, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx);
   } else {
-    if (dtype == OMP_F32)
-      hipLaunchKernelGGL((swin_attn_mfma_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv,
-                         qkv_bias, rel_bias_table, (float*)out, B, H, W, C, nH, shift, nWy, nWx);
-    else
-      hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv,
-                         qkv_bias, rel_bias_table, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx);
+    const bool expb = bias_expanded != nullptr && g_swin_impl != 2;
+    OMP_CHECK_ARG(expb || rel_bias_table != nullptr, "omp_swin_window_attn: the table form of the bias is needed for this path");
+    const float* tb = expb ? bias_expanded : rel_bias_table;
+    if (dtype == OMP_F32) {
+      if (expb) hipLaunchKernelGGL((swin_attn_mfma_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx);
+      else hipLaunchKernelGGL((swin_attn_mfma_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx);
+    } else {
+      if (expb) hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, qkv_bias, tb, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx);
+      else hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, qkv_bias, tb, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx);
+    }
   }
   OMP_CHECK_LAUNCH("omp_swin_window_attn");
   return OMP_OK;
 }
 
 extern "C" int omp_debug_swin_attn_impl(int which) {
-  g_swin_impl = which == 1 ? 1 : 0;
+  g_swin_impl = (which == 1 || which == 2) ? which : 0;
   return OMP_OK;
 }

@@ -23,7 +23,7 @@ FUSED_MLP_WIDTHS = (128, 256)
 
 class _Block(object):
     __slots__ = ('n1g', 'n1b', 'qkv_w', 'qkv_b', 'table', 'proj_w', 'proj_b', 'n2g', 'n2b', 'fc1_w',
-                 'fc1_b', 'fc2_w', 'fc2_b', 'shift', 'mlp_pack')
+                 'fc1_b', 'fc2_w', 'fc2_b', 'shift', 'mlp_pack', 'bias_exp')
 
 
 class _Stage(object):
@@ -59,6 +59,7 @@ class Encoder(object):
                 blk.n1g, blk.n1b = f32(p + 'norm1.weight'), f32(p + 'norm1.bias')
                 blk.qkv_w, blk.qkv_b = mat(p + 'attn.qkv.weight'), f32(p + 'attn.qkv.bias')
                 blk.table = f32(p + 'attn.relative_position_bias_table')
+                blk.bias_exp = ops.swin_expand_bias(blk.table)   # gathered once (the reference re-gathers table[index] per call)
                 blk.proj_w, blk.proj_b = mat(p + 'attn.proj.weight'), f32(p + 'attn.proj.bias')
                 blk.n2g, blk.n2b = f32(p + 'norm2.weight'), f32(p + 'norm2.bias')
                 blk.fc1_w, blk.fc1_b = mat(p + 'mlp.fc1.weight'), f32(p + 'mlp.fc1.bias')
@@ -98,7 +99,7 @@ class Encoder(object):
                 y = ops.layernorm(x, blk.n1g, blk.n1b, eps=LN_EPS)
                 qkv = ops.gemm(y, blk.qkv_w, blk.qkv_b)
                 att = ops.swin_window_attn(qkv, blk.qkv_b, blk.table, B, H, W, C, st.nH, blk.shift, out=y,
-                                           window=self.window)
+                                           window=self.window, bias_expanded=blk.bias_exp)
                 ops.gemm(att, blk.proj_w, blk.proj_b, residual=x, out=x)
                 if blk.mlp_pack is not None:   # norm2 + fc1 + GELU + fc2 + residual in one launch, in place
                     ops.swin_mlp_fused(x, blk.n2g, blk.n2b, blk.mlp_pack, blk.fc2_b, out=x, eps=LN_EPS)

@@ -326,7 +326,9 @@ class Decoder(object):
         S = 1
         while S < 16 and 4 * S * per_wave < M:
             S *= 2
-        while S > 1 and len(groups) * self.nH * S > 4096:
+        # ~4 workgroups per CU are enough to saturate HBM (profiles/r02j_kbench_cross128.txt: 128 images x 8 heads at
+        # S = 1 stream at 6.1-6.3 TB/s); beyond that a split only adds the partial buffer and the merge launch
+        while S > 1 and len(groups) * self.nH * S > 1024:
             S //= 2
         return S
 

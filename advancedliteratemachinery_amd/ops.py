@@ -115,12 +115,20 @@ def patch_embed_ln(img, w, b, gamma, beta, out_dtype, eps=1e-5):
     return out, Hp, Wp
 
 
-def swin_window_attn(qkv, qkv_bias, table, B, H, W, C, nH, shift, out=None, window=7):
+def swin_expand_bias(table):
+    """relative_position_bias_table fp32 [169, nH] -> fp32 [nH, 64, 64] (bias / scale, -inf on padding keys), once per checkpoint."""
+    nH = table.shape[1]
+    out = torch.empty((nH, 64, 64), dtype=torch.float32, device=table.device)
+    _lib.check(_lib.lib().omp_swin_expand_bias(ptr(_c(table, 'table')), nH, ptr(out), stream()), 'omp_swin_expand_bias')
+    return out
+
+
+def swin_window_attn(qkv, qkv_bias, table, B, H, W, C, nH, shift, out=None, window=7, bias_expanded=None):
     _c(qkv, 'qkv')
     if out is None:
         out = torch.empty((B * H * W, C), dtype=qkv.dtype, device=qkv.device)
-    rc = _lib.lib().omp_swin_window_attn(ptr(qkv), ptr(qkv_bias), ptr(table), ptr(out), dt(qkv), B, H, W, C,
-                                         nH, window, shift, stream())
+    rc = _lib.lib().omp_swin_window_attn2(ptr(qkv), ptr(qkv_bias), ptr(table), ptr(bias_expanded), ptr(out), dt(qkv), B, H, W, C,
+                                          nH, window, shift, stream())
     _lib.check(rc, 'omp_swin_window_attn')
     return out
 
@@ -241,7 +249,7 @@ def cross_q4(on):
 
 
 def swin_attn_impl(which):
-    """debug/testing: 0 = matrix-core window attention (default), 1 = scalar cross-check kernel."""
+    """debug/testing: 0 = matrix-core window attention (default), 1 = scalar cross-check kernel, 2 = matrix cores with table lookups."""
     _lib.check(_lib.lib().omp_debug_swin_attn_impl(which), 'omp_debug_swin_attn_impl')
 
 

@@ -70,7 +70,7 @@ def parse():
     p.add_argument('--overlap', type=int, default=1, help='polygon || recognition decoders on two streams')
     p.add_argument('--lanes', type=int, default=int(os.environ.get('OMP355_LANES', '2')),
                    help='step groups in flight per GPU (engine/pipeline.py): they overlap on separate HIP streams')
-    p.add_argument('--coalesce', type=int, default=int(os.environ.get('OMP355_COALESCE', '16')),
+    p.add_argument('--coalesce', type=int, default=int(os.environ.get('OMP355_COALESCE', '32')),
                    help='consecutive steps (batches of --batch images) merged into one engine call: the decoders then '
                         'advance coalesce*batch images per launch (dynamic batching across steps); 1 = every step alone; '
                         'capped at ceil(steps / lanes) so that every lane gets work')

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 7
+#define OMP_ABI_VERSION 8
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -134,6 +134,12 @@ int omp_patch_embed_ln(const float* img, const float* w, const float* b, const f
 int omp_swin_window_attn(const void* qkv, const float* qkv_bias, const float* rel_bias_table,
                          void* out, int dtype, int B, int H, int W, int C, int nH, int window,
                          int shift, omp_stream_t s);
+/* The same with the relative-position bias EXPANDED once per checkpoint (swin_transformer.py:133-135 re-gathers
+ * table[index] on every call): bias_expanded fp32 [nH][64][64] from omp_swin_expand_bias (bias / scale per (query, key),
+ * -inf on the padding key slots); rel_bias_table may then be NULL. */
+int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, const float* rel_bias_table, const float* bias_expanded,
+                          void* out, int dtype, int B, int H, int W, int C, int nH, int window, int shift, omp_stream_t s);
+int omp_swin_expand_bias(const float* rel_bias_table, int nH, float* out, omp_stream_t s);
 
 /* ---- PatchMerging gather + LayerNorm(4C) ------------------------------------------------------------
  * Replaces swin_transformer.py:281-293 (pad to even, 2x2 gather in order (0,0),(1,0),(0,1),(1,1),
@@ -316,7 +322,8 @@ int omp_debug_force_gemm_kernel(int which);
 /* development: device buffer uint64 [n_workgroups][8] that omp_debug_force_gemm_kernel(15) fills with s_memtime stamps
  * per workgroup: 0 start, 1 first K tile landed, 2 K loop done, 3 accumulators in LDS, 4 stores retired, 5 XCC id */
 int omp_debug_set_gemm_trace(void* buffer, int64_t n_workgroups);
-int omp_debug_swin_attn_impl(int which); /* 0 = matrix-core kernel (default), 1 = scalar cross-check kernel */
+int omp_debug_swin_attn_impl(int which); /* 0 = matrix-core kernel (default), 1 = scalar cross-check kernel, 2 = matrix cores with per-score table lookups */
+int omp_debug_cross_nt(int on);          /* 1 = non-temporal K / V^T loads in the 1-query-tile cross-attention kernel */
 int omp_debug_cross_q4(int on);          /* 1 = LDS-ring cross-attention for 33..64 rows/image (default), 0 = register-streaming kernel */
 
 /* Single teacher-forced step that also leaves logits in plan->logits (parity tests). */

@@ -189,14 +189,14 @@ def check_patch_embed():
 
 def check_window_attn():
     out = []
-    for impl, iname in ((0, 'mfma'), (1, 'scalar')):
+    for impl, iname, expanded in ((0, 'mfma+expanded bias', True), (2, 'mfma+table', False), (1, 'scalar', False)):
         ops.swin_attn_impl(impl)
-        out += _check_window_attn(iname)
+        out += _check_window_attn(iname, expanded)
     ops.swin_attn_impl(0)
     return out
 
 
-def _check_window_attn(iname):
+def _check_window_attn(iname, expanded=False):
     out = []
     for dn, dt in DTYPES.items():
         for (B, H, W, C, nH) in ((2, 10, 13, 128, 4), (1, 14, 14, 256, 8), (2, 5, 7, 1024, 32), (1, 20, 9, 512, 16), (1, 3, 30, 96, 3)):
@@ -207,7 +207,8 @@ def _check_window_attn(iname):
                 qkv_in = q(x.reshape(-1, C) @ Wqkv.t() + bqkv, dt)
                 # the reference core is evaluated on the SAME (rounded) qkv values
                 ref = _ref_window_attention_from_qkv(qkv_in.reshape(B, H, W, 3 * C), bqkv, table, nH, shift)
-                y = ops.swin_window_attn(qkv_in.to(DEV, dt), bqkv.to(DEV), table.to(DEV), B, H, W, C, nH, shift)
+                bexp = ops.swin_expand_bias(table.to(DEV)) if expanded else None
+                y = ops.swin_window_attn(qkv_in.to(DEV, dt), bqkv.to(DEV), table.to(DEV), B, H, W, C, nH, shift, bias_expanded=bexp)
                 out.append(rec('window_attn[%s,%s,B%d %dx%d C%d shift%d]' % (iname, dn, B, H, W, C, shift),
                                maxerr(y.reshape(B, H, W, C), ref), 2e-5 if dt == torch.float32 else 6e-2,
                                'max|ref|=%.1f (bf16: P and the output are rounded to 8 mantissa bits)' % ref.abs().max().item()))

@@ -66,6 +66,36 @@ def bench_cross(dtype=torch.bfloat16):
     ops.cross_q4(1)
 
 
+def bench_cross128(dtype=torch.bfloat16):
+    """the two cross-attention kernels at the bench's engine-call size (128 images, M = 4096)"""
+    I, M, nH, d, KB = 128, 4096, 8, 512, 32
+    from advancedliteratemachinery_amd.model.transformer import Decoder
+    g = torch.Generator(device='cpu').manual_seed(0)
+    K = torch.randn(2, I, nH, M, 64, generator=g).to(DEV, dtype)
+    Vt = torch.randn(2, I, nH, M // KB, 64, KB, generator=g).to(DEV, dtype)
+    h = _lib.lib()
+    for rows_per_img, splits in ((1, (1, 2, 4)), (64, (1, 2))):
+        counts = [rows_per_img] * I
+        groups, qt = Decoder.make_tiles(counts)
+        gd = torch.tensor(groups, dtype=torch.int32, device=DEV)
+        R = sum(counts)
+        q = torch.randn(R, d, device=DEV).to(dtype)
+        out = torch.empty(R, d, device=DEV, dtype=dtype)
+        alg = I * 2 * M * d * 2 + 2 * R * d * 2
+        for S in splits:
+            partial = torch.empty(R, nH, S, 68, device=DEV)
+            for nt in ((0, 1) if rows_per_img == 1 else (0,)):
+                h.omp_debug_cross_nt(nt)
+                st = [0]
+
+                def fn():
+                    st[0] += 1
+                    ops.dec_cross_attn_step(q, K[st[0] & 1], Vt[st[0] & 1], nH * M * 64, M, None, gd, len(groups), qt, partial, out, M, nH, S)
+                us = timeit(fn, iters=30, warm=4)
+                print('cross128 rows/img=%-2d S=%d nt=%d : %7.1f us  %6.0f GB/s (%.2f of 8 TB/s)' % (rows_per_img, S, nt, us, alg / us / 1e3, alg / us / 1e3 / 8000), flush=True)
+    h.omp_debug_cross_nt(0)
+
+
 def bench_gemm(dtype=torch.bfloat16):
     # (M, N, K, act, residual) of the Swin-B stages at B=8 1024x1024 and the K/V projection
     shapes = [(524288, 384, 128, 0, 0), (524288, 128, 128, 0, 1), (524288, 512, 128, 1, 0), (524288, 128, 512, 0, 1),
@@ -168,10 +198,14 @@ def bench_misc(dtype=torch.bfloat16):
         bias = torch.randn(3 * C, device=DEV)
         tab = torch.randn(169, nH, device=DEV)
         out = torch.empty(B * hh * hh, C, device=DEV, dtype=dtype)
+        bexp = ops.swin_expand_bias(tab)
         for shift in (0, 3):
-            us = timeit(lambda: ops.swin_window_attn(qkv, bias, tab, B, hh, hh, C, nH, shift, out=out), iters=10, warm=2)
             by = B * hh * hh * 4 * C * 2
-            print('swin_attn C=%-4d shift=%d : %8.1f us  %6.0f GB/s' % (C, shift, us, by / us / 1e3), flush=True)
+            for name, be in (('table', None), ('expanded', bexp)):
+                ops.swin_attn_impl(0 if be is not None else 2)
+                us = timeit(lambda: ops.swin_window_attn(qkv, bias, tab, B, hh, hh, C, nH, shift, out=out, bias_expanded=be), iters=10, warm=2)
+                print('swin_attn C=%-4d shift=%d %-8s : %8.1f us  %6.0f GB/s' % (C, shift, name, us, by / us / 1e3), flush=True)
+        ops.swin_attn_impl(0)
         x = torch.randn(B * hh * hh, C, device=DEV).to(dtype)
         g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
         y = torch.empty_like(x)
@@ -195,3 +229,5 @@ if __name__ == '__main__':
         bench_misc()
     if 'mlp' in what or 'all' in what:
         bench_mlp()
+    if 'cross128' in what:
+        bench_cross128()
