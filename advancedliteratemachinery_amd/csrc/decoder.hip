@@ -185,6 +185,86 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same step for MANY rows (polygon / recognition decoders: thousands of rows, <= ~40 cached positions): one wave per
+// ROW, all 8 heads at once.  Lane l holds dims (l & 7) * 8 .. + 8 of head l >> 3, so one cache position of a row
+// ([Lmax][512] layout, 1 KB in bf16) is ONE fully coalesced 16-byte-per-lane load, the append of the new k / v is one
+// coalesced store, and a row costs one wave instead of eight (round 1: one wave per (row, head), 16 384 workgroups at
+// R = 8192, 2.3-2.9 TB/s in isolation and 1.1 TB/s in the bench).  Keys are visited in order with an online softmax
+// (base 2: q carries 1/sqrt(64) * log2 e); the score of a key is an 8-lane xor-shuffle reduction.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 2) void dec_self_attn_row_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+                                                                T* __restrict__ out, const int32_t* __restrict__ d_pos, int R,
+                                                                int d, int Lmax) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int p = *d_pos;
+  const T* row = qkv + (int64_t)r * 3 * d + lane * 8;
+  float q[8], kn[8], vn[8];
+  load8(row, q);
+  load8(row + d, kn);
+  load8(row + 2 * d, vn);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] *= 0.125f * 1.4426950408889634f;
+  T* kbase = kc + (int64_t)r * Lmax * d + lane * 8;
+  T* vbase = vc + (int64_t)r * Lmax * d + lane * 8;
+  store8(kbase + (int64_t)p * d, kn);
+  store8(vbase + (int64_t)p * d, vn);
+  float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = 0.f;
+  constexpr int U = 4;   // cache positions per memory round trip (2 U loads in flight per lane)
+  typedef typename Vec16<T>::type raw_t;   // 16 bytes as loaded; widened to fp32 only when consumed (registers = occupancy here)
+  constexpr int NR = 8 * (int)sizeof(T) / 16;   // 16-byte pieces per 8 elements: 1 (bf16) / 2 (f32)
+  for (int j0 = 0; j0 <= p; j0 += U) {
+    raw_t kraw[U][NR], vraw[U][NR];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u;
+      if (j < p) {        // wave-uniform
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+          kraw[u][c] = ld16<T>(kbase + (int64_t)j * d + c * (8 / NR));
+          vraw[u][c] = ld16<T>(vbase + (int64_t)j * d + c * (8 / NR));
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u;
+      if (j <= p) {
+        float kk[8], vv[8];
+        if (j < p) {
+#pragma unroll
+          for (int c = 0; c < NR; ++c) { unpack16(kraw[u][c], kk + c * (8 / NR)); unpack16(vraw[u][c], vv + c * (8 / NR)); }
+        } else {          // position p itself comes from registers
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { kk[i] = kn[i]; vv[i] = vn[i]; }
+        }
+        float sdot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sdot = fmaf(q[i], kk[i], sdot);
+        sdot += __shfl_xor(sdot, 1, 64);
+        sdot += __shfl_xor(sdot, 2, 64);
+        sdot += __shfl_xor(sdot, 4, 64);
+        const float mn = fmaxf(m, sdot);
+        const float a = __builtin_amdgcn_exp2f(m - mn);   // exp2(-inf) = 0 on the first key
+        const float pj = __builtin_amdgcn_exp2f(sdot - mn);
+        l = l * a + pj;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = o[i] * a + pj * vv[i];
+        m = mn;
+      }
+    }
+  }
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] *= inv;
+  store8(out + (int64_t)r * d + lane * 8, o);
+}
+
+// ---------------------------------------------------------------------------------------------
 // cross attention over the image memory, flash-style on the matrix cores.
 //
 // Memory layout (written by the K/V projection GEMM epilogues, OMP_STORE_KBLK / OMP_STORE_VBLK):
@@ -690,7 +770,8 @@ __global__ void advance_pos_kernel(int32_t* d_pos) { *d_pos += 1; }
 // optional hipEvent bracketing of the cross-attention kernel (bench.py's roofline measurement)
 thread_local bool g_capturing = false;   // one host thread per pipeline lane may be capturing
 
-int g_cross_nt = 1;   // non-temporal K / V^T loads in the 1-query-tile kernel (+3-5 %, profiles/r02j_kbench_cross128.txt); omp_debug_cross_nt(0) = plain
+int g_cross_nt = 1;   // non-temporal K / V^T loads in the 1-query-tile kernel once >= 32 images share a launch (+3-5 %,
+                      // profiles/r02j_kbench_cross128.txt; a few images' slabs still fit the 256 MB Infinity Cache and want to stay there); omp_debug_cross_nt(0) = plain
 
 template <typename T, int QT, int PD, bool NT = false>
 int launch_cross_t(const CrossP& cp, int n_groups, int S, hipStream_t st) {
@@ -726,6 +807,7 @@ int launch_merge(const CrossP& cp, int S, hipStream_t st) {
   return OMP_OK;
 }
 
+int g_self_attn_impl = 0;   // 0 auto, 1 one wave per (row, head), 2 one wave per row (omp_debug_self_attn_impl)
 int g_cross_q4 = 1;   // 1 = LDS-ring kernel for 33..64 rows per image (bf16); 0 = register-streaming kernel everywhere
 
 template <int NS>
@@ -764,7 +846,7 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   const bool f = dtype == OMP_F32;
   // PD key blocks in flight per wave: with one query tile a wave's whole slice is usually 4 blocks -> all of it
   if (q4) rc = launch_cross_q4<8>(cp, n_groups, S, st);
-  else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : (g_cross_nt ? launch_cross_t<bf16_t, 1, 4, true>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st));
+  else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : ((g_cross_nt && n_groups >= 32) ? launch_cross_t<bf16_t, 1, 4, true>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st));
   else if (qt == 2) rc = f ? launch_cross_t<float, 2, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 2, 2>(cp, n_groups, S, st);
   else rc = f ? launch_cross_t<float, 4, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 4, 2>(cp, n_groups, S, st);
   if (rc != OMP_OK) return rc;
@@ -801,6 +883,21 @@ extern "C" int omp_dec_self_attn_step(const void* qkv, void* kcache, void* vcach
                                       omp_stream_t s) {
   OMP_CHECK_ARG(qkv && kcache && vcache && out && d_pos, "omp_dec_self_attn_step: null pointer");
   OMP_CHECK_ARG(d == nH * DH, "omp_dec_self_attn_step: head_dim must be 64 (d=%d nH=%d)", d, nH);
+  OMP_CHECK_ARG(dtype == OMP_F32 || dtype == OMP_BF16, "omp_dec_self_attn_step: bad dtype");
+  // many rows, short caches (polygon / recognition): one wave per row; few rows, long caches (points): one wave per (row, head)
+  const bool rows = g_self_attn_impl == 2 || (g_self_attn_impl == 0 && nH == 8 && R >= 1024);
+  if (rows) {
+    OMP_CHECK_ARG(nH == 8, "omp_dec_self_attn_step: the row kernel covers d = 512 (8 heads)");
+    dim3 g4((R + 3) / 4);
+    if (dtype == OMP_F32)
+      hipLaunchKernelGGL((dec_self_attn_row_kernel<float>), g4, dim3(256), 0, (hipStream_t)s, (const float*)qkv, (float*)kcache,
+                         (float*)vcache, (float*)out, d_pos, R, d, Lmax);
+    else
+      hipLaunchKernelGGL((dec_self_attn_row_kernel<bf16_t>), g4, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, (bf16_t*)kcache,
+                         (bf16_t*)vcache, (bf16_t*)out, d_pos, R, d, Lmax);
+    OMP_CHECK_LAUNCH("omp_dec_self_attn_step(rows)");
+    return OMP_OK;
+  }
   dim3 grid(R, (nH + 3) / 4);
   if (dtype == OMP_F32)
     hipLaunchKernelGGL((dec_self_attn_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv,
@@ -947,6 +1044,11 @@ int sample_and_advance(const omp_decoder_plan* P, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int omp_debug_self_attn_impl(int which) {
+  g_self_attn_impl = (which == 1 || which == 2) ? which : 0;
+  return OMP_OK;
+}
 
 extern "C" int omp_debug_cross_nt(int on) {
   g_cross_nt = on ? 1 : 0;

@@ -143,6 +143,42 @@ def check_mlp_fused():
     return out
 
 
+def check_self_attn():
+    """decoder self-attention step with KV cache (transformer.py:412-414 / :438-440 + the causal mask): both kernels (one wave
+    per (row, head); one wave per row for many rows) against softmax(q K^T / 8) V over the cached positions, every step of a
+    short decode, caches appended by the kernel itself."""
+    from advancedliteratemachinery_amd import _lib
+    out = []
+    nH, d = 8, 512
+    for dn, dt in DTYPES.items():
+        for impl, iname in ((1, 'wave per (row, head)'), (2, 'wave per row')):
+            _lib.lib().omp_debug_self_attn_impl(impl)
+            for (R, steps, Lmax) in ((5, 9, 12), (70, 37, 40), (515, 36, 36)):
+                g = torch.Generator().manual_seed(R)
+                kc = torch.zeros(R, Lmax, d, dtype=dt, device=DEV)
+                vc = torch.zeros(R, Lmax, d, dtype=dt, device=DEV)
+                o = torch.empty(R, d, dtype=dt, device=DEV)
+                dpos = torch.zeros(1, dtype=torch.int32, device=DEV)
+                Ks, Vs = [], []
+                worst = 0.0
+                for p in range(steps):
+                    qkv = q(torch.randn(R, 3 * d, generator=g) * 1.5, dt)
+                    dpos.fill_(p)
+                    ops.dec_self_attn_step(qkv.to(DEV, dt), kc, vc, o, dpos, nH)
+                    qq, kk, vv = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+                    Ks.append(kk); Vs.append(vv)
+                    K = torch.stack(Ks, 1).reshape(R, p + 1, nH, 64).permute(0, 2, 1, 3)
+                    V = torch.stack(Vs, 1).reshape(R, p + 1, nH, 64).permute(0, 2, 1, 3)
+                    att = torch.softmax((qq.reshape(R, nH, 1, 64) * 0.125) @ K.transpose(-1, -2), -1)
+                    ref = (att @ V).reshape(R, d)
+                    worst = max(worst, maxerr(o, ref))
+                cache_err = max(maxerr(kc[:, :steps], torch.stack(Ks, 1)), maxerr(vc[:, :steps], torch.stack(Vs, 1)))
+                out.append(rec('self_attn[%s,%s,R=%d,%d steps]' % (dn, iname, R, steps), worst, 2e-5 if dt == torch.float32 else 3e-2))
+                out.append(rec('self_attn[%s,%s,R=%d] cache contents' % (dn, iname, R), cache_err, 0))
+    _lib.lib().omp_debug_self_attn_impl(0)
+    return out
+
+
 def check_gemm_small():
     """split-K small-M kernel (decoder steps), with and without the fused LayerNorm prologue."""
     out = []
@@ -744,5 +780,5 @@ def check_lanes(dtype_name='fp32', n_lanes=3, n_jobs=7):
     return [rec('lanes==direct[%s,%d lanes,%d jobs]' % (dtype_name, n_lanes, n_jobs), bad, 0)]
 
 
-ALL_OP_CHECKS = [check_layernorm, check_gemm, check_mlp_fused, check_gemm_small, check_patch_embed, check_window_attn, check_patch_merge, check_fpn,
+ALL_OP_CHECKS = [check_layernorm, check_gemm, check_mlp_fused, check_self_attn, check_gemm_small, check_patch_embed, check_window_attn, check_patch_merge, check_fpn,
                  check_posembed, check_sampling, check_cross_attn]

@@ -186,9 +186,12 @@ def bench_selfattn(dtype=torch.bfloat16):
         vc = torch.randn(R, Lmax, d, device=DEV).to(dtype)
         out = torch.empty(R, d, device=DEV, dtype=dtype)
         dp = torch.tensor([pos], dtype=torch.int32, device=DEV)
-        us = timeit(lambda: ops.dec_self_attn_step(qkv, kc, vc, out, dp, nH), iters=100)
         by = R * (pos + 1) * d * 2 * 2
-        print('selfattn[%s] R=%-4d pos=%-3d : %6.1f us  %6.0f GB/s' % (str(dtype)[6:], R, pos, us, by / us / 1e3), flush=True)
+        for impl in (1, 2):
+            _lib.lib().omp_debug_self_attn_impl(impl)
+            us = timeit(lambda: ops.dec_self_attn_step(qkv, kc, vc, out, dp, nH), iters=100)
+            print('selfattn[%s] R=%-4d pos=%-3d impl=%d : %6.1f us  %6.0f GB/s' % (str(dtype)[6:], R, pos, impl, us, by / us / 1e3), flush=True)
+        _lib.lib().omp_debug_self_attn_impl(0)
 
 
 def bench_misc(dtype=torch.bfloat16):
