@@ -49,6 +49,10 @@ BIG_CASES = {
     'kie_960x1280': dict(args=dict(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=9,
                                    infer_vie=True, vie_categories=4, val_dataset=['sroie_val']),
                          hw=(960, 1280), depths=(2, 2, 18, 2), mem_stride=(7, 3), feat_stride=(8, 7, 7), src_stride=(32, 3, 3)),
+    # EXTENSION, config 1's 'Swin-T': embed 96, depths 2-2-6-2, heads 3-6-12-24, no FPN (the reference's FPN and input_proj are
+    # hard-wired to Swin-B widths; input_proj is rebuilt at 768 inputs by oracle/ref_import.py -- patched widths)
+    'swint_nofpn': dict(args=dict(tfm_pre_norm=True, use_fpn=False, use_char_window_prompt=True, pt_seq_length=6),
+                        hw=(200, 264), depths=(2, 2, 6, 2), swin=dict(embed_dim=96, num_heads=(3, 6, 12, 24))),
     'spot_padded': dict(args=dict(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=8),
                         hws=[(150, 203), (120, 170)], depths=(2, 2, 18, 2)),
 }
@@ -60,7 +64,7 @@ IMG_SEED = 1
 def case_inputs(case):
     """Everything a test needs to rebuild the inputs of `case` WITHOUT the reference."""
     args = make_args(**case['args'])
-    sd = weights.make_state_dict(args, seed=WEIGHT_SEED, head_gain=HEAD_GAIN, depths=case['depths'])
+    sd = weights.make_state_dict(args, seed=WEIGHT_SEED, head_gain=HEAD_GAIN, depths=case['depths'], **case.get('swin', {}))
     g = torch.Generator().manual_seed(IMG_SEED)
     seqs = O.default_prompts(args)
     if 'hws' in case:
@@ -104,7 +108,7 @@ def teacher_forced(decode_fn, args, out, seqs):
 def run_reference(name):
     case = CASES[name] if name in CASES else BIG_CASES[name]
     args, sd, img, mask, seqs = case_inputs(case)
-    model = ref_import.build_reference_model(args, sd, depths=case['depths'])
+    model = ref_import.build_reference_model(args, sd, depths=case['depths'], **case.get('swin', {}))
     if img.shape[0] > 1:
         per = [_run_one(model, args, sd, case, img[b:b + 1], mask[b:b + 1], seqs) for b in range(img.shape[0])]
         return dict(name=name, case=case, fingerprint=fingerprint(sd), images=per)

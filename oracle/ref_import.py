@@ -95,6 +95,13 @@ def build_reference_model(args, state_dict, embed_dim=128, depths=(2, 2, 18, 2),
     bb = m['joiner'].Joiner(swin, pos)
     tr = m['transformer'].build_transformer(args)
     model = m['omniparser'].OmniParser(bb, tr, args.num_classes, args.use_fpn)
+    # EXTENSION (Swin-T and other widths, BASELINE config 1): the reference hard-codes input_proj to 1024 input channels
+    # (omniparser.py:13-17).  For a narrower backbone the 1x1 conv -- and nothing else -- is rebuilt with the backbone's
+    # width: 'reference classes with patched widths' 
+    w = state_dict.get('input_proj.weight')
+    if w is not None and w.shape[1] != model.input_proj.in_channels:
+        old = model.input_proj
+        model.input_proj = nn.Conv2d(w.shape[1], old.out_channels, kernel_size=old.kernel_size, stride=old.stride)
     missing = model.load_state_dict(state_dict, strict=True)
     model.eval()
     return model

@@ -437,8 +437,8 @@ def check_cross_attn():
 # ---------------------------------------------------------------------------------------------
 # decoder: teacher-forced logits vs oracle.decode on random memories (2 images, ragged counts)
 # ---------------------------------------------------------------------------------------------
-def build_model(args, sd, depths, dtype, graph=False):
-    m = OmniParser(args, dict(depths=depths), engine_dtype=dtype)
+def build_model(args, sd, depths, dtype, graph=False, swin=None):
+    m = OmniParser(args, dict(dict(depths=depths), **(swin or {})), engine_dtype=dtype)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV)
     m.use_graph = graph
@@ -578,7 +578,7 @@ def _check_e2e(name, dtype_name, graph):
     fp = maxerr(G.fingerprint(sd), gold['fingerprint'])
     tag = name + (',graph' if graph else '')
     out.append(rec('e2e[%s] weight fingerprint' % name, fp, 1e-6))
-    model = build_model(args, sd, case['depths'], dt, graph)
+    model = build_model(args, sd, case['depths'], dt, graph, case.get('swin'))
     if 'images' in gold:   # padded batch: every image must come out as the reference run on it alone
         B = img.shape[0]
         enc, dec = model.engine()

@@ -68,3 +68,10 @@ def test_graph_replay_matches_eager(C):
 def test_pipelined_lanes_match_direct(C):
     """Batches in flight on several HIP streams (engine/pipeline.py) == the synchronous path."""
     _assert_all(C.check_lanes('fp32'))
+
+
+def test_swin_t_extension_fp32(C):
+    """BASELINE config 1 names Swin-T, which the reference cannot build (FPN / input_proj are wired to Swin-B widths, SURVEY 0);
+    the parametrised backbone (embed 96, depths 2-2-6-2, heads 3-6-12-24) is pinned to the reference's classes with the one
+    hard-coded width patched (oracle/ref_import.py).  fp32 engine only: the bf16 GEMMs need K % 64 == 0."""
+    _assert_all(C.check_e2e('swint_nofpn', 'fp32'))

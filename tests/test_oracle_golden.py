@@ -8,7 +8,7 @@ import torch
 from oracle import gen_golden as G
 from oracle import omniparser_ref as O
 
-CASES = list(G.CASES)
+CASES = list(G.CASES) + ['swint_nofpn']   # + the Swin-T extension (patched widths); the other BIG_CASES are GPU-test fixtures
 
 
 def _load(golden_dir, name):
@@ -24,12 +24,14 @@ def test_oracle_matches_reference_fixture(golden_dir, name):
     assert torch.allclose(G.fingerprint(sd), gold['fingerprint'], rtol=1e-9, atol=0), \
         'procedural weights differ from the ones the golden file was generated with'
     with torch.no_grad():
-        out, enc = O.forward(sd, args, img, mask, seqs, depths=case['depths'],
-                             return_encoded=True)
+        out, enc = O.forward(sd, args, img, mask, seqs, depths=case['depths'], return_encoded=True,
+                             **({'num_heads': case['swin']['num_heads']} if 'swin' in case else {}))
         for f, shp, smp in zip(enc['feats'], gold['feat_shapes'], gold['feat_sample']):
             assert tuple(f.shape) == shp
-            assert (f[0, ::8, ::3, ::3] - smp).abs().max() < 1e-4
-        assert (enc['src'][0, ::16, ::2, ::2] - gold['src_sample']).abs().max() < 1e-4
+            fs = gold.get('feat_stride', (8, 3, 3))
+            assert (f[0, ::fs[0], ::fs[1], ::fs[2]] - smp).abs().max() < 1e-4
+        ss = gold.get('src_stride', (16, 2, 2))
+        assert (enc['src'][0, ::ss[0], ::ss[1], ::ss[2]] - gold['src_sample']).abs().max() < 1e-4
         assert (enc['memory'][:, 0, :] - gold['memory']).abs().max() < 1e-4
         assert (enc['pos'][::5, 0, ::3] - gold['pos_sample']).abs().max() < 1e-5
         go = gold['out']

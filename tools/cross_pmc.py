@@ -37,7 +37,7 @@ def main():
 
     # key splits as Decoder._n_split picks them for this many images (transformer.py)
     s_pt = 8
-    while s_pt > 1 and I * nH * s_pt > 4096:
+    while s_pt > 1 and I * nH * s_pt > 1024:
         s_pt //= 2
     s_q4 = 1
     while s_q4 < 16 and I * nH * s_q4 < 512 and M >= 8 * KB * s_q4:

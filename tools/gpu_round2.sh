@@ -18,6 +18,10 @@ kbench) timeout 600 python tools/kbench.py ${KBENCH_WHAT:-gemm} > $OUT/kbench.tx
 pmc)   for I in ${PMC_IMAGES:-80 128}; do for c in FETCH_SIZE WRITE_SIZE; do
          (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pmc_${c}_$I -o pmc -- python $R/tools/cross_pmc.py $I > $R/$OUT/pmc_${c}_$I.log 2>&1); echo "pmc $c $I rc=$?" >> $OUT/rc.log
          f=$(find $OUT/pmc_${c}_$I -name "*counter_collection.csv" 2>/dev/null | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f $c > $OUT/pmc_${c}_$I.txt 2>> $OUT/rc.log; rm -rf $OUT/pmc_${c}_$I
-       done; done;;
+         done
+         python tools/pmc_cross_json.py $OUT/pmc_FETCH_SIZE_$I.txt $OUT/pmc_WRITE_SIZE_$I.txt $I "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python tools/cross_pmc.py $I" $OUT/pmc_cross_attn.json > $OUT/pmc_cross_attn.json.new 2>> $OUT/rc.log && mv $OUT/pmc_cross_attn.json.new $OUT/pmc_cross_attn.json
+       done;;
+mfma)  (cd /tmp && KBENCH_GEMM_VARIANTS=0 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $R/$OUT/pmc_mfma -o pmc -- python $R/tools/kbench.py gemm mlp > $R/$OUT/pmc_mfma_kbench.log 2>&1); echo "mfma rc=$?" >> $OUT/rc.log
+       f=$(find $OUT/pmc_mfma -name "*counter_collection.csv" 2>/dev/null | head -1); [ -n "$f" ] && python tools/pmc_mfma.py $f > $OUT/pmc_mfma_gemm_shapes.txt 2>> $OUT/rc.log; rm -rf $OUT/pmc_mfma;;
 esac; done
 cat $OUT/rc.log

@@ -18,11 +18,21 @@ def mean_of(path):
 
 
 def main():
+    """python tools/pmc_cross_json.py <fetch.txt> <write.txt> <images_per_launch> "<command>" [existing.json]
+    prints the JSON file bench.py reads: one record per images-per-launch (an existing file is merged into)."""
     fm, fn = mean_of(sys.argv[1])
     wm, wn = mean_of(sys.argv[2])
-    print(json.dumps(dict(kernel='dec_cross_attn*', fetch_kib_mean=fm, write_kib_mean=wm, launches_fetch=fn, launches_write=wn,
-                          images_per_launch=int(sys.argv[3]), command=sys.argv[4] if len(sys.argv) > 4 else '',
-                          units='KiB as reported by rocprofv3; bench.py applies the gfx950 x2 correction to FETCH_SIZE'), indent=1))
+    out = {}
+    if len(sys.argv) > 5:
+        try:
+            old = json.load(open(sys.argv[5]))
+            out = {str(old['images_per_launch']): old} if 'images_per_launch' in old else dict(old)
+        except (OSError, ValueError):
+            out = {}
+    out[str(int(sys.argv[3]))] = dict(kernel='dec_cross_attn*', fetch_kib_mean=fm, write_kib_mean=wm, launches_fetch=fn, launches_write=wn,
+                                      images_per_launch=int(sys.argv[3]), command=sys.argv[4] if len(sys.argv) > 4 else '',
+                                      units='KiB as reported by rocprofv3; bench.py applies the gfx950 x2 correction to FETCH_SIZE')
+    print(json.dumps(out, indent=1))
 
 
 if __name__ == '__main__':
