@@ -175,4 +175,35 @@ __device__ __forceinline__ float erf_fast(float a) {
 // nn.GELU() (exact erf form), swin_transformer.py:21
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
+// GELU for the bf16 engine (the GELU cost of a GEMM epilogue is VALU issue slots: 42 % of the fused MLP at C = 128,
+// profiles/r02f_mlp_trace.txt).  One range, no select:  gelu(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2)  with
+// erfc(t / sqrt 2) = 2^(t q(t)), q a degree-5 polynomial fitted on [0, 6] (|x| is clamped there: erfc < 2e-9).  Two
+// elements per call so that the polynomial runs on v_pk_fma_f32.  Max |error| 3.2e-7 over [-8, 8] in fp32 arithmetic
+// (numpy twin in tests/test_host_logic.py), i.e. 1/2000 of a bf16 ulp at |x| ~ 0.1 -- the fp32 engine keeps erf_fast.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+  const f32x2 a = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2 t = {fminf(a[0], 6.0f), fminf(a[1], 6.0f)};
+  f32x2 q = {2.992467125e-05f, 2.992467125e-05f};
+  q = __builtin_elementwise_fma(q, t, f32x2{-7.398781599e-04f, -7.398781599e-04f});
+  q = __builtin_elementwise_fma(q, t, f32x2{7.977474481e-03f, 7.977474481e-03f});
+  q = __builtin_elementwise_fma(q, t, f32x2{-5.323820189e-02f, -5.323820189e-02f});
+  q = __builtin_elementwise_fma(q, t, f32x2{-4.589156806e-01f, -4.589156806e-01f});
+  q = __builtin_elementwise_fma(q, t, f32x2{-1.151147127e+00f, -1.151147127e+00f});
+  const f32x2 p = q * t;
+  const f32x2 e = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
+  const f32x2 h = a * f32x2{-0.5f, -0.5f};
+  const f32x2 r = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
+  return __builtin_elementwise_fma(h, e, r);
+}
+// n (even) values in place
+template <int N>
+__device__ __forceinline__ void gelu_fast_n(float* v) {
+#pragma unroll
+  for (int i = 0; i < N; i += 2) {
+    const f32x2 g = gelu_fast2(f32x2{v[i], v[i + 1]});
+    v[i] = g[0]; v[i + 1] = g[1];
+  }
+}
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -378,9 +378,10 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
 #pragma unroll
           for (int q = 0; q < CH; ++q) {
             v[q] += bcol[q];
-            if constexpr (decltype(ACT)::value == OMP_ACT_GELU) v[q] = gelu_erf(v[q]);
+            if constexpr (decltype(ACT)::value == OMP_ACT_GELU && !std::is_same<TOut, bf16_t>::value) v[q] = gelu_erf(v[q]);
             if constexpr (decltype(ACT)::value == OMP_ACT_RELU) v[q] = fmaxf(v[q], 0.0f);
           }
+          if constexpr (decltype(ACT)::value == OMP_ACT_GELU && std::is_same<TOut, bf16_t>::value) gelu_fast_n<CH>(v);
           if (res != nullptr) {
             if (p.C2 != nullptr) {   // memory and memory + pos from one product
               typename Vec16<TOut>::type o2;

@@ -166,12 +166,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void mlp_fused_kernel(MlpP p) {
     const f32x4 bb1 = *reinterpret_cast<const f32x4*>(b1s + 16 + 4 * lg);
     bf16x8 hf[RG];
 #pragma unroll
-    for (int rg = 0; rg < RG; ++rg)
+    for (int rg = 0; rg < RG; ++rg) {
+      float hv[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        hf[rg][e] = (bf16_t)gelu_erf(a1[0][rg][e] + bb0[e]);
-        hf[rg][e + 4] = (bf16_t)gelu_erf(a1[1][rg][e] + bb1[e]);
-      }
+      for (int e = 0; e < 4; ++e) { hv[e] = a1[0][rg][e] + bb0[e]; hv[e + 4] = a1[1][rg][e] + bb1[e]; }
+      gelu_fast_n<8>(hv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) hf[rg][e] = (bf16_t)hv[e];
+    }
     if constexpr (TRACE) { asm volatile("" :: "v"(hf[0]), "v"(hf[RG - 1])); }
     const unsigned long long c2 = now();
 #pragma unroll

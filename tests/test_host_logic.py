@@ -189,6 +189,34 @@ def test_erf_fast_twin_matches_scipy():
     assert np.abs(y.astype(np.float64) - erf(a.astype(np.float64))).max() < 1.5e-7
 
 
+def test_gelu_fast_twin_matches_exact_gelu():
+    """numpy twin of csrc/common.h gelu_fast2 (the bf16 engine's GELU: max(x,0) - 0.5|x| 2^(t q(t)), t = min(|x|, 6)):
+    same constants, fp32 arithmetic, against 0.5 x (1 + erf(x / sqrt 2)) in float64 -- pins the coefficients."""
+    import re
+    import numpy as np
+    from scipy.special import erf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'advancedliteratemachinery_amd', 'csrc', 'common.h')).read()
+    body = src[src.index('f32x2 gelu_fast2(f32x2 x)'):src.index('// n (even) values in place')]
+    consts = [float(c) for c in re.findall(r'\{(-?\d\.\d+e[-+]?\d+)f,', body)]
+    assert len(consts) == 6, consts
+    f = np.float32
+
+    def fma(a, b, c):
+        return (np.float64(a) * np.float64(b) + np.float64(c)).astype(f)
+    x = np.linspace(-9, 9, 600001).astype(f)
+    a = np.abs(x)
+    t = np.minimum(a, f(6.0))
+    q = np.full_like(x, consts[0])
+    for c in consts[1:]:
+        q = fma(q, t, f(c))
+    p = (q * t).astype(f)
+    e = np.exp2(p.astype(np.float64)).astype(f)
+    y = fma((a * f(-0.5)).astype(f), e, np.maximum(x, f(0)))
+    ref = 0.5 * x.astype(np.float64) * (1.0 + erf(x.astype(np.float64) / np.sqrt(2.0)))
+    assert np.abs(y.astype(np.float64) - ref).max() < 5e-7
+
+
 def test_encoder_chunking_concatenates_memory_in_image_order():
     """OmniParser._encode_chunked: a large engine call is encoded enc_chunk images at a time; memory rows / masks of
     the chunks are concatenated in image order and the per-batch scalars are kept"""

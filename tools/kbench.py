@@ -151,7 +151,7 @@ def bench_mlp(dtype=torch.bfloat16):
 
 def bench_dec_gemm(dtype=torch.bfloat16):
     """decoder-step GEMMs: weight streaming at R = 8 rows (point decoder) and R = 512 (polygon / recognition)."""
-    for R, which in ((8, 0), (64, 0), (128, 0), (512, 6), (2048, 6), (8192, 6), (8192, 5)):
+    for R, which in ((8, 0), (64, 0), (128, 0), (256, 0), (512, 6), (2048, 6), (8192, 6), (8192, 5), (16384, 0)):
         ops.force_gemm_kernel(which if R > 64 else 0)
         for (N, K, ln) in ((1536, 512, 1), (512, 512, 0), (2048, 512, 1), (512, 2048, 0), (1104, 512, 0)):
             W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(dtype)
