@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 10
 STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
@@ -94,10 +94,14 @@ _SIGS = {
     'omp_debug_cross_nt': (c_int, [c_int]),
     'omp_debug_self_attn_impl': (c_int, [c_int]),
     'omp_vit_patch_embed': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
+    'omp_vit_attn': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_a3_pool': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_row_argmax_prob': (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'omp_resize_normalize_pad': (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'omp_stream_create_cu_mask': (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p)]),
+    'omp_stream_destroy': (c_int, [c_void_p]),
+    'omp_debug_where': (c_int, [c_void_p, c_int, c_void_p]),
     'omp_prof_enable': (c_int, [c_int]),
     'omp_prof_read': (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
     'omp_prof_read_class': (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double)]),

@@ -79,3 +79,42 @@ void omp_set_error(const char* fmt, ...) {
 
 extern "C" const char* omp_last_error(void) { return g_err; }
 extern "C" int omp_abi_version(void) { return OMP_ABI_VERSION; }
+
+// ---- HIP streams restricted to a subset of the compute units -----------------------------------------------------
+// The hot path alternates matrix-core-bound phases (Swin encoder) and HBM-bound phases (the decoders' cross-attention
+// streams 8.4 MB of K / V^T per image, layer and step).  Two engine calls in flight overlap them only if the HBM-bound
+// kernels do not take every CU: their streams can be created on a CU subset here (engine/pipeline.py).
+namespace {
+__global__ void where_kernel(int32_t* out) {
+  if (threadIdx.x == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);    // XCC_ID
+    const unsigned hw = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);     // HW_ID
+    out[blockIdx.x * 2] = (int32_t)xcc;
+    out[blockIdx.x * 2 + 1] = (int32_t)hw;
+  }
+  // stay resident long enough for the grid to spread over every CU the stream may use
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < 200000ull) {}
+}
+}  // namespace
+
+extern "C" int omp_stream_create_cu_mask(const uint32_t* mask, int n_words, omp_stream_t* out) {
+  OMP_CHECK_ARG(mask && out && n_words > 0, "omp_stream_create_cu_mask: bad arguments");
+  hipStream_t st = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask);
+  if (e != hipSuccess) { omp_set_error("omp_stream_create_cu_mask: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
+  *out = (omp_stream_t)st;
+  return OMP_OK;
+}
+
+extern "C" int omp_stream_destroy(omp_stream_t s) {
+  if (s != nullptr && hipStreamDestroy((hipStream_t)s) != hipSuccess) { omp_set_error("omp_stream_destroy failed"); return OMP_ERR_LAUNCH; }
+  return OMP_OK;
+}
+
+extern "C" int omp_debug_where(int32_t* out, int n_workgroups, omp_stream_t s) {
+  OMP_CHECK_ARG(out && n_workgroups > 0, "omp_debug_where: bad arguments");
+  hipLaunchKernelGGL(where_kernel, dim3(n_workgroups), dim3(64), 0, (hipStream_t)s, out);
+  OMP_CHECK_LAUNCH("omp_debug_where");
+  return OMP_OK;
+}

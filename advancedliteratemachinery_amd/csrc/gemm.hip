@@ -41,8 +41,14 @@ struct GemmP {
   unsigned long long* trace;                            // debug: per-workgroup phase timestamps (gemm_dma<..., TRACE>)
 };
 
+// bf16 destinations take the bf16 engine's GELU everywhere (vectorised or not: a value must not depend on which
+// kernel or epilogue path produced it), fp32 destinations the < 1 ulp erf form
+template <typename TOut>
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == OMP_ACT_GELU) return gelu_erf(v);
+  if (act == OMP_ACT_GELU) {
+    if constexpr (std::is_same<TOut, bf16_t>::value) return gelu_fast2(f32x2{v, 0.0f})[0];
+    else return gelu_erf(v);
+  }
   if (act == OMP_ACT_RELU) return fmaxf(v, 0.0f);
   return v;
 }
@@ -148,7 +154,7 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, const float* bias
   for (int r = 0; r < 4; ++r) {
     float b = 0.0f;
     if (bias != nullptr) b = p.bias_m ? bias[m] : (n + r < p.N ? bias[n + r] : 0.0f);
-    v[r] = apply_act(acc[r] + b, p.act);
+    v[r] = apply_act<TOut>(acc[r] + b, p.act);
   }
   store4<TOut>(p, m, n, v);
 }
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
       if (bias != nullptr && p.bias_m && m0 + r < p.M) bm = bias[m0 + r];
       float v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = apply_act(t[u] + bcol[q + u] + bm, p.act);
+      for (int u = 0; u < 4; ++u) v[u] = apply_act<TOut>(t[u] + bcol[q + u] + bm, p.act);
       store4<TOut>(p, m0 + r, n + q, v);
     }
   }

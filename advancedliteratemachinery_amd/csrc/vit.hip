@@ -5,12 +5,189 @@
 // self-attention, the blocked-K / blocked-V^T cross-attention kernels (a ViT layer's keys and values are written
 // by the k / v projection epilogues straight into the slabs those kernels stream; an image's 257 tokens are 5
 // row groups that share its slab).  What has no counterpart there lives in this file:
+//   vit_attn_kernel          bf16 self-attention of one (image, head) per workgroup: the 257 keys / values of the
+//                            head stay in LDS, every wave owns pairs of 16-query tiles (see the kernel)
 //   vit_patch_embed_kernel   4x4/4 patchify (a K = 48 dot product per output) + bias + cls token + pos_embed
 //   a3_pool_kernel           the A^3 module's token softmax and weighted pooling (token_learner.py:27-31)
 //   row_argmax_prob_kernel   greedy id and max-softmax probability of every logits row (test_final.py:145-170)
 #include "common.h"
 
 namespace {
+
+// ---------------------------------------------------------------------------------------------
+// ViT self-attention, bf16 (timm Attention.forward: softmax(q k^T / 8) v per head; modules/mgp_str.py:71-74 runs it
+// 12 times on 257 tokens).  One workgroup = one (image, head):
+//   * the head's K rows [Mpad][64] and V^T blocks [Mpad/32][64][32] (the slabs the k / v projection epilogues write,
+//     same layout as the decoder's cross-attention) are copied ONCE into LDS by DMA, 128-byte rows with the 16-byte
+//     chunk index XOR-swizzled on the source address so that the fragment ds_read_b128s are conflict-free;
+//   * a wave owns 16-query tiles, two at a time (each K / V^T fragment read from LDS feeds two matrix-core
+//     products): S^T = K Q^T for 96 keys at a time into registers, masked running max / exp / sum in registers
+//     (a query's keys sit in one lane of each of the 4 lane groups: two shuffles per chunk), P^T repacked to bf16
+//     in the order the V^T slab stores its keys, O^T = alpha O^T + V^T P^T, scaled by 1 / sum on the way out.
+// Through the blocked cross-attention kernels the same layer cost 5 row groups x (K + V^T streamed from L2) per
+// (image, head) and ran its last group for one query.
+template <int NB>   // 16-key score blocks (Mpad = 16 NB; NB even)
+__global__ __launch_bounds__(256, 2) void vit_attn_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ K,
+                                                          const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out, int64_t ldo,
+                                                          int T, int nH) {
+  typedef bf16x8 frag;
+  constexpr int MP = NB * 16, KBYTES = MP * 128, ROUNDS = MP / 32;
+  constexpr int CB = 6;   // score blocks (16 keys each) per softmax chunk: 2 x 6 x 4 score registers per lane
+  static_assert(NB % CB == 0 && CB % 2 == 0, "chunking");
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // K image | V^T image, MP rows of 128 B each
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int64_t slab = ((int64_t)b * nH + h) * MP * 64;
+  {
+    const int dr = lane >> 3, dc = (lane & 7) ^ dr;
+    const bf16_t* ks = K + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
+    const bf16_t* vs = Vt + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ks + i * 32 * 64),
+                                       (__attribute__((address_space(3))) void*)(lds + (i * 32 + wave * 8) * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vs + i * 32 * 64),
+                                       (__attribute__((address_space(3))) void*)(lds + KBYTES + (i * 32 + wave * 8) * 128), 16, 0, 0);
+    }
+  }
+  // fragment byte offsets: K block kb, k-step st -> row kb*16 + li, chunk st*4 + g; V^T key step s, dim tile dt ->
+  // row s*32 + dt*8 + (li >> 1), chunk (li & 1)*4 + g (a 128-byte row holds two dims x 32 key slots)
+  const int koff0 = li * 128 + (((0 * 4 + g) ^ (li & 7)) << 4), koff1 = li * 128 + (((1 * 4 + g) ^ (li & 7)) << 4);
+  int voff[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int rw = dt * 8 + (li >> 1), c = (li & 1) * 4 + g;
+    voff[dt] = KBYTES + rw * 128 + ((c ^ (rw & 7)) << 4);
+  }
+  const int nq = (T + 15) >> 4;          // query tiles
+  const int first_dead = T >> 4;         // first score block with a masked key
+  const bf16_t* qb = q + (int64_t)b * T * ldq + h * 64 + g * 8;
+  bf16_t* ob = out + (int64_t)b * T * ldo + h * 64 + g * 4;
+
+  auto tile = [&](auto NQ_, int f0) {
+    constexpr int NQ = decltype(NQ_)::value;
+    constexpr float L2E = 1.4426950408889634f;
+    frag qf[NQ][2];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      int qi = (f0 + n) * 16 + li;
+      if (qi > T - 1) qi = T - 1;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        float tmp[8];
+        unpack16(*reinterpret_cast<const frag*>(qb + (int64_t)qi * ldq + st * 32), tmp);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tmp[i] *= 0.125f;   // 1 / sqrt(64), exact in bf16
+        pack16(tmp, qf[n][st]);
+      }
+    }
+    float mrun[NQ], lrun[NQ];
+    f32x4 ot[NQ][4];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      mrun[n] = -INFINITY; lrun[n] = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) ot[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c0 = 0; c0 < NB; c0 += CB) {
+      // compiler barrier: the LDS images are loop-invariant, and hipcc otherwise hoists every fragment read of a tile
+      // (36 + 36 x 4 registers) out of the tile loop and spills them
+      asm volatile("" ::: "memory");
+      f32x4 sc[NQ][CB];
+#pragma unroll
+      for (int kb = 0; kb < CB; ++kb) {
+        const frag k0 = *reinterpret_cast<const frag*>(lds + (c0 + kb) * 2048 + koff0);
+        const frag k1 = *reinterpret_cast<const frag*>(lds + (c0 + kb) * 2048 + koff1);
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[n][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[n][1], a, 0, 0, 0);
+          sc[n][kb] = a;
+        }
+      }
+      // keys >= T (the zero rows that pad the slab) take no weight
+#pragma unroll
+      for (int kb = 0; kb < CB; ++kb)
+        if (c0 + kb >= first_dead) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool dead = (c0 + kb) * 16 + g * 4 + r >= T;
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) sc[n][kb][r] = dead ? -INFINITY : sc[n][kb][r];
+          }
+        }
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) {
+        float m = sc[n][0][0];
+#pragma unroll
+        for (int kb = 0; kb < CB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m = fmaxf(m, sc[n][kb][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float mn = fmaxf(mrun[n], m);
+        const float mref = (mn == -INFINITY) ? 0.f : mn;    // a chunk of padding only: exp(-inf - 0) = 0, not NaN
+        const float alpha = __builtin_amdgcn_exp2f((mrun[n] - mref) * L2E);
+        mrun[n] = mn;
+        const float ml = mref * L2E;
+        float l = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < CB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(sc[n][kb][r], L2E, -ml));
+            sc[n][kb][r] = e;
+            l += e;
+          }
+        lrun[n] = lrun[n] * alpha + l;
+        if (c0 > 0) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[n][dt][r] *= alpha;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < CB / 2; ++s) {
+        frag pf[NQ];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pf[n][r] = (bf16_t)sc[n][2 * s][r]; pf[n][4 + r] = (bf16_t)sc[n][2 * s + 1][r]; }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const frag vc = *reinterpret_cast<const frag*>(lds + (c0 / 2 + s) * 4096 + voff[dt]);
+#pragma unroll
+          for (int n = 0; n < NQ; ++n) ot[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc, pf[n], ot[n][dt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      float l = lrun[n];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.0f / l;
+      const int qi = (f0 + n) * 16 + li;
+      if (qi < T) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          *reinterpret_cast<bf16x4*>(ob + (int64_t)qi * ldo + dt * 16) =
+              bf16x4{(bf16_t)(ot[n][dt][0] * inv), (bf16_t)(ot[n][dt][1] * inv), (bf16_t)(ot[n][dt][2] * inv),
+                     (bf16_t)(ot[n][dt][3] * inv)};
+      }
+    }
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // pairs of query tiles round-robin over the waves; an odd last tile goes, alone, to the wave after the last pair
+  const int npair = nq >> 1;
+  for (int pr = wave; pr < npair; pr += 4) tile(std::integral_constant<int, 2>(), 2 * pr);
+  if ((nq & 1) && (npair & 3) == wave) tile(std::integral_constant<int, 1>(), nq - 1);
+}
 
 constexpr int VPE_TOK = 16;   // patch tokens per workgroup
 
@@ -177,6 +354,32 @@ extern "C" int omp_vit_patch_embed(const float* img, const float* w, const float
                        (bf16_t*)out, B, H, W, Hp, Wp, E);
   else { omp_set_error("omp_vit_patch_embed: bad dtype %d", out_dtype); return OMP_ERR_INVALID; }
   OMP_CHECK_LAUNCH("omp_vit_patch_embed");
+  return OMP_OK;
+}
+
+extern "C" int omp_vit_attn(const void* q, int64_t ldq, const void* K, const void* Vt, int Mpad, void* out, int64_t ldo,
+                            int dtype, int B, int T, int nH, omp_stream_t s) {
+  OMP_CHECK_ARG(q && K && Vt && out, "omp_vit_attn: null pointer");
+  OMP_CHECK_ARG(B > 0 && T > 0 && nH > 0 && T <= Mpad, "omp_vit_attn: bad shape B=%d T=%d nH=%d Mpad=%d", B, T, nH, Mpad);
+  OMP_CHECK_ARG(ldq % 8 == 0 && ldo % 4 == 0, "omp_vit_attn: ldq %% 8, ldo %% 4");
+  if (dtype != OMP_BF16 || Mpad != 288) {
+    omp_set_error("omp_vit_attn: built for bf16 and Mpad = 288 (257 tokens); use omp_dec_cross_attn_step otherwise");
+    return OMP_ERR_UNSUPPORTED;
+  }
+  constexpr int NB = 18;
+  constexpr size_t smem = 2 * (size_t)NB * 16 * 128;
+  auto kern = vit_attn_kernel<NB>;
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      omp_set_error("omp_vit_attn: cannot raise dynamic LDS limit");
+      return OMP_ERR_LAUNCH;
+    }
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nH, B), dim3(256), smem, (hipStream_t)s, (const bf16_t*)q, ldq, (const bf16_t*)K,
+                     (const bf16_t*)Vt, (bf16_t*)out, ldo, T, nH);
+  OMP_CHECK_LAUNCH("omp_vit_attn");
   return OMP_OK;
 }
 

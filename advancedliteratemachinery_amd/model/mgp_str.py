@@ -9,8 +9,9 @@ and with `is_eval=True` -> [[char_attn, bpe_attn, wp_attn], char_out, bpe_out, w
 BPE / WordPiece strings need the GPT-2 / BERT vocabulary files and are left to the caller's tokenizers).
 
 Execution: activations token-major [B*257, 768] in the engine dtype; the ViT-B encoder runs on the shared
-kernels (omp_layernorm, omp_gemm_bias_act, omp_dec_cross_attn_step), see csrc/vit.hip for the mapping of the
-257-token self-attention onto the blocked K / V^T cross-attention kernels.  There is no CPU fallback.
+kernels (omp_layernorm, omp_gemm_bias_act) with the k / v projections writing blocked K / V^T slabs; the 257-token
+self-attention is csrc/vit.hip::vit_attn_kernel in bf16 (one workgroup per (image, head), keys and values in LDS)
+and the blocked cross-attention kernels (omp_dec_cross_attn_step) in fp32.  There is no CPU fallback.
 """
 import torch
 import torch.nn as nn
@@ -146,6 +147,7 @@ class MGPSTR(nn.Module):
             self._names[k] = pname
             self.register_parameter(pname, nn.Parameter(torch.zeros(*shape), requires_grad=False))
         self._engine, self._engine_key = None, None
+        self.vit_attn_kernel = True    # bf16, 257 tokens: csrc/vit.hip::vit_attn_kernel; False = blocked cross-attention kernels
         self.eval()
 
     # reference key names in and out ----------------------------------------------------------------
@@ -196,7 +198,10 @@ class MGPSTR(nn.Module):
             q = ops.gemm(y, blk['wq'], blk['bq'])
             ops.gemm(y, blk['wk'], blk['bk'], out=K, store_mode=_lib.STORE_KBLK, kv=geom)
             ops.gemm(blk['wv'], y, blk['bv'], out=Vt, store_mode=_lib.STORE_VBLK, kv=geom, bias_along_m=True, M=E, N=B * T, K=E)
-            ops.dec_cross_attn_step(q, K[0], Vt[0], nH * Mpad * 64, Mpad, None, groups, n_groups, 4, None, att, T, nH, 1)
+            if self.vit_attn_kernel and dt == torch.bfloat16 and Mpad == 288:
+                ops.vit_attn(q, K[0], Vt[0], att, B, T, nH, Mpad)     # one workgroup per (image, head), K / V^T in LDS
+            else:
+                ops.dec_cross_attn_step(q, K[0], Vt[0], nH * Mpad * 64, Mpad, None, groups, n_groups, 4, None, att, T, nH, 1)
             ops.gemm(att, blk['wo'], blk['bo'], residual=x, out=x)
             ops.layernorm(x, blk['n2'][0], blk['n2'][1], out=y, eps=LN_EPS_BLOCK)
             h = ops.gemm(y, blk['w1'], blk['b1'], act=ops.ACT_GELU)

@@ -217,6 +217,14 @@ def vit_patch_embed(img, w, bias, cls, pos, out_dtype):
     return out
 
 
+def vit_attn(q, K, Vt, out, B, T, nH, Mpad):
+    """bf16 ViT self-attention on one layer's blocked slabs: q [B*T, nH*64], K [B, nH, Mpad, 64], Vt [B, nH, Mpad/32, 64, 32]
+    -> out [B*T, nH*64] (all heads, all images, one launch)."""
+    rc = _lib.lib().omp_vit_attn(ptr(q), q.stride(0), ptr(K), ptr(Vt), Mpad, ptr(out), out.stride(0), dt(q), B, T, nH, stream())
+    _lib.check(rc, 'omp_vit_attn')
+    return out
+
+
 def a3_pool(sel, feat, B, T, S, want_attn=True):
     """sel fp32 [B*T, >=S], feat [B*T, C] -> (pooled fp32 [B*S, C], maps fp32 [B, S, T] or None)."""
     C = feat.shape[-1]
@@ -235,6 +243,37 @@ def row_argmax_prob(logits):
     rc = _lib.lib().omp_row_argmax_prob(ptr(logits), logits.stride(0), R, V, ptr(ids), ptr(prob), stream())
     _lib.check(rc, 'omp_row_argmax_prob')
     return ids, prob
+
+
+def cu_mask_words(n_per_xcd, total_cus=256, n_xcd=8, complement=False):
+    """CU mask with `n_per_xcd` compute units on every XCD: bit i is set iff (i mod 32) < n_per_xcd ... balanced under both
+    numberings a runtime may use for the mask (XCD-major: xcd = i / 32; interleaved: xcd = i mod 8) when n_per_xcd is a
+    multiple of 8.  complement=True returns the other CUs."""
+    per = total_cus // n_xcd
+    words = [0] * ((total_cus + 31) // 32)
+    for i in range(total_cus):
+        inside = (i % per) < n_per_xcd
+        if inside != complement:
+            words[i // 32] |= 1 << (i % 32)
+    return words
+
+
+def masked_stream(words, device=None):
+    """torch.cuda.ExternalStream on the CUs of `words` (omp_stream_create_cu_mask); the HIP stream lives as long as
+    the process (a handful per lane)."""
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    out = ctypes.c_void_p()
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        rc = _lib.lib().omp_stream_create_cu_mask(ctypes.cast(arr, ctypes.c_void_p), len(words), ctypes.byref(out))
+        _lib.check(rc, 'omp_stream_create_cu_mask')
+        return torch.cuda.ExternalStream(out.value, device=device)
+
+
+def where_probe(n_workgroups):
+    """(xcc_id, hw_id) int32 [n_workgroups, 2] of a short probe grid on the current stream."""
+    out = torch.zeros((n_workgroups, 2), dtype=torch.int32, device='cuda')
+    _lib.check(_lib.lib().omp_debug_where(ptr(out), n_workgroups, stream()), 'omp_debug_where')
+    return out
 
 
 def force_gemm_kernel(which):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 8
+#define OMP_ABI_VERSION 10
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -281,6 +281,15 @@ int omp_decoder_graph_reset(int graph_slot);
  * projections write the blocked slabs, an image's 257 tokens are row groups of that image); these three entry
  * points cover what is specific to MGP-STR. */
 
+/* bf16 self-attention of a ViT layer, all heads of all images in one launch: out[b*T + i, h*64 + :] =
+ * softmax_j(q_i . k_j / 8) v_j.  Replaces timm Attention.forward (the blocks modules/mgp_str.py:71-74 runs).
+ * q [B*T, ldq] (head h at columns h*64), K / Vt = one layer's blocked slabs [B][nH][Mpad][64] and
+ * [B][nH][Mpad/32][64][32] as written by omp_gemm_bias_act with OMP_STORE_KBLK / OMP_STORE_VBLK (kv_key_block 32),
+ * padded keys zero.  Built for dtype OMP_BF16 and Mpad == 288 (T <= 288, MGP-STR: 257); other shapes return
+ * OMP_ERR_UNSUPPORTED and are served by omp_dec_cross_attn_step on the same slabs. */
+int omp_vit_attn(const void* q, int64_t ldq, const void* K, const void* Vt, int Mpad, void* out, int64_t ldo,
+                 int dtype, int B, int T, int nH, omp_stream_t s);
+
 /* Patch embedding + cls token + position embedding.  Replaces timm PatchEmbed (Conv2d(3,E,4,4) -> flatten ->
  * transpose) and modules/mgp_str.py:66-70.  img NCHW fp32 [B,3,H,W] (H, W multiples of 4); w [E,3,4,4], bias [E],
  * cls [E], pos [(H/4)*(W/4)+1, E] fp32; out [B, (H/4)*(W/4)+1, E] token-major, token 0 = cls. */
@@ -296,6 +305,14 @@ int omp_a3_pool(const float* sel, int ld_sel, const void* feat, int dtype, float
 /* Greedy id and its softmax probability for every row of logits fp32 [R, ld] (V columns used).  Replaces
  * topk(1) + softmax(...).max(dim=2) of test_final.py:145-170. */
 int omp_row_argmax_prob(const float* logits, int64_t ld, int R, int V, int32_t* ids, float* prob, omp_stream_t s);
+
+/* ---- streams on a subset of the compute units (engine/pipeline.py: HBM-bound decoder phases of one engine call
+ * next to the matrix-core-bound encoder of another) ---------------------------------------------------------------
+ * mask: n_words x 32 bits, bit i = compute unit i in the runtime's numbering (hipExtStreamCreateWithCUMask).
+ * omp_debug_where: every workgroup of a short probe grid records (XCC_ID, HW_ID) -> out[2 * n_workgroups]. */
+int omp_stream_create_cu_mask(const uint32_t* mask, int n_words, omp_stream_t* out);
+int omp_stream_destroy(omp_stream_t s);
+int omp_debug_where(int32_t* out, int n_workgroups, omp_stream_t s);
 
 /* ---- test-time image pre-processing (the step before the hot path) -----------------
  * Replaces dataset/transforms.py:249-298 (RandomResize([test_min_size], test_max_size) = Pillow bilinear resize

@@ -67,6 +67,13 @@ def dec_cross_attn_step(q, K, Vt, img_stride, Mpad, key_mask, groups, n_groups, 
         out[row0:row0 + nrows] = (att @ vv).permute(1, 0, 2).reshape(nrows, nH * 64).to(out.dtype)
 
 
+def vit_attn(q, K, Vt, out, B, T, nH, Mpad):
+    """test double of omp_vit_attn: same slabs, all T queries of every image at once"""
+    groups = torch.tensor([(b * T, T, b) for b in range(B)], dtype=torch.int32)
+    dec_cross_attn_step(q, K, Vt, nH * Mpad * 64, Mpad, None, groups, B, (T + 15) // 16, None, out, T, nH, 1)
+    return out
+
+
 def vit_patch_embed(img, w, bias, cls, pos, out_dtype):
     B, E = img.shape[0], w.shape[0]
     x = F.conv2d(img, w.reshape(E, 3, 4, 4), bias, stride=4).flatten(2).transpose(1, 2)

@@ -87,6 +87,30 @@ def check_gemm():
                     t_ = tol if dt == torch.float32 else max(tol, ref.abs().max().item() * 2.0 ** -8)
                     out.append(rec('gemm[%s,k%d,%dx%dx%d,%s]' % (dn, which, M, N, K, an), maxerr(y, ref), t_))
             if which == 9:
+                # blocked K / V^T slabs of the cross-attention memory written by the 256x256 kernel's epilogue vs the
+                # same product through gemm_dma (k5): identical slabs expected (same arithmetic order per element)
+                from advancedliteratemachinery_amd import _lib
+                nH, d, K = 8, 512, 512
+                for (Bn, tok) in ((2, 72), (3, 257)):
+                    Mpad = (tok + 31) // 32 * 32
+                    mem = q(rnd(Bn * tok, K, seed=tok), dt).to(DEV, dt)
+                    Wk = q(rnd(2 * d, K, seed=tok + 1) / math.sqrt(K), dt).to(DEV, dt)
+                    bk = rnd(2 * d, seed=tok + 2).to(DEV)
+                    geom = (Bn, tok, Mpad, nH, 32)
+                    slabs = {}
+                    for w2 in (9, 5):
+                        ops.force_gemm_kernel(w2)
+                        Kd = torch.zeros(2, Bn, nH, Mpad, 64, dtype=dt, device=DEV)
+                        ops.gemm(mem, Wk, bk, out=Kd, store_mode=_lib.STORE_KBLK, kv=geom)
+                        Vd = None
+                        if tok % 8 == 0:
+                            Vd = torch.zeros(2, Bn, nH, Mpad // 32, 64, 32, dtype=dt, device=DEV)
+                            ops.gemm(Wk, mem, bk, out=Vd, store_mode=_lib.STORE_VBLK, kv=geom, bias_along_m=True, M=2 * d, N=Bn * tok, K=K)
+                        slabs[w2] = (Kd, Vd)
+                    out.append(rec('gemm[%s,k9 vs k5,K slab,B%d tok%d]' % (dn, Bn, tok), maxerr(slabs[9][0], slabs[5][0].float().cpu()), 0.0))
+                    if slabs[9][1] is not None:
+                        out.append(rec('gemm[%s,k9 vs k5,V^T slab,B%d tok%d]' % (dn, Bn, tok), maxerr(slabs[9][1], slabs[5][1].float().cpu()), 0.0))
+                ops.force_gemm_kernel(9)
                 continue
             # fp32 output + in-place fp32 residual (decoder), bias_row table, transposed store
             M, N, K = 24, 512, 512

@@ -19,7 +19,7 @@ def C():
     return gpu_checks_mgp
 
 
-@pytest.mark.parametrize('name', ['check_vit_patch_embed', 'check_a3_pool', 'check_row_argmax_prob'])
+@pytest.mark.parametrize('name', ['check_vit_patch_embed', 'check_a3_pool', 'check_row_argmax_prob', 'check_vit_attn'])
 def test_mgp_op(C, name):
     _assert_all(getattr(C, name)())
 

@@ -119,6 +119,25 @@ def bench_gemm(dtype=torch.bfloat16):
         ops.force_gemm_kernel(0)
 
 
+def bench_kvproj(dtype=torch.bfloat16):
+    """K / V^T projection of the encoder memory into the blocked slabs (12 (decoder, layer) slabs x 512 features)."""
+    B, tok, K, nH, NL = 64, 4096, 512, 8, 12
+    mem = torch.randn(B * tok, K, device=DEV).to(dtype)
+    W = (torch.randn(NL * 512, K, device=DEV) / K ** 0.5).to(dtype)
+    bias = torch.randn(NL * 512, device=DEV)
+    Kd = torch.zeros(NL, B, nH, tok, 64, dtype=dtype, device=DEV)
+    Vd = torch.zeros(NL, B, nH, tok // 32, 64, 32, dtype=dtype, device=DEV)
+    geom = (B, tok, tok, nH, 32)
+    fl = 2.0 * B * tok * NL * 512 * K
+    for which in GEMM_VARIANTS:
+        ops.force_gemm_kernel(which)
+        us = timeit(lambda: ops.gemm(mem, W, bias, out=Kd, store_mode=_lib.STORE_KBLK, kv=geom), iters=5, warm=2)
+        print('kvproj[k%d] K slabs   %d images : %8.1f us  %6.1f TF/s' % (which, B, us, fl / us / 1e6), flush=True)
+        us = timeit(lambda: ops.gemm(W, mem, bias, out=Vd, store_mode=_lib.STORE_VBLK, kv=geom, bias_along_m=True, M=NL * 512, N=B * tok, K=K), iters=5, warm=2)
+        print('kvproj[k%d] V^T slabs %d images : %8.1f us  %6.1f TF/s' % (which, B, us, fl / us / 1e6), flush=True)
+    ops.force_gemm_kernel(0)
+
+
 def bench_mlp(dtype=torch.bfloat16):
     """Swin MLP per stage at B=8 1024x1024: LayerNorm + fc1(GELU) + fc2(+residual) as three launches vs omp_swin_mlp_fused."""
     from advancedliteratemachinery_amd.model.packing import pack_mlp
@@ -232,5 +251,7 @@ if __name__ == '__main__':
         bench_misc()
     if 'mlp' in what or 'all' in what:
         bench_mlp()
+    if 'kvproj' in what:
+        bench_kvproj()
     if 'cross128' in what:
         bench_cross128()
