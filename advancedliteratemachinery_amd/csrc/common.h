@@ -149,6 +149,36 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// max / sum over the 4 lanes {l, l^16, l^32, l^48} (the lane groups of a 16x16 matrix-core tile hold different
+// contraction slices of the same output column): two register swaps instead of two ds_bpermute round trips.
+// v_permlane32_swap exchanges the upper half of its first operand with the lower half of the second,
+// v_permlane16_swap the odd 16-lane rows of the first with the even rows of the second; fed the same value twice,
+// the two results are the value and its partner's.
+// (inline asm, with the two wait states the swap needs after a VALU write of its operands inside the string: fed the
+// same SSA value twice, hipcc / ROCm 7.2 folds the builtin's two results into one -- it emitted max(r0, r0).)
+__device__ __forceinline__ void lane_swap32(float& a, float& b) {
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_swap16(float& a, float& b) {
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float quad_group_max(float v) {
+  float a = v, b = v;
+  lane_swap32(a, b);
+  a = fmaxf(a, b);
+  b = a;
+  lane_swap16(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float quad_group_sum(float v) {
+  float a = v, b = v;
+  lane_swap32(a, b);
+  a = a + b;
+  b = a;
+  lane_swap16(a, b);
+  return a + b;
+}
+
 // erf(a), branch-free: both ranges are evaluated and selected, so a wave never diverges (the library erff
 // takes two divergent paths and costs several hundred cycles per element in a GEMM epilogue).  Minimax
 // polynomials for |a| <= 0.9277 and 1 - exp(poly) above; max error < 1 ulp (8.8e-8 relative, checked against

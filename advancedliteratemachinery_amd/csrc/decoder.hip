@@ -433,8 +433,7 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
             bmax = fmaxf(bmax, v);
           }
         }
-        bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
-        bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+        bmax = quad_group_max(bmax);   // register swaps, no LDS round trip (common.h)
         const float mn = fmaxf(m[t], bmax);
         // If every key seen so far is masked (mn = -inf) use 0 as the reference so exp(-inf - 0) = 0, not NaN.
         const float mref = (mn == -INFINITY) ? 0.f : mn;
@@ -470,9 +469,7 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     if (t < nqt) {
-      float l = lpart[t];
-      l += __shfl_xor(l, 16, 64);
-      l += __shfl_xor(l, 32, 64);
+      const float l = quad_group_sum(lpart[t]);
       float* mine = part + ((wave * QT + t) * 16 + li) * PSTR;
       if (g == 0) { mine[0] = m[t]; mine[1] = l; }
 #pragma unroll
@@ -516,16 +513,19 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
 // dec_cross_merge_kernel).  LDS image of a block = 32 rows x 128 B for K (row = key) and for V^T (row = two
 // consecutive dims x 32 key slots); a DMA instruction fills 8 rows lane-linearly, so the XOR swizzle that
 // makes the 16-byte fragment reads conflict-free (slot = chunk ^ (row & 7)) is applied to the per-lane
-// SOURCE address.  Ring protocol as in gemm_dma: wait own DMA of block b (counted vmcnt, later blocks stay in
-// flight) -> one s_barrier (everybody's part of b has landed, everybody is done with b-1) -> refill the
-// stage of b-1 with block b+NS-1 -> compute b.
+// SOURCE address.  The ring is consumed in CHUNKS of CH blocks (64 keys at CH = 2): wait own DMA of chunk c
+// (counted vmcnt, later chunks stay in flight) -> one s_barrier (everybody's part of c has landed, everybody is
+// done with c-1) -> refill the stages of c-1 with chunk c+D -> compute c with ONE running-max update, one
+// accumulator rescale and one cross-lane maximum (v_permlane swaps, no LDS round trip) per chunk.
 // ---------------------------------------------------------------------------------------------
-template <int NS>
+template <int NS, int CH>
 __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
   typedef bf16_t T;
   typedef Mma<T> MM;
   typedef MM::frag frag;
   constexpr int KB = 32, BLKB = 8192;   // keys per block; bytes per ring stage (K then V^T)
+  constexpr int SLOTS = NS / CH, D = SLOTS - 1;   // a chunk = CH blocks; D chunks in flight ahead of the one in use
+  static_assert(NS % CH == 0 && D >= 1 && 2 * CH * (D - 1) <= 28, "ring geometry");
   extern __shared__ __attribute__((aligned(16))) char ring[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int grp = blockIdx.x, h = blockIdx.y, sp = blockIdx.z, S = gridDim.z;
@@ -535,23 +535,31 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
   int kend = kbeg + p.kpw;
   if (kend > p.M) kend = p.M;
   const int nblk = kbeg < kend ? (kend - kbeg + KB - 1) / KB : 0;
+  const int nchunk = (nblk + CH - 1) / CH;
 
   const int64_t slab = (int64_t)img * p.img_stride + (int64_t)h * p.Mpad * 64;
   // DMA: lane l of this wave's instruction fills slot (l & 7) of row 8*wave + (l >> 3) of the block image
   const int dr = lane >> 3, dc = (lane & 7) ^ dr;
   const T* ksrc = reinterpret_cast<const T*>(p.K) + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
   const T* vsrc = reinterpret_cast<const T*>(p.V) + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
-  auto issue = [&](int blk, int stage) {
-    const int64_t off = (int64_t)(kbeg + blk * KB) * 64;   // a block is KB*64 elements in both slabs
-    char* dst = ring + stage * BLKB + wave * 1024;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + off),
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + off),
-                                     (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 0);
+  // chunk c -> ring stages slot * CH .. slot * CH + CH - 1.  A ragged last chunk re-requests the last valid block for
+  // its missing ones: their keys are masked below, but their V^T image must hold finite numbers (0 x NaN = NaN)
+  auto issue_chunk = [&](int c, int slot) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      int blk = c * CH + j;
+      if (blk > nblk - 1) blk = nblk - 1;
+      const int64_t off = (int64_t)(kbeg + blk * KB) * 64;   // a block is KB*64 elements in both slabs
+      char* dst = ring + (slot * CH + j) * BLKB + wave * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + off),
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + off),
+                                       (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 0);
+    }
   };
 #pragma unroll
-  for (int t = 0; t < NS - 1; ++t)
-    if (t < nblk) issue(t, t);
+  for (int t = 0; t < D; ++t)
+    if (t < nchunk) issue_chunk(t, t);
 
   // fragment byte offsets inside a stage
   int koff[2][2], voff[4];
@@ -587,82 +595,84 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int st_c = 0, st_i = NS - 1;
-  for (int b = 0; b < nblk; ++b) {
-    const int after = nblk - 1 - b;
-    wait_dma_blocks<2>(after < NS - 2 ? after : NS - 2);
+  int sl_c = 0, sl_i = D;   // slot in use, slot to refill (the one used by the previous chunk)
+  for (int c = 0; c < nchunk; ++c) {
+    const int after = nchunk - 1 - c;
+    wait_dma_blocks<2 * CH>(after < D - 1 ? after : D - 1);
     __builtin_amdgcn_s_barrier();
-    if (b + NS - 1 < nblk) issue(b + NS - 1, st_i);
+    if (c + D < nchunk) issue_chunk(c + D, sl_i);
     if (active) {
-      const char* base = ring + st_c * BLKB;
-      const int k0 = kbeg + b * KB;
-      frag kc[2][2], vc[4];
+      float sc[CH * 8];
 #pragma unroll
-      for (int sb = 0; sb < 2; ++sb)
+      for (int j = 0; j < CH; ++j) {
+        const char* base = ring + (sl_c * CH + j) * BLKB;
 #pragma unroll
-        for (int st = 0; st < 2; ++st) kc[sb][st] = *reinterpret_cast<const frag*>(base + koff[sb][st]);
+        for (int sb = 0; sb < 2; ++sb) {
+          const frag k0f = *reinterpret_cast<const frag*>(base + koff[sb][0]);
+          const frag k1f = *reinterpret_cast<const frag*>(base + koff[sb][1]);
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+          MM::mma(sacc, k0f, qf[0]);
+          MM::mma(sacc, k1f, qf[1]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) vc[dt] = *reinterpret_cast<const frag*>(base + voff[dt]);
-      float sc[8];
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
-        f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
-        MM::mma(sacc, kc[sb][0], qf[0]);
-        MM::mma(sacc, kc[sb][1], qf[1]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sc[sb * 4 + r] = sacc[r];
+          for (int r = 0; r < 4; ++r) sc[j * 8 + sb * 4 + r] = sacc[r];
+        }
       }
       // masking, branch-free per element (both conditions are wave-uniform): key padding mask bytes are all
       // loaded before any is used; the ragged tail of the split needs only the index compare
+      const int k0 = kbeg + c * CH * KB;
       if (km != nullptr) {
-        uint8_t mk[8];
+        uint8_t mk[CH * 8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int kk = k0 + (i >> 2) * 16 + g * 4 + (i & 3);
+        for (int i = 0; i < CH * 8; ++i) {
+          const int kk = k0 + (i >> 3) * KB + ((i >> 2) & 1) * 16 + g * 4 + (i & 3);
           mk[i] = km[kk < p.M ? kk : p.M - 1];
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int kk = k0 + (i >> 2) * 16 + g * 4 + (i & 3);
+        for (int i = 0; i < CH * 8; ++i) {
+          const int kk = k0 + (i >> 3) * KB + ((i >> 2) & 1) * 16 + g * 4 + (i & 3);
           const bool dead = (kk >= kend) | (mk[i] != 0);
           sc[i] = dead ? -INFINITY : sc[i];
         }
-      } else if (k0 + KB > kend) {
+      } else if (k0 + CH * KB > kend) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int kk = k0 + (i >> 2) * 16 + g * 4 + (i & 3);
+        for (int i = 0; i < CH * 8; ++i) {
+          const int kk = k0 + (i >> 3) * KB + ((i >> 2) & 1) * 16 + g * 4 + (i & 3);
           sc[i] = (kk >= kend) ? -INFINITY : sc[i];
         }
       }
       float bmax = sc[0];
 #pragma unroll
-      for (int i = 1; i < 8; ++i) bmax = fmaxf(bmax, sc[i]);
-      bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
-      bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+      for (int i = 1; i < CH * 8; ++i) bmax = fmaxf(bmax, sc[i]);
+      bmax = quad_group_max(bmax);        // the 4 lane groups hold different keys of the same query
       const float mn = fmaxf(m, bmax);
       const float mref = (mn == -INFINITY) ? 0.f : mn;   // all keys so far masked: exp(-inf - 0) = 0, not NaN
       const float alpha = __expf(m - mref);
       float ps = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { sc[i] = __expf(sc[i] - mref); ps += sc[i]; }
+      for (int i = 0; i < CH * 8; ++i) { sc[i] = __expf(sc[i] - mref); ps += sc[i]; }
       lpart = lpart * alpha + ps;
       m = mn;
-      const frag pf = CrossTraits<T>::pfrag(sc);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
+      for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
-        MM::mma(ot[dt], vc[dt], pf);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const char* base = ring + (sl_c * CH + j) * BLKB;
+        const frag pf = CrossTraits<T>::pfrag(sc + j * 8);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const frag vc = *reinterpret_cast<const frag*>(base + voff[dt]);
+          MM::mma(ot[dt], vc, pf);
+        }
       }
     }
-    st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
-    st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
+    sl_c = (sl_c + 1 == SLOTS) ? 0 : sl_c + 1;
+    sl_i = (sl_i + 1 == SLOTS) ? 0 : sl_i + 1;
   }
 
   if (!active) return;
-  float l = lpart;
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
+  const float l = quad_group_sum(lpart);
   const int qi = wave * 16 + li;
   if (qi >= nrows) return;
   if (S == 1) {
@@ -808,12 +818,12 @@ int launch_merge(const CrossP& cp, int S, hipStream_t st) {
 }
 
 int g_self_attn_impl = 0;   // 0 auto, 1 one wave per (row, head), 2 one wave per row (omp_debug_self_attn_impl)
-int g_cross_q4 = 1;   // 1 = LDS-ring kernel for 33..64 rows per image (bf16); 0 = register-streaming kernel everywhere
+int g_cross_q4 = 1;   // 1 = LDS-ring kernel for 33..64 rows per image (bf16), 64-key chunks; 2 = the same, one block per step; 0 = register-streaming kernel everywhere
 
-template <int NS>
+template <int NS, int CH>
 int launch_cross_q4(const CrossP& cp, int n_groups, int S, hipStream_t st) {
   const size_t smem = (size_t)NS * 8192;
-  auto kern = dec_cross_attn_q4_kernel<NS>;
+  auto kern = dec_cross_attn_q4_kernel<NS, CH>;
   static bool done = false;   // per template instantiation
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -845,7 +855,7 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   int rc;
   const bool f = dtype == OMP_F32;
   // PD key blocks in flight per wave: with one query tile a wave's whole slice is usually 4 blocks -> all of it
-  if (q4) rc = launch_cross_q4<8>(cp, n_groups, S, st);
+  if (q4) rc = (g_cross_q4 == 2) ? launch_cross_q4<8, 1>(cp, n_groups, S, st) : launch_cross_q4<8, 2>(cp, n_groups, S, st);
   else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : ((g_cross_nt && n_groups >= 32) ? launch_cross_t<bf16_t, 1, 4, true>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st));
   else if (qt == 2) rc = f ? launch_cross_t<float, 2, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 2, 2>(cp, n_groups, S, st);
   else rc = f ? launch_cross_t<float, 4, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 4, 2>(cp, n_groups, S, st);
@@ -1056,7 +1066,7 @@ extern "C" int omp_debug_cross_nt(int on) {
 }
 
 extern "C" int omp_debug_cross_q4(int on) {
-  g_cross_q4 = on ? 1 : 0;
+  g_cross_q4 = (on == 2) ? 2 : (on ? 1 : 0);
   return OMP_OK;
 }
 

@@ -153,7 +153,7 @@ int dispatch_ln(LnP p, int x_dtype, int y_dtype, hipStream_t st, const char* nam
 // ---------------------------------------------------------------------------------------------
 // PatchEmbed: one block = TOK consecutive tokens of one token-row; thread c = output channel.
 // ---------------------------------------------------------------------------------------------
-constexpr int PE_TOK = 8;
+constexpr int PE_TOK = 16;   // tokens per workgroup: a thread's 48 weights are loaded once per workgroup
 
 template <typename TO>
 __global__ void patch_embed_kernel(const float* __restrict__ img, const float* __restrict__ w,
@@ -182,11 +182,17 @@ __global__ void patch_embed_kernel(const float* __restrict__ img, const float* _
       wr[i] = t4[0]; wr[i + 1] = t4[1]; wr[i + 2] = t4[2]; wr[i + 3] = t4[3];
     }
     const float bv = bias[tid];
-#pragma unroll
+#pragma unroll 4
     for (int t = 0; t < PE_TOK; ++t) {
       float a = 0.f;
 #pragma unroll
-      for (int e = 0; e < 48; ++e) a = fmaf(wr[e], patch[t * 48 + e], a);
+      for (int e = 0; e < 48; e += 4) {   // wave-wide broadcast reads, 16 bytes each (the kernel is LDS-issue bound)
+        const f32x4 p4 = *reinterpret_cast<const f32x4*>(patch + t * 48 + e);
+        a = fmaf(wr[e], p4[0], a);
+        a = fmaf(wr[e + 1], p4[1], a);
+        a = fmaf(wr[e + 2], p4[2], a);
+        a = fmaf(wr[e + 3], p4[3], a);
+      }
       vals[t * E + tid] = a + bv;
     }
   }

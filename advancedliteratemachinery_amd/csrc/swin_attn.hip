@@ -394,8 +394,7 @@ __global__ __launch_bounds__(256, (EXPB && sizeof(T) == 2) ? 4 : 2) void swin_at
         mx = fmaxf(mx, a);
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = quad_group_max(mx);
     float l = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -403,8 +402,7 @@ __global__ __launch_bounds__(256, (EXPB && sizeof(T) == 2) ? 4 : 2) void swin_at
       else sc[k] = expf(sc[k] - mx);
       l += sc[k];
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = quad_group_sum(l);
     const float inv = 1.0f / l;
 #pragma unroll
     for (int k = 0; k < 16; ++k) sc[k] *= inv;

@@ -125,8 +125,7 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(const bf16_t* __restri
         for (int kb = 0; kb < CB; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) m = fmaxf(m, sc[n][kb][r]);
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = quad_group_max(m);
         const float mn = fmaxf(mrun[n], m);
         const float mref = (mn == -INFINITY) ? 0.f : mn;    // a chunk of padding only: exp(-inf - 0) = 0, not NaN
         const float alpha = __builtin_amdgcn_exp2f((mrun[n] - mref) * L2E);
@@ -166,9 +165,7 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(const bf16_t* __restri
     }
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
-      float l = lrun[n];
-      l += __shfl_xor(l, 16, 64);
-      l += __shfl_xor(l, 32, 64);
+      const float l = quad_group_sum(lrun[n]);
       const float inv = 1.0f / l;
       const int qi = (f0 + n) * 16 + li;
       if (qi < T) {

@@ -83,6 +83,7 @@ class Encoder(object):
                 raise ValueError('FPN needs 4 backbone stages')
             # fpn_in[0] consumes c5 ... fpn_in[3] consumes c2 (reference fpn.py:18-19)
             self.fpn_w = [mat('fpn.fpn_in.%d.weight' % i).reshape(256, -1).contiguous() for i in range(4)]
+        self._pos_cache = {}   # (B, h, w, device) -> sine embedding of an all-False mask (encode(no_padding=True))
         self.proj_w = mat('input_proj.weight').reshape(args.tfm_hidden_dim, -1).contiguous()
         self.proj_b = f32('input_proj.bias')
 
@@ -121,8 +122,10 @@ class Encoder(object):
         return ops.mask_nearest(m8.contiguous(), h, w)
 
     # -- full encode ----------------------------------------------------------------------------
-    def encode(self, img, mask, want_intermediates=False):
-        """-> dict(memory [B*M,d], mem_pos [B*M,d], key_mask uint8 [B,M] or None, M, hw)."""
+    def encode(self, img, mask, want_intermediates=False, no_padding=False, out=None):
+        """-> dict(memory [B*M,d], mem_pos [B*M,d], key_mask uint8 [B,M] or None, M, hw).
+        no_padding: the caller knows `mask` is all False -> the sine embedding (a function of the mask only) is taken from a
+        per-shape cache.  out: optional (memory, mem_pos) destination views of a larger engine call (_encode_chunked)."""
         B = img.shape[0]
         feats = self.backbone(img)
         if self.use_fpn:
@@ -140,16 +143,25 @@ class Encoder(object):
             src, ho, wo = feats[-1]
             lvl = (ho, wo)
         lm = self.level_mask(mask, *lvl)
-        pos = ops.sine_posembed(lm, self.args.tfm_hidden_dim // 2, self.dtype)
         M = ho * wo
-        pos = pos.view(B * M, -1)
+        pkey = (B, ho, wo, src.device)
+        pos = self._pos_cache.get(pkey) if no_padding else None
+        if pos is None:
+            pos = ops.sine_posembed(lm, self.args.tfm_hidden_dim // 2, self.dtype).view(B * M, -1)
+            if no_padding:
+                if len(self._pos_cache) >= 8:
+                    self._pos_cache.clear()
+                self._pos_cache[pkey] = pos
         # ONE product, two destinations: memory = src W^T + b and memory + pos (the key input of every decoder layer)
-        memory = torch.empty((B * M, self.proj_w.shape[0]), dtype=self.dtype, device=src.device)
+        if out is not None:
+            memory, mem_pos_out = out
+        else:
+            memory, mem_pos_out = torch.empty((B * M, self.proj_w.shape[0]), dtype=self.dtype, device=src.device), None
         if B * M > 64:
-            mem_pos = ops.gemm(src, self.proj_w, self.proj_b, residual=pos, out_noresidual=memory)
+            mem_pos = ops.gemm(src, self.proj_w, self.proj_b, residual=pos, out_noresidual=memory, out=mem_pos_out)
         else:   # tiny inputs run on the small-M kernels, which have no second destination
             ops.gemm(src, self.proj_w, self.proj_b, out=memory)
-            mem_pos = ops.gemm(src, self.proj_w, self.proj_b, residual=pos)
+            mem_pos = ops.gemm(src, self.proj_w, self.proj_b, residual=pos, out=mem_pos_out)
         out = dict(memory=memory, mem_pos=mem_pos, M=M, hw=(ho, wo), pos=pos, key_mask=lm.reshape(B, M))
         if want_intermediates:
             out['feats'] = feats

@@ -125,7 +125,7 @@ class OmniParser(nn.Module):
             if has_padding is None:
                 has_padding = bool(mask.any())
             self._mark('start')
-            e = self._encode_chunked(enc, img, mask)
+            e = self._encode_chunked(enc, img, mask, no_padding=not has_padding)
             self._mark('encode')
             kv = dec.project_memory(e['memory'], e['mem_pos'], B, e['M'], e['key_mask'] if has_padding else None)
             prompt = [int(t) for t in sequence[0].reshape(-1).tolist()]
@@ -143,17 +143,31 @@ class OmniParser(nn.Module):
                 return out
             return self._decode(dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side)
 
-    def _encode_chunked(self, enc, img, mask):
+    def _encode_chunked(self, enc, img, mask, no_padding=False):
         """The encoder gains nothing from more than a few images per launch (its kernels already fill the chip) while
         its activations grow with the batch; the decoders do gain (their steps are latency-bound).  So a large engine
-        call is encoded `enc_chunk` images at a time and only the (small) memory tensors are concatenated."""
+        call is encoded `enc_chunk` images at a time; every chunk's input_proj writes its rows of the call's memory
+        tensors directly (the first chunk's are copied once its shape is known)."""
         B, ch = img.shape[0], max(1, int(self.enc_chunk))
+        kw = dict(no_padding=True) if no_padding else {}
         if B <= ch:
-            return enc.encode(img, mask)
-        parts = [enc.encode(img[i:i + ch], mask[i:i + ch]) for i in range(0, B, ch)]
-        out = dict(parts[0])
-        for k in ('memory', 'mem_pos', 'pos', 'key_mask'):
-            out[k] = torch.cat([p[k] for p in parts], 0)
+            return enc.encode(img, mask, **kw)
+        first = enc.encode(img[:ch], mask[:ch], **kw)
+        M = first['M']
+        out = dict(first)
+        full = {k: torch.empty((B * M,) + tuple(first[k].shape[1:]), dtype=first[k].dtype, device=first[k].device)
+                for k in ('memory', 'mem_pos')}
+        for k in full:
+            full[k][:ch * M].copy_(first[k])
+        pos, km = [first['pos']], [first['key_mask']]
+        for i in range(ch, B, ch):
+            n = min(ch, B - i)
+            p = enc.encode(img[i:i + n], mask[i:i + n], out=(full['memory'][i * M:(i + n) * M], full['mem_pos'][i * M:(i + n) * M]), **kw)
+            pos.append(p['pos'])
+            km.append(p['key_mask'])
+        out.update(full)
+        out['pos'] = torch.cat(pos, 0)   # small (diagnostics / parity tests only: the decoders read mem_pos)
+        out['key_mask'] = torch.cat(km, 0)
         return out
 
     def _decode(self, dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side):

@@ -283,8 +283,9 @@ def force_gemm_kernel(which):
 
 
 def cross_q4(on):
-    """debug/testing: 1 = LDS-ring cross-attention kernel for 33..64 rows per image (default), 0 = register-streaming kernel."""
-    _lib.check(_lib.lib().omp_debug_cross_q4(1 if on else 0), 'omp_debug_cross_q4')
+    """debug/testing: 1 = LDS-ring cross-attention kernel for 33..64 rows per image, 64-key chunks (default), 2 = the same ring
+    consumed one 32-key block per step, 0 = register-streaming kernel."""
+    _lib.check(_lib.lib().omp_debug_cross_q4(int(on)), 'omp_debug_cross_q4')
 
 
 def swin_attn_impl(which):

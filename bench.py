@@ -59,7 +59,11 @@ def parse():
     p.add_argument('--no-batch8', action='store_true', help='skip the coalesce-1 (true batch-8 engine calls) leg')
     p.add_argument('--no-eos-run', action='store_true', help='skip the EOS-honouring leg')
     p.add_argument('--eos-pt-len', type=int, default=130, help='pt_seq_length of the EOS-honouring leg (<= 64 instances per image)')
-    p.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    p.add_argument('--workload', default='spotting', choices=['spotting', 'kie', 'mgp_str'],
+                   help="spotting = BASELINE config 2 (the bench line the driver records); kie = config 3 (--infer_vie, batch 32 @ "
+                        "960x1280 per GPU); mgp_str = config 5 (MGP-STR ViT-B, batch 512 words).  The side workloads print the same "
+                        "JSON line format for their own metric")
+    p.add_argument('--batch', type=int, default=None, help='images per GPU per step (default: 8 spotting, 32 kie, 512 mgp_str)')
     p.add_argument('--size', type=int, default=1024)
     p.add_argument('--instances', type=int, default=64, help='forced text instances per image')
     p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
@@ -264,6 +268,155 @@ def cpu_baseline(args, sd, size, instances, pt_steps, budget_s=40.0):
                 chars_per_sec=instances * args.rec_length / t_total)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# side workloads (BASELINE configs 3 and 5): same timing protocol, their own metric
+# ---------------------------------------------------------------------------------------------------------------------
+def _timed_loop(a, world, device, step):
+    """W warm-up steps, then exactly K steps between barrier + synchronize pairs (max over ranks), repeated until
+    --min-seconds are measured; -> (median seconds per K steps, all repetitions)."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for i in range(a.warmup):
+        step(i)
+    reps = []
+    while True:
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i)
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        stop = 0.0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        reps.append(el)
+        stop = 1.0 if (sum(reps) >= a.min_seconds or len(reps) >= 64) else 0.0
+        if world > 1:
+            t = torch.tensor([stop], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            stop = float(t.item())
+        if stop > 0:
+            return pct(reps, 0.5), reps
+
+
+def _class_roofline(lib, cls, eager_steps, kernel_name, peak, unit, scale):
+    """hipEvent-bracketed launches of one kernel class over `eager_steps()` -> roofline record (work / time vs peak)."""
+    lib.omp_prof_enable(1 << cls)
+    eager_steps()
+    torch.cuda.synchronize()
+    ms, cnt, work = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+    lib.omp_prof_read_class(cls, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(work))
+    lib.omp_prof_enable(0)
+    if cnt.value == 0 or ms.value <= 0:
+        return None
+    ach = work.value / (ms.value * 1e-3) / scale
+    return dict(bound='mfma' if unit == 'TFLOP/s' else 'hbm', kernel=kernel_name, achieved=ach, peak=peak, unit=unit, frac=ach / peak,
+                traffic=None, launches=int(cnt.value), avg_us=ms.value * 1e3 / cnt.value,
+                note='hipEvent-bracketed eager launches on their launch stream; no PMC pass for this workload (traffic null)')
+
+
+def run_mgp_str(a, device, world, rank):
+    """BASELINE config 5: MGP-STR (ViT-B patch 4, 32x128), batch 512 cropped words per GPU, bf16; step = one forward
+    (encoder, three A^3 modules + heads) + greedy ids / probabilities of the three granularities on the device."""
+    from advancedliteratemachinery_amd import _lib, ops
+    from advancedliteratemachinery_amd.model.mgp_str import MGPSTR
+    from advancedliteratemachinery_amd.utils import synthetic as W
+    B = a.batch or 512
+    c = W.mgp_cfg()
+    sd = W.make_mgp_state_dict(c, seed=0)
+    model = MGPSTR(engine_dtype=a.dtype)
+    model.load_reference_state_dict({'module.' + k: v for k, v in sd.items()})
+    model = model.to(device)
+    g = torch.Generator().manual_seed(99 + rank)
+    pool = [(torch.rand(B, 3, 32, 128, generator=g) * 2 - 1).to(device) for _ in range(2)]
+    stream = torch.cuda.Stream(device=device)
+    last = {}
+
+    def step(i):
+        outs = model(pool[i % 2])
+        last['ids'] = [ops.row_argmax_prob(lg.reshape(B * lg.shape[1], -1)) for lg in outs]
+    with torch.cuda.stream(stream):
+        el, reps = _timed_loop(a, world, device, step)
+        roof = _class_roofline(_lib.lib(), 1, lambda: [step(i) for i in range(2)],
+                               'gemm_256 / gemm_dma (ViT-B q / k / v / proj / fc1 / fc2, A^3 modules, vocabulary heads)', MFMA_PEAK_TFS, 'TFLOP/s', 1e12) if not a.no_roofline else None
+    wps = world * B * a.steps / el
+    res = dict(metric='words/sec, MGP-STR recogniser (ViT-B patch4 32x128)', value=wps, unit='words/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
+               ms_per_step=el / a.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None, dtype=a.dtype, data='synthetic',
+               timing=dict(repeats=len(reps), seconds_measured=sum(reps), ms_per_step_p10=pct(reps, 0.1) / a.steps * 1e3, ms_per_step_p90=pct(reps, 0.9) / a.steps * 1e3),
+               config=dict(workload='MGP-STR (BASELINE config 5), ViT-B patch4 32x128, batch %d words/GPU, %s, three granularities decoded greedily on the device' % (B, a.dtype),
+                           global_batch=world * B, parallelism='word-sharded dp%d' % world, tflops_model=49.8e9 * wps / 1e12),
+               roofline=roof)
+    if rank == 0 and not a.no_cpu_baseline:
+        from oracle import mgp_str_ref as R
+        torch.set_num_threads(min(host_cores(), 64))
+        sdf = {k: v.float() for k, v in sd.items()}
+        img = pool[0][:2].float().cpu()
+        with torch.no_grad():
+            R.forward(sdf, c, img)
+            t0 = time.time()
+            n = 0
+            while time.time() - t0 < 10.0:
+                R.forward(sdf, c, img)
+                n += 1
+        dtc = (time.time() - t0) / n
+        res['cpu_baseline'] = dict(value=2.0 / dtc, unit='words/s', cores=min(host_cores(), 64), kind='port',
+                                   sample='oracle/mgp_str_ref.py forward (fp32) on 2 words, %d repetitions in %.1f s' % (n, time.time() - t0))
+    return res
+
+
+def run_kie(a, device, world, rank):
+    """BASELINE config 3: OmniParser KIE (--infer_vie, SROIE-style classes), Swin-B, batch 32 @ 1280x960 per GPU, bf16.
+    Random weights: decoding is forced to --instances point-sequence items per image (3 tokens each with --infer_vie);
+    the entity walk (transformer.py:143-217) then decodes polygon + recognition for every word it finds."""
+    from advancedliteratemachinery_amd import _lib
+    from advancedliteratemachinery_amd.model import OmniParser
+    from advancedliteratemachinery_amd.utils.parser import make_args
+    from advancedliteratemachinery_amd.utils import synthetic as weights
+    B, N = a.batch or 32, a.instances
+    H, Wd = 960, 1280
+    args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, infer_vie=True, vie_categories=4, val_dataset=['sroie_val'])
+    sd = weights.make_state_dict(args, seed=0)
+    model = OmniParser(args, engine_dtype=a.dtype)
+    model.load_state_dict(sd)
+    model = model.to(device)
+    model.use_graph = bool(a.graph)
+    model.overlap_decoders = bool(a.overlap)
+    seqs = prompts(args) + [torch.tensor([H, Wd])]
+    g = torch.Generator().manual_seed(77 + rank)
+    pool = [torch.randn(B, 3, H, Wd, generator=g).to(device) for _ in range(2)]
+    mask = torch.zeros(B, H, Wd, dtype=torch.bool, device=device)
+    stream = torch.cuda.Stream(device=device)
+    stats = dict(entities=0, words=0, images=0)
+
+    def step(i):
+        res = model.infer(pool[i % 2], mask, seqs, forced_instances=N, has_padding=False)
+        for r in res:
+            stats['images'] += 1
+            if r:
+                stats['entities'] += len(r)
+                stats['words'] += sum(len(t[3]) for t in r)
+    with torch.cuda.stream(stream):
+        el, reps = _timed_loop(a, world, device, step)
+        roof = None
+        if not a.no_roofline:
+            model.use_graph = False
+            roof = _class_roofline(_lib.lib(), 1, lambda: step(0), 'gemm_256 / gemm_dma (Swin-B, FPN, input_proj, K-V projection, large-row decoder GEMMs)',
+                                   MFMA_PEAK_TFS, 'TFLOP/s', 1e12)
+    ips = world * B * a.steps / el
+    return dict(metric='images/sec (1280x960), OmniParser KIE (--infer_vie)', value=ips, unit='images/s', n_gpus=world, steps=a.steps, warmup=a.warmup,
+                ms_per_step=el / a.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None, dtype=a.dtype, data='synthetic',
+                timing=dict(repeats=len(reps), seconds_measured=sum(reps), ms_per_step_p10=pct(reps, 0.1) / a.steps * 1e3, ms_per_step_p90=pct(reps, 0.9) / a.steps * 1e3),
+                config=dict(workload='OmniParser KIE (BASELINE config 3), Swin-B, batch %d/GPU @ 1280x960, forced %d point-sequence items/image, %s' % (B, N, a.dtype),
+                            global_batch=world * B, image_size=[H, Wd], parallelism='image-sharded dp%d' % world,
+                            words_per_image=stats['words'] / max(1, stats['images']), entities_per_image=stats['entities'] / max(1, stats['images'])),
+                roofline=roof)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -288,6 +441,15 @@ def main():
         dist.all_reduce(seen)
         if dist.get_world_size() != a.gpus or int((seen > 0).sum()) != a.gpus or len(set(seen.tolist())) != a.gpus:
             raise SystemExit('RCCL sees %d ranks / devices %s, expected %d distinct' % (dist.get_world_size(), seen.tolist(), a.gpus))
+
+    if a.workload != 'spotting':
+        res = (run_mgp_str if a.workload == 'mgp_str' else run_kie)(a, device, world, rank)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    a.batch = a.batch or 8
 
     from advancedliteratemachinery_amd import _lib
     model, args, sd = build_model(a.dtype, a.graph, device)

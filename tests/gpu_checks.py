@@ -71,7 +71,7 @@ def check_gemm():
             if which == 9 and dt != torch.bfloat16:
                 continue     # the 256x256 phase-interleaved kernel is bf16-only
             ops.force_gemm_kernel(which)
-            for (M, N, K) in shapes + ([(777, 1536, 512), (4100, 520, 2048), (256, 256, 128)] if which == 9 else []):
+            for (M, N, K) in shapes + ([(777, 1536, 512), (4100, 520, 2048), (256, 256, 128), (70000, 768, 256)] if which == 9 else []):
                 if which == 3 and M > 600:
                     continue
                 if which == 9 and N % 8 != 0:
@@ -86,6 +86,12 @@ def check_gemm():
                     # bf16: the OUTPUT is rounded to bf16 -> half an ulp of the largest value on top of the accumulation error
                     t_ = tol if dt == torch.float32 else max(tol, ref.abs().max().item() * 2.0 ** -8)
                     out.append(rec('gemm[%s,k%d,%dx%dx%d,%s]' % (dn, which, M, N, K, an), maxerr(y, ref), t_))
+                if which == 9:
+                    # no residual (qkv / fc1 path of the 256x256 kernel)
+                    ref = F.gelu(A @ W.t() + bias)
+                    y = ops.gemm(A.to(DEV, dt), W.to(DEV, dt), bias.to(DEV), act=ops.ACT_GELU)
+                    out.append(rec('gemm[%s,k%d,%dx%dx%d,gelu,no residual]' % (dn, which, M, N, K), maxerr(y, ref),
+                                   max(tol, ref.abs().max().item() * 2.0 ** -8)))
             if which == 9:
                 # blocked K / V^T slabs of the cross-attention memory written by the 256x256 kernel's epilogue vs the
                 # same product through gemm_dma (k5): identical slabs expected (same arithmetic order per element)

@@ -225,11 +225,16 @@ def test_encoder_chunking_concatenates_memory_in_image_order():
     class FakeEnc(object):
         calls = []
 
-        def encode(self, img, mask):
+        def encode(self, img, mask, out=None):
             b = img.shape[0]
             FakeEnc.calls.append(b)
             ids = img[:, 0, 0, 0].repeat_interleave(4)          # M = 4 memory rows per image, tagged with the image id
-            return dict(memory=ids[:, None].float(), mem_pos=ids[:, None].float() + 0.5, pos=ids[:, None].float() * 0,
+            memory, mem_pos = ids[:, None].float(), ids[:, None].float() + 0.5
+            if out is not None:                                  # later chunks write straight into the call's tensors
+                out[0].copy_(memory)
+                out[1].copy_(mem_pos)
+                memory, mem_pos = out
+            return dict(memory=memory, mem_pos=mem_pos, pos=ids[:, None].float() * 0,
                         key_mask=mask[:, 0, :4].to(torch.uint8), M=4, hw=(2, 2))
 
     m = OmniParser.__new__(OmniParser)
@@ -240,6 +245,7 @@ def test_encoder_chunking_concatenates_memory_in_image_order():
     out = OmniParser._encode_chunked(m, FakeEnc(), img, mask)
     assert FakeEnc.calls == [3, 3, 2]
     assert out['memory'][:, 0].tolist() == [float(i) for i in range(8) for _ in range(4)]
+    assert out['mem_pos'][:, 0].tolist() == [float(i) + 0.5 for i in range(8) for _ in range(4)]
     assert out['key_mask'].shape == (8, 4) and out['key_mask'][5].all() and not out['key_mask'][4].any()
     assert out['M'] == 4 and out['hw'] == (2, 2)
 

@@ -67,8 +67,8 @@ def bench_cross(dtype=torch.bfloat16):
 
 
 def bench_cross128(dtype=torch.bfloat16):
-    """the two cross-attention kernels at the bench's engine-call size (128 images, M = 4096)"""
-    I, M, nH, d, KB = 128, 4096, 8, 512, 32
+    """the two cross-attention kernels at the bench's engine-call size (KBENCH_CROSS_IMAGES images, default 128, M = 4096)"""
+    I, M, nH, d, KB = int(os.environ.get('KBENCH_CROSS_IMAGES', '128')), 4096, 8, 512, 32
     from advancedliteratemachinery_amd.model.transformer import Decoder
     g = torch.Generator(device='cpu').manual_seed(0)
     K = torch.randn(2, I, nH, M, 64, generator=g).to(DEV, dtype)
@@ -84,8 +84,11 @@ def bench_cross128(dtype=torch.bfloat16):
         alg = I * 2 * M * d * 2 + 2 * R * d * 2
         for S in splits:
             partial = torch.empty(R, nH, S, 68, device=DEV)
-            for nt in ((0, 1) if rows_per_img == 1 else (0,)):
-                h.omp_debug_cross_nt(nt)
+            for nt in ((0, 1) if rows_per_img == 1 else (2, 1)):   # 64 rows: nt column = q4 mode (2 = block per step, 1 = 64-key chunks)
+                if rows_per_img == 1:
+                    h.omp_debug_cross_nt(nt)
+                else:
+                    h.omp_debug_cross_q4(nt)
                 st = [0]
 
                 def fn():
@@ -94,6 +97,7 @@ def bench_cross128(dtype=torch.bfloat16):
                 us = timeit(fn, iters=30, warm=4)
                 print('cross128 rows/img=%-2d S=%d nt=%d : %7.1f us  %6.0f GB/s (%.2f of 8 TB/s)' % (rows_per_img, S, nt, us, alg / us / 1e3, alg / us / 1e3 / 8000), flush=True)
     h.omp_debug_cross_nt(0)
+    h.omp_debug_cross_q4(1)
 
 
 def bench_gemm(dtype=torch.bfloat16):
@@ -103,7 +107,9 @@ def bench_gemm(dtype=torch.bfloat16):
               (32768, 1536, 512, 0, 0), (32768, 512, 512, 0, 1), (32768, 2048, 512, 1, 0), (32768, 512, 2048, 0, 1),
               (8192, 3072, 1024, 0, 0), (8192, 1024, 1024, 0, 1), (8192, 4096, 1024, 1, 0), (8192, 1024, 4096, 0, 1),
               (32768, 6144, 512, 0, 0)]
+    ms = int(os.environ.get('KBENCH_GEMM_MSCALE', '1'))   # 4 = the encoder's 32-image chunks
     for (M, N, K, act, res) in shapes:
+        M = M * ms
         A = torch.randn(M, K, device=DEV).to(dtype)
         W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(dtype)
         bias = torch.randn(N, device=DEV)
