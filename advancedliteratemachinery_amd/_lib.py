@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
@@ -99,6 +99,10 @@ _SIGS = {
     'omp_row_argmax_prob': (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'omp_resize_normalize_pad': (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'omp_ctx_create': (c_int, [ctypes.POINTER(c_void_p)]),
+    'omp_ctx_destroy': (c_int, [c_void_p]),
+    'omp_ctx_make_current': (c_int, [c_void_p]),
+    'omp_ctx_current': (c_void_p, []),
     'omp_stream_create_cu_mask': (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p)]),
     'omp_stream_destroy': (c_int, [c_void_p]),
     'omp_debug_where': (c_int, [c_void_p, c_int, c_void_p]),

@@ -1,4 +1,4 @@
-// Error plumbing + ABI version for libomp355.
+// Error plumbing, the context object (all mutable library state) and the ABI version of libomp355.
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -8,25 +8,65 @@
 
 #include "common.h"
 
-namespace {
-thread_local char g_err[512] = "";
-
 // ---- measurement hooks (bench.py roofline legs): hipEvent brackets around eagerly launched kernels of one class ----
-struct ProfClass {
+struct OmpProfClass {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t used = 0;
   double work = 0.0;   // flops (GEMM / MLP) or algorithmic bytes (cross-attention) of the bracketed launches
 };
-ProfClass g_prof[OMP_PROF_NCLASS];
-int g_prof_mask = 0;
-std::mutex g_prof_mu;
+
+namespace {
+thread_local char g_err[512] = "";
+thread_local omp_ctx* t_ctx = nullptr;   // this thread's context; nullptr = the process default
+std::mutex g_prof_mu;                    // the event lists may be appended to from several lane threads of one context
+
+omp_ctx& default_ctx() {
+  static omp_ctx* c = [] {
+    omp_ctx* x = new omp_ctx();
+    x->prof = new OmpProfClass[OMP_PROF_NCLASS];
+    return x;
+  }();
+  return *c;
+}
+}  // namespace
+
+omp_ctx& omp_cur() { return t_ctx != nullptr ? *t_ctx : default_ctx(); }
+
+extern "C" int omp_ctx_create(omp_ctx** out) {
+  OMP_CHECK_ARG(out != nullptr, "omp_ctx_create: null pointer");
+  omp_ctx* c = new omp_ctx();
+  c->prof = new OmpProfClass[OMP_PROF_NCLASS];
+  *out = c;
+  return OMP_OK;
 }
 
-bool omp_prof_active(int cls) { return (g_prof_mask >> cls) & 1; }
+extern "C" int omp_ctx_destroy(omp_ctx* c) {
+  if (c == nullptr) return OMP_OK;
+  OMP_CHECK_ARG(c != &default_ctx(), "omp_ctx_destroy: the default context is not destroyable");
+  if (t_ctx == c) t_ctx = nullptr;
+  for (int i = 0; i < OMP_MAX_GRAPH_SLOTS; ++i) {
+    if (c->slots[i].exec) (void)hipGraphExecDestroy(c->slots[i].exec);
+    if (c->slots[i].graph) (void)hipGraphDestroy(c->slots[i].graph);
+  }
+  for (int k = 0; k < OMP_PROF_NCLASS; ++k)
+    for (auto& e : c->prof[k].ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  delete[] c->prof;
+  delete c;
+  return OMP_OK;
+}
+
+extern "C" int omp_ctx_make_current(omp_ctx* c) {
+  t_ctx = (c == &default_ctx()) ? nullptr : c;
+  return OMP_OK;
+}
+
+extern "C" omp_ctx* omp_ctx_current(void) { return &omp_cur(); }
+
+bool omp_prof_active(int cls) { return (omp_cur().prof_mask >> cls) & 1; }
 
 int omp_prof_begin(int cls, hipStream_t st, double work) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  ProfClass& c = g_prof[cls];
+  OmpProfClass& c = omp_cur().prof[cls];
   if (c.used == c.ev.size()) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
@@ -39,20 +79,22 @@ int omp_prof_begin(int cls, hipStream_t st, double work) {
 
 void omp_prof_end(int cls, int slot, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (slot >= 0 && (size_t)slot < g_prof[cls].ev.size()) (void)hipEventRecord(g_prof[cls].ev[slot].second, st);
+  OmpProfClass& c = omp_cur().prof[cls];
+  if (slot >= 0 && (size_t)slot < c.ev.size()) (void)hipEventRecord(c.ev[slot].second, st);
 }
 
 extern "C" int omp_prof_enable(int mask) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof_mask = mask & ((1 << OMP_PROF_NCLASS) - 1);
-  for (int c = 0; c < OMP_PROF_NCLASS; ++c) { g_prof[c].used = 0; g_prof[c].work = 0.0; }
+  omp_ctx& x = omp_cur();
+  x.prof_mask = mask & ((1 << OMP_PROF_NCLASS) - 1);
+  for (int c = 0; c < OMP_PROF_NCLASS; ++c) { x.prof[c].used = 0; x.prof[c].work = 0.0; }
   return OMP_OK;
 }
 
 extern "C" int omp_prof_read_class(int cls, double* total_ms, int64_t* count, double* work) {
   OMP_CHECK_ARG(cls >= 0 && cls < OMP_PROF_NCLASS, "omp_prof_read_class: bad class %d", cls);
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  ProfClass& c = g_prof[cls];
+  OmpProfClass& c = omp_cur().prof[cls];
   double tot = 0.0;
   for (size_t i = 0; i < c.used; ++i) {
     float ms = 0.f;

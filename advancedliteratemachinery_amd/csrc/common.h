@@ -48,6 +48,36 @@ void omp_set_error(const char* fmt, ...);
 
 // measurement hooks (api.hip): hipEvent brackets around the eagerly launched kernels of one class
 enum { OMP_PROF_CROSS = 0, OMP_PROF_GEMM = 1, OMP_PROF_MLP = 2, OMP_PROF_NCLASS = 3 };
+
+// ---------------------------------------------------------------------------------------------
+// omp_ctx: ALL mutable library state (kernel selectors, development trace buffers, the table of captured decoder-step
+// hipGraphs, the measurement brackets).  A host thread works on its current context (omp_ctx_make_current; the process
+// default context until then); entry points read it once per call.  Nothing else in the library is writable at run
+// time except the thread-local error string and the thread-local "capturing" flag of omp_decoder_run.
+// ---------------------------------------------------------------------------------------------
+constexpr int OMP_MAX_GRAPH_SLOTS = 4096;   // fixed table (no reallocation): pipeline lanes drive their own slots from their own threads
+struct OmpGraphSlot {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+struct OmpProfClass;   // api.hip
+struct omp_ctx {
+  // kernel selectors (omp_debug_*): 0 = the measured default everywhere
+  int force_gemm = 0;        // 0 auto, 3 rows, 4 small split-K, 5 dma 128x128, 6 dma 64x64 ring, 9 = 256x256 phase-interleaved, 15 = 5 + timestamps
+  int cross_q4 = 1;          // 1 = LDS-ring kernel for 33..64 rows per image, 64-key chunks; 2 = one block per step; 3 / 4 development; 0 = register streaming
+  int cross_nt = 1;          // non-temporal K / V^T loads once >= 32 images share a launch
+  int self_attn_impl = 0;    // 0 auto, 1 one wave per (row, head), 2 one wave per row
+  int swin_impl = 0;         // 0 matrix cores, 1 scalar cross-check kernel, 2 matrix cores with per-score table lookups
+  int mlp_variant = 0;       // alternative instantiations of the fused MLP; 100 = traced default
+  unsigned long long* gemm_trace = nullptr;   // device buffers of the TRACE instantiations
+  long long gemm_trace_cap = 0;
+  unsigned long long* mlp_trace = nullptr;
+  OmpGraphSlot slots[OMP_MAX_GRAPH_SLOTS];
+  int prof_mask = 0;
+  OmpProfClass* prof = nullptr;   // [OMP_PROF_NCLASS], owned by the context (api.hip)
+};
+omp_ctx& omp_cur();   // the calling thread's current context
+
 bool omp_prof_active(int cls);
 int omp_prof_begin(int cls, hipStream_t st, double work);   // -> slot
 void omp_prof_end(int cls, int slot, hipStream_t st);

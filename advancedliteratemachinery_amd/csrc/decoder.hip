@@ -518,7 +518,7 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
 // done with c-1) -> refill the stages of c-1 with chunk c+D -> compute c with ONE running-max update, one
 // accumulator rescale and one cross-lane maximum (v_permlane swaps, no LDS round trip) per chunk.
 // ---------------------------------------------------------------------------------------------
-template <int NS, int CH>
+template <int NS, int CH, bool NT>
 __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
   typedef bf16_t T;
   typedef Mma<T> MM;
@@ -551,10 +551,11 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
       if (blk > nblk - 1) blk = nblk - 1;
       const int64_t off = (int64_t)(kbeg + blk * KB) * 64;   // a block is KB*64 elements in both slabs
       char* dst = ring + (slot * CH + j) * BLKB + wave * 1024;
+      // NT: the slabs are read once per step and never fit a cache at 256 images per call -> non-temporal (aux = 2)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + off),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, NT ? 2 : 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + off),
-                                       (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, NT ? 2 : 0);
     }
   };
 #pragma unroll
@@ -780,8 +781,6 @@ __global__ void advance_pos_kernel(int32_t* d_pos) { *d_pos += 1; }
 // optional hipEvent bracketing of the cross-attention kernel (bench.py's roofline measurement)
 thread_local bool g_capturing = false;   // one host thread per pipeline lane may be capturing
 
-int g_cross_nt = 1;   // non-temporal K / V^T loads in the 1-query-tile kernel once >= 32 images share a launch (+3-5 %,
-                      // profiles/r02j_kbench_cross128.txt; a few images' slabs still fit the 256 MB Infinity Cache and want to stay there); omp_debug_cross_nt(0) = plain
 
 template <typename T, int QT, int PD, bool NT = false>
 int launch_cross_t(const CrossP& cp, int n_groups, int S, hipStream_t st) {
@@ -817,13 +816,11 @@ int launch_merge(const CrossP& cp, int S, hipStream_t st) {
   return OMP_OK;
 }
 
-int g_self_attn_impl = 0;   // 0 auto, 1 one wave per (row, head), 2 one wave per row (omp_debug_self_attn_impl)
-int g_cross_q4 = 1;   // 1 = LDS-ring kernel for 33..64 rows per image (bf16), 64-key chunks; 2 = the same, one block per step; 0 = register-streaming kernel everywhere
 
-template <int NS, int CH>
+template <int NS, int CH, bool NT>
 int launch_cross_q4(const CrossP& cp, int n_groups, int S, hipStream_t st) {
   const size_t smem = (size_t)NS * 8192;
-  auto kern = dec_cross_attn_q4_kernel<NS, CH>;
+  auto kern = dec_cross_attn_q4_kernel<NS, CH, NT>;
   static bool done = false;   // per template instantiation
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -844,7 +841,8 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   if (S > 1 && cp.partial == nullptr) { omp_set_error("omp_dec_cross_attn_step: n_split %d needs a partial buffer", S); return OMP_ERR_INVALID; }
   const int KB = dtype == OMP_F32 ? 16 : 32;
   if (cp.Mpad % KB != 0 || cp.Mpad < cp.M) { omp_set_error("omp_dec_cross_attn_step: Mpad %d must be a multiple of %d and >= M", cp.Mpad, KB); return OMP_ERR_INVALID; }
-  const bool q4 = g_cross_q4 != 0 && dtype == OMP_BF16 && qt == 4;   // waves own query tiles, not key slices
+  const omp_ctx& cx = omp_cur();
+  const bool q4 = cx.cross_q4 != 0 && dtype == OMP_BF16 && qt == 4;   // waves own query tiles, not key slices
   const int slices = q4 ? S : S * 4;
   cp.kpw = (((cp.M + slices - 1) / slices + KB - 1) / KB) * KB;
   const bool prof = omp_prof_active(OMP_PROF_CROSS) && !g_capturing;
@@ -855,8 +853,16 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   int rc;
   const bool f = dtype == OMP_F32;
   // PD key blocks in flight per wave: with one query tile a wave's whole slice is usually 4 blocks -> all of it
-  if (q4) rc = (g_cross_q4 == 2) ? launch_cross_q4<8, 1>(cp, n_groups, S, st) : launch_cross_q4<8, 2>(cp, n_groups, S, st);
-  else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : ((g_cross_nt && n_groups >= 32) ? launch_cross_t<bf16_t, 1, 4, true>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st));
+  if (q4) {
+    const bool nt = cx.cross_nt && n_groups >= 32;
+    switch (cx.cross_q4) {
+      case 2: rc = launch_cross_q4<8, 1, false>(cp, n_groups, S, st); break;    // one block per step (round-2 start)
+      case 3: rc = launch_cross_q4<10, 2, true>(cp, n_groups, S, st); break;    // development: 4 chunks ahead, 80 KB ring
+      case 4: rc = launch_cross_q4<8, 2, false>(cp, n_groups, S, st); break;    // development: chunks, temporal loads
+      default: rc = nt ? launch_cross_q4<8, 2, true>(cp, n_groups, S, st) : launch_cross_q4<8, 2, false>(cp, n_groups, S, st);
+    }
+  }
+  else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : ((cx.cross_nt && n_groups >= 32) ? launch_cross_t<bf16_t, 1, 4, true>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st));
   else if (qt == 2) rc = f ? launch_cross_t<float, 2, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 2, 2>(cp, n_groups, S, st);
   else rc = f ? launch_cross_t<float, 4, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 4, 2>(cp, n_groups, S, st);
   if (rc != OMP_OK) return rc;
@@ -895,7 +901,8 @@ extern "C" int omp_dec_self_attn_step(const void* qkv, void* kcache, void* vcach
   OMP_CHECK_ARG(d == nH * DH, "omp_dec_self_attn_step: head_dim must be 64 (d=%d nH=%d)", d, nH);
   OMP_CHECK_ARG(dtype == OMP_F32 || dtype == OMP_BF16, "omp_dec_self_attn_step: bad dtype");
   // many rows, short caches (polygon / recognition): one wave per row; few rows, long caches (points): one wave per (row, head)
-  const bool rows = g_self_attn_impl == 2 || (g_self_attn_impl == 0 && nH == 8 && R >= 1024);
+  const int impl = omp_cur().self_attn_impl;
+  const bool rows = impl == 2 || (impl == 0 && nH == 8 && R >= 1024);
   if (rows) {
     OMP_CHECK_ARG(nH == 8, "omp_dec_self_attn_step: the row kernel covers d = 512 (8 heads)");
     dim3 g4((R + 3) / 4);
@@ -1040,14 +1047,6 @@ int check_plan(const omp_decoder_plan* P) {
   return OMP_OK;
 }
 
-struct GraphSlot {
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-};
-// fixed table (no reallocation): pipeline lanes drive their own slots from their own host threads
-constexpr int MAX_GRAPH_SLOTS = 4096;
-GraphSlot g_slots[MAX_GRAPH_SLOTS];
-
 int sample_and_advance(const omp_decoder_plan* P, hipStream_t st) {
   return omp_head_softmax_mask_argmax(P->logits, P->vocab, P->R, &P->sample, P->seq, P->probs, P->seq_ld,
                                       P->finished, P->lengths, P->d_pos, 1, st);
@@ -1056,25 +1055,26 @@ int sample_and_advance(const omp_decoder_plan* P, hipStream_t st) {
 }  // namespace
 
 extern "C" int omp_debug_self_attn_impl(int which) {
-  g_self_attn_impl = (which == 1 || which == 2) ? which : 0;
+  omp_cur().self_attn_impl = (which == 1 || which == 2) ? which : 0;
   return OMP_OK;
 }
 
 extern "C" int omp_debug_cross_nt(int on) {
-  g_cross_nt = on ? 1 : 0;
+  omp_cur().cross_nt = on ? 1 : 0;
   return OMP_OK;
 }
 
 extern "C" int omp_debug_cross_q4(int on) {
-  g_cross_q4 = (on == 2) ? 2 : (on ? 1 : 0);
+  omp_cur().cross_q4 = (on >= 0 && on <= 4) ? on : 1;
   return OMP_OK;
 }
 
 extern "C" int omp_decoder_graph_reset(int slot) {
-  if (slot >= 0 && slot < MAX_GRAPH_SLOTS) {
-    if (g_slots[slot].exec) (void)hipGraphExecDestroy(g_slots[slot].exec);
-    if (g_slots[slot].graph) (void)hipGraphDestroy(g_slots[slot].graph);
-    g_slots[slot] = GraphSlot();
+  if (slot >= 0 && slot < OMP_MAX_GRAPH_SLOTS) {
+    OmpGraphSlot& gs = omp_cur().slots[slot];
+    if (gs.exec) (void)hipGraphExecDestroy(gs.exec);
+    if (gs.graph) (void)hipGraphDestroy(gs.graph);
+    gs = OmpGraphSlot();
   }
   return OMP_OK;
 }
@@ -1100,8 +1100,8 @@ extern "C" int omp_decoder_run(const omp_decoder_plan* P, int first_pos, int n_s
       RUN(sample_and_advance(P, st));
       continue;
     }
-    OMP_CHECK_ARG(graph_slot < MAX_GRAPH_SLOTS, "omp_decoder_run: graph slot %d out of range", graph_slot);
-    GraphSlot& gs = g_slots[graph_slot];
+    OMP_CHECK_ARG(graph_slot < OMP_MAX_GRAPH_SLOTS, "omp_decoder_run: graph slot %d out of range", graph_slot);
+    OmpGraphSlot& gs = omp_cur().slots[graph_slot];
     if (gs.exec == nullptr) {
       hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
       if (e != hipSuccess) { omp_set_error("omp_decoder_run: begin capture: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }

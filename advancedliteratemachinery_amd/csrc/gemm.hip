@@ -21,9 +21,6 @@
 
 namespace {
 
-unsigned long long* g_trace = nullptr;   // omp_debug_set_gemm_trace: [capacity][8] s_memtime stamps per workgroup
-long long g_trace_cap = 0;
-int g_force_kernel = 0;  // 0 auto, 3 rows, 4 small split-K, 5 dma 128x128 (2 stages), 6 dma 64x64 ring, 9 = 256x256 phase-interleaved, 15 = 5 with phase timestamps
 
 struct GemmP {
   const void* A; int64_t lda;
@@ -671,7 +668,8 @@ int launch_small(const GemmP& p, hipStream_t st) {
 template <typename T, typename TOut>
 int launch_gemm(const GemmP& p0, hipStream_t st) {
   GemmP p = p0;
-  int which = g_force_kernel;
+  omp_ctx& cx = omp_cur();
+  int which = cx.force_gemm;
   const int kq = 4 * Mma<T>::KSTEP;
   if (p.ln_g != nullptr || which == 4 || (which == 0 && p.small_hint && p.M <= 64 && p.K % kq == 0)) {
     if (p.M > 64 || p.K % kq != 0 || p.trans_out) {
@@ -724,11 +722,11 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
     }
   } else if (which == 15) {          // development: gemm_dma<128,128,2> with per-workgroup phase timestamps
     p.tiles_m = (int)ceil_div64(p.M, 128); p.tiles_n = (int)ceil_div64(p.N, 128);
-    if (g_trace == nullptr || (long long)p.tiles_m * p.tiles_n > g_trace_cap) {
+    if (cx.gemm_trace == nullptr || (long long)p.tiles_m * p.tiles_n > cx.gemm_trace_cap) {
       omp_set_error("omp_gemm_bias_act: selector 15 needs omp_debug_set_gemm_trace(buffer for >= %d workgroups)", p.tiles_m * p.tiles_n);
       return OMP_ERR_INVALID;
     }
-    p.trace = g_trace;
+    p.trace = cx.gemm_trace;
     int rc = launch_dma<T, TOut, 128, 128, 2, true>(p, st);
     if (rc != OMP_OK) return rc;
   } else if (which == 3) {
@@ -745,13 +743,13 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
 }  // namespace
 
 extern "C" int omp_debug_set_gemm_trace(void* buffer, int64_t n_workgroups) {
-  g_trace = reinterpret_cast<unsigned long long*>(buffer);
-  g_trace_cap = buffer ? n_workgroups : 0;
+  omp_cur().gemm_trace = reinterpret_cast<unsigned long long*>(buffer);
+  omp_cur().gemm_trace_cap = buffer ? n_workgroups : 0;
   return OMP_OK;
 }
 
 extern "C" int omp_debug_force_gemm_kernel(int which) {
-  g_force_kernel = which;
+  omp_cur().force_gemm = which;
   return OMP_OK;
 }
 

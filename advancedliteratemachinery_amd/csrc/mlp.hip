@@ -263,19 +263,17 @@ int launch_mlp(const MlpP& p, hipStream_t st) {
   return OMP_OK;
 }
 
-int g_mlp_variant = 0;   // development: omp_debug_swin_mlp_variant (variants >= 100: TRACE builds of the defaults)
-unsigned long long* g_mlp_trace = nullptr;
 int dispatch_mlp(const MlpP& p, int C, int v, hipStream_t st);
 
 }  // namespace
 
 extern "C" int omp_debug_swin_mlp_variant(int v) {
-  g_mlp_variant = v;
+  omp_cur().mlp_variant = v;
   return OMP_OK;
 }
 
 extern "C" int omp_debug_swin_mlp_trace(void* buffer) {
-  g_mlp_trace = reinterpret_cast<unsigned long long*>(buffer);
+  omp_cur().mlp_trace = reinterpret_cast<unsigned long long*>(buffer);
   return OMP_OK;
 }
 
@@ -294,9 +292,9 @@ extern "C" int omp_swin_mlp_fused(const void* x, int64_t ldx, const float* ln_ga
   p.ln_g = ln_gamma; p.ln_b = ln_beta; p.eps = eps;
   p.Wp = reinterpret_cast<const char*>(wpack); p.b2 = b2;
   p.Y = reinterpret_cast<bf16_t*>(y); p.ldy = ldy;
-  p.M = M; p.nsub = hidden / 32; p.trace = g_mlp_trace;
+  p.M = M; p.nsub = hidden / 32; p.trace = omp_cur().mlp_trace;
   hipStream_t st = (hipStream_t)s;
-  const int v = g_mlp_variant;
+  const int v = omp_cur().mlp_variant;
   const int slot = omp_prof_active(OMP_PROF_MLP) ? omp_prof_begin(OMP_PROF_MLP, st, 4.0 * (double)M * C * hidden) : -1;
   const int rc = dispatch_mlp(p, C, v, st);
   if (slot >= 0) omp_prof_end(OMP_PROF_MLP, slot, st);

@@ -437,7 +437,6 @@ __global__ __launch_bounds__(256, (EXPB && sizeof(T) == 2) ? 4 : 2) void swin_at
   }
 }
 
-int g_swin_impl = 0;   // 0 = matrix cores, 1 = scalar cross-check kernel, 2 = matrix cores with per-score table lookups (round-1 path)
 
 // relative_position_bias_table [169, nH] -> per head [64 queries][64 keys] fp32: bias[(dy + 6) * 13 + (dx + 6)] / scale for
 // real tokens, -inf for the 15 padding key slots, 0 for padding query rows (never stored)
@@ -481,7 +480,8 @@ extern "C" int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, con
   const int nWy = (H + WS - 1) / WS, nWx = (W + WS - 1) / WS;
   dim3 grid((unsigned)((int64_t)B * nWy * nWx), (unsigned)((nH + 3) / 4));
   if (dtype != OMP_F32 && dtype != OMP_BF16) { omp_set_error("omp_swin_window_attn: bad dtype %d", dtype); return OMP_ERR_INVALID; }
-  if (g_swin_impl == 1) {
+  const int swin_impl = omp_cur().swin_impl;
+  if (swin_impl == 1) {
     if (dtype == OMP_F32)
       hipLaunchKernelGGL((swin_attn_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv,
                          qkv_bias, rel_bias_table, (float*)out, B, H, W, C, nH, shift, nWy, nWx);
@@ -489,7 +489,7 @@ extern "C" int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, con
       hipLaunchKernelGGL((swin_attn_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv,
                          qkv_bias, rel_bias_table, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx);
   } else {
-    const bool expb = bias_expanded != nullptr && g_swin_impl != 2;
+    const bool expb = bias_expanded != nullptr && swin_impl != 2;
     OMP_CHECK_ARG(expb || rel_bias_table != nullptr, "omp_swin_window_attn: the table form of the bias is needed for this path");
     const float* tb = expb ? bias_expanded : rel_bias_table;
     if (dtype == OMP_F32) {
@@ -505,6 +505,6 @@ extern "C" int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, con
 }
 
 extern "C" int omp_debug_swin_attn_impl(int which) {
-  g_swin_impl = (which == 1 || which == 2) ? which : 0;
+  omp_cur().swin_impl = (which == 1 || which == 2) ? which : 0;
   return OMP_OK;
 }

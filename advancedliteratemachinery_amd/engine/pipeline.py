@@ -52,6 +52,8 @@ class LanePool(object):
             self.device = torch.device(self.device.type, torch.cuda.current_device())
         if dec_priority is None:
             dec_priority = os.environ.get('OMP355_DEC_PRIORITY', '0') == '1'
+        from .. import ops
+        self._ctx = ops.current_context_handle()   # lane threads work on the omp_ctx of the thread that built the pool
         self.lanes = [Lane(self.device, i, dec_priority) for i in range(max(1, n_lanes))]
         self._queues = [queue.Queue() for _ in self.lanes]
         self._next = 0
@@ -65,6 +67,8 @@ class LanePool(object):
         boot_error = None
         try:
             torch.cuda.set_device(self.device)
+            from .. import ops
+            ops.make_context_current(self._ctx)
         except BaseException as e:  # noqa: BLE001 -- a dead lane must fail its jobs, not leave them pending forever
             boot_error = e
         while True:

@@ -245,6 +245,44 @@ def row_argmax_prob(logits):
     return ids, prob
 
 
+class Context(object):
+    """An omp_ctx: independent kernel selectors, captured decoder graphs and measurement brackets (include/omp355.h).
+    `with ctx:` makes it current for the calling thread and restores the previous one; pipeline lane threads inherit the
+    context that was current where their LanePool was created."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().omp_ctx_create(ctypes.byref(h)), 'omp_ctx_create')
+        self.handle = h.value
+        self._prev = []
+
+    def make_current(self):
+        _lib.check(_lib.lib().omp_ctx_make_current(ctypes.c_void_p(self.handle)), 'omp_ctx_make_current')
+
+    def __enter__(self):
+        self._prev.append(current_context_handle())
+        self.make_current()
+        return self
+
+    def __exit__(self, *exc):
+        _lib.check(_lib.lib().omp_ctx_make_current(ctypes.c_void_p(self._prev.pop())), 'omp_ctx_make_current')
+        return False
+
+    def destroy(self):
+        if self.handle:
+            _lib.check(_lib.lib().omp_ctx_destroy(ctypes.c_void_p(self.handle)), 'omp_ctx_destroy')
+            self.handle = None
+
+
+def current_context_handle():
+    """raw omp_ctx* of the calling thread (the process default context unless one was made current)"""
+    return _lib.lib().omp_ctx_current()
+
+
+def make_context_current(handle):
+    _lib.check(_lib.lib().omp_ctx_make_current(ctypes.c_void_p(handle)), 'omp_ctx_make_current')
+
+
 def cu_mask_words(n_per_xcd, total_cus=256, n_xcd=8, complement=False):
     """CU mask with `n_per_xcd` compute units on every XCD: bit i is set iff (i mod 32) < n_per_xcd ... balanced under both
     numberings a runtime may use for the mask (XCD-major: xcd = i / 32; interleaved: xcd = i mod 8) when n_per_xcd is a

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 10
+#define OMP_ABI_VERSION 11
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -305,6 +305,20 @@ int omp_a3_pool(const float* sel, int ld_sel, const void* feat, int dtype, float
 /* Greedy id and its softmax probability for every row of logits fp32 [R, ld] (V columns used).  Replaces
  * topk(1) + softmax(...).max(dim=2) of test_final.py:145-170. */
 int omp_row_argmax_prob(const float* logits, int64_t ld, int R, int V, int32_t* ids, float* prob, omp_stream_t s);
+
+/* ---- context: ALL mutable state of the library ---------------------------------------------------
+ * An omp_ctx holds the kernel selectors (omp_debug_*), the development trace buffers, the table of hipGraphs that
+ * omp_decoder_run captures under its graph_slot ids, and the measurement brackets (omp_prof_*).  Every entry point
+ * works on the CURRENT context of the calling host thread: the process default context until the thread calls
+ * omp_ctx_make_current.  Two engines in one process (or one per pipeline lane) get independent state by creating
+ * their own; destroying a context destroys the graphs it captured.  Beyond the context the library keeps only a
+ * thread-local error string.  Scratch memory is owned by the caller (every buffer is an argument; omp_decoder_plan
+ * lists the decoder's), so there is no omp_workspace_bytes to query. */
+typedef struct omp_ctx omp_ctx;
+int omp_ctx_create(omp_ctx** out);
+int omp_ctx_destroy(omp_ctx* ctx);          /* not the default context */
+int omp_ctx_make_current(omp_ctx* ctx);     /* NULL = back to the process default context */
+omp_ctx* omp_ctx_current(void);             /* the calling thread's context (never NULL) */
 
 /* ---- streams on a subset of the compute units (engine/pipeline.py: HBM-bound decoder phases of one engine call
  * next to the matrix-core-bound encoder of another) ---------------------------------------------------------------

@@ -274,3 +274,32 @@ def test_graph_slots_are_recycled():
     for s in got:
         _GraphSlots.release(s)
     assert _GraphSlots.acquire() >= 0
+
+
+def test_omp_ctx_is_per_thread_and_default_is_protected():
+    """include/omp355.h context API: a thread works on the process default context until it makes another one current;
+    other threads are unaffected; the default context cannot be destroyed."""
+    import ctypes
+    import threading
+    from advancedliteratemachinery_amd import _lib, ops
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('libomp355.so not built')
+    h = _lib.lib()
+    default = ops.current_context_handle()
+    assert default
+    ctx = ops.Context()
+    seen = {}
+    with ctx:
+        assert ops.current_context_handle() == ctx.handle != default
+        t = threading.Thread(target=lambda: seen.setdefault('other', ops.current_context_handle()))
+        t.start()
+        t.join()
+        inner = ops.Context()
+        with inner:
+            assert ops.current_context_handle() == inner.handle
+        assert ops.current_context_handle() == ctx.handle        # restored on exit
+        inner.destroy()
+    assert seen['other'] == default                                # a new thread starts on the default context
+    assert ops.current_context_handle() == default
+    assert h.omp_ctx_destroy(ctypes.c_void_p(default)) != 0        # refused
+    ctx.destroy()
