@@ -857,8 +857,7 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
     const bool nt = cx.cross_nt && n_groups >= 32;
     switch (cx.cross_q4) {
       case 2: rc = launch_cross_q4<8, 1, false>(cp, n_groups, S, st); break;    // one block per step (round-2 start)
-      case 3: rc = launch_cross_q4<10, 2, true>(cp, n_groups, S, st); break;    // development: 4 chunks ahead, 80 KB ring
-      case 4: rc = launch_cross_q4<8, 2, false>(cp, n_groups, S, st); break;    // development: chunks, temporal loads
+      case 4: rc = launch_cross_q4<8, 2, false>(cp, n_groups, S, st); break;    // A/B: chunks with temporal loads (an 80 KB ring, 4 chunks ahead, measured equal: r02y)
       default: rc = nt ? launch_cross_q4<8, 2, true>(cp, n_groups, S, st) : launch_cross_q4<8, 2, false>(cp, n_groups, S, st);
     }
   }
@@ -1065,7 +1064,7 @@ extern "C" int omp_debug_cross_nt(int on) {
 }
 
 extern "C" int omp_debug_cross_q4(int on) {
-  omp_cur().cross_q4 = (on >= 0 && on <= 4) ? on : 1;
+  omp_cur().cross_q4 = (on == 0 || on == 2 || on == 4) ? on : 1;
   return OMP_OK;
 }
 

@@ -356,7 +356,7 @@ int omp_debug_set_gemm_trace(void* buffer, int64_t n_workgroups);
 int omp_debug_swin_attn_impl(int which); /* 0 = matrix-core kernel (default), 1 = scalar cross-check kernel, 2 = matrix cores with per-score table lookups */
 int omp_debug_self_attn_impl(int which); /* 0 auto, 1 = one wave per (row, head), 2 = one wave per row (all 8 heads) */
 int omp_debug_cross_nt(int on);          /* 1 = non-temporal K / V^T loads in the 1-query-tile cross-attention kernel */
-int omp_debug_cross_q4(int on);          /* 1 = LDS-ring cross-attention for 33..64 rows/image (default), 0 = register-streaming kernel */
+int omp_debug_cross_q4(int on);          /* 1 = LDS-ring cross-attention for 33..64 rows/image in 64-key chunks, non-temporal DMA (default), 2 = one 32-key block per step, 4 = chunks with temporal loads, 0 = register-streaming kernel */
 
 /* Single teacher-forced step that also leaves logits in plan->logits (parity tests). */
 int omp_decoder_step_logits(const omp_decoder_plan* plan, int pos, omp_stream_t s);
