@@ -145,13 +145,19 @@ class Encoder(object):
         lm = self.level_mask(mask, *lvl)
         M = ho * wo
         pkey = (B, ho, wo, src.device)
-        pos = self._pos_cache.get(pkey) if no_padding else None
-        if pos is None:
+        hit = self._pos_cache.get(pkey) if no_padding else None
+        if hit is not None:
+            # produced on another stream (pipeline lanes share the encoder): order this stream after its kernel
+            pos, ready = hit
+            torch.cuda.current_stream().wait_event(ready)
+        else:
             pos = ops.sine_posembed(lm, self.args.tfm_hidden_dim // 2, self.dtype).view(B * M, -1)
             if no_padding:
+                ready = torch.cuda.Event()
+                ready.record()
                 if len(self._pos_cache) >= 8:
                     self._pos_cache.clear()
-                self._pos_cache[pkey] = pos
+                self._pos_cache[pkey] = (pos, ready)
         # ONE product, two destinations: memory = src W^T + b and memory + pos (the key input of every decoder layer)
         if out is not None:
             memory, mem_pos_out = out

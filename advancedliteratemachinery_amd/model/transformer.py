@@ -69,15 +69,27 @@ class _GraphSlots(object):
         return -1
 
     @classmethod
-    def release(cls, slot):
+    def release(cls, slot, ctx=None):
+        """ctx: the omp_ctx handle the graph was captured in (the slot tables are per context): it is made current for the
+        reset and the caller's context restored; None = the calling thread's current context."""
         if slot is None or slot < 0:
             return
         try:
-            _lib.lib().omp_decoder_graph_reset(slot)
+            h = _lib.lib()
+            here = h.omp_ctx_current()
+            if ctx is not None and ctx != here:
+                if ctx not in cls._dead_ctx:     # a destroyed context took its graphs with it
+                    h.omp_ctx_make_current(ctx)
+                    h.omp_decoder_graph_reset(slot)
+                    h.omp_ctx_make_current(here)
+            else:
+                h.omp_decoder_graph_reset(slot)
         except Exception:   # noqa: BLE001 -- interpreter shutdown
             return
         with cls._lock:
             cls._free.append(slot)
+
+    _dead_ctx = set()   # handles of destroyed contexts (ops.Context.destroy registers them)
 
 
 # bounds of the per-decoder caches (ADVICE r1): a real evaluation has variable image sizes and instance counts, so
@@ -111,8 +123,8 @@ class _Phase(object):
         self.slots = OrderedDict()   # plan bytes -> graph slot (a phase re-bound to other K/V slabs is another graph)
 
     def release_graphs(self):
-        for slot in self.slots.values():
-            _GraphSlots.release(slot)
+        for slot, ctx in self.slots.values():
+            _GraphSlots.release(slot, ctx)
         self.slots.clear()
 
 
@@ -289,16 +301,17 @@ class Decoder(object):
         # real stream (bench / predict do), eager launches otherwise
         if not self.use_graph or torch.cuda.current_stream().cuda_stream == 0:
             return -1
-        key = bytes(ph.plan)
+        here = _lib.lib().omp_ctx_current()
+        key = bytes(ph.plan) + here.to_bytes(8, 'little')   # a graph lives in the omp_ctx it was captured in
         if key in ph.slots:
             ph.slots.move_to_end(key)
-            return ph.slots[key]
+            return ph.slots[key][0]
         while len(ph.slots) >= MAX_SLOTS_PER_PHASE:
-            _, old = ph.slots.popitem(last=False)
-            _GraphSlots.release(old)
+            _, (old, octx) = ph.slots.popitem(last=False)
+            _GraphSlots.release(old, octx)
         slot = _GraphSlots.acquire()   # -1 (eager launches) only when every slot of the library's table is live
         if slot >= 0:
-            ph.slots[key] = slot
+            ph.slots[key] = (slot, here)
         return slot
 
     def _run(self, ph, first_pos, n_steps):

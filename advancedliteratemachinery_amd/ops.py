@@ -255,6 +255,8 @@ class Context(object):
         _lib.check(_lib.lib().omp_ctx_create(ctypes.byref(h)), 'omp_ctx_create')
         self.handle = h.value
         self._prev = []
+        from .model.transformer import _GraphSlots
+        _GraphSlots._dead_ctx.discard(self.handle)   # the allocator may hand a destroyed context's address out again
 
     def make_current(self):
         _lib.check(_lib.lib().omp_ctx_make_current(ctypes.c_void_p(self.handle)), 'omp_ctx_make_current')
@@ -270,6 +272,8 @@ class Context(object):
 
     def destroy(self):
         if self.handle:
+            from .model.transformer import _GraphSlots
+            _GraphSlots._dead_ctx.add(self.handle)   # graphs captured in it die with it: never reset them through it again
             _lib.check(_lib.lib().omp_ctx_destroy(ctypes.c_void_p(self.handle)), 'omp_ctx_destroy')
             self.handle = None
 

@@ -810,5 +810,58 @@ def check_lanes(dtype_name='fp32', n_lanes=3, n_jobs=7):
     return [rec('lanes==direct[%s,%d lanes,%d jobs]' % (dtype_name, n_lanes, n_jobs), bad, 0)]
 
 
+def check_contexts(dtype_name='bf16'):
+    """omp_ctx (include/omp355.h): a model run inside its own context captures its decoder graphs there and returns what
+    the default context returns; a kernel selector set in one context does not leak into another; destroying the context
+    (with its graphs) leaves the default context usable."""
+    args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=8)
+    depths = (2, 2, 2, 2)
+    sd = weights.make_state_dict(args, seed=6, depths=depths)
+    imgs = rnd(2, 3, 64, 96, seed=8).to(DEV)
+    mask = torch.zeros(2, 64, 96, dtype=torch.bool, device=DEV)
+    seqs = O.default_prompts(args)
+    st = torch.cuda.Stream()
+
+    def run():
+        model = build_model(args, sd, depths, DTYPES[dtype_name], True)
+        with torch.cuda.stream(st):
+            r = model.infer(imgs, mask, seqs, forced_instances=3)
+            r = model.infer(imgs, mask, seqs, forced_instances=3)   # replays the graphs captured by the first call
+        st.synchronize()
+        return r
+    ref = run()
+    ctx = ops.Context()
+    with ctx:
+        ops.force_gemm_kernel(5)        # 128x128 tiles everywhere -- in THIS context only
+        got = run()
+    A, W = q(rnd(600, 512, seed=1), torch.bfloat16).to(DEV, torch.bfloat16), q(rnd(512, 512, seed=2), torch.bfloat16).to(DEV, torch.bfloat16)
+    y_default = ops.gemm(A, W)           # default context: selector untouched -> auto dispatch still works after the `with`
+    ctx.destroy()
+    again = run()
+    bad = 0
+    for b in range(2):
+        for k in range(3):
+            bad += 0 if bool((ref[b][0][k] == again[b][0][k]).all()) else 1
+    # forced 128x128 tiles vs auto dispatch: same arithmetic per element (gemm256.inc header), so tokens agree
+    same = sum(int(bool((ref[b][0][k] == got[b][0][k]).all())) for b in range(2) for k in range(3))
+    return [rec('ctx: default context unchanged by a destroyed context[%s]' % dtype_name, bad, 0),
+            rec('ctx: run inside a private context[%s]' % dtype_name, 6 - same, 0),
+            rec('ctx: gemm in the default context after the private one', maxerr(y_default, A.float().cpu() @ W.float().cpu().t()), 0.5)]
+
+
+def check_masked_stream():
+    """omp_stream_create_cu_mask: a GEMM on a stream restricted to a quarter of the CUs computes the same numbers"""
+    A, W = q(rnd(2048, 512, seed=3), torch.bfloat16).to(DEV, torch.bfloat16), q(rnd(768, 512, seed=4) / 22.0, torch.bfloat16).to(DEV, torch.bfloat16)
+    ref = ops.gemm(A, W)
+    torch.cuda.synchronize()
+    st = ops.masked_stream(ops.cu_mask_words(8))
+    with torch.cuda.stream(st):
+        y = ops.gemm(A, W)
+        where = ops.where_probe(1024)
+    st.synchronize()
+    cus = len(set((int(x) & 15, (int(h) >> 8) & 0xff) for x, h in where.cpu().tolist()))
+    return [rec('masked stream gemm', maxerr(y, ref.float().cpu()), 0.0), rec('masked stream CUs used (<= 64)', max(0, cus - 64), 0, '%d distinct (xcc, se/sh/cu)' % cus)]
+
+
 ALL_OP_CHECKS = [check_layernorm, check_gemm, check_mlp_fused, check_self_attn, check_gemm_small, check_patch_embed, check_window_attn, check_patch_merge, check_fpn,
                  check_posembed, check_sampling, check_cross_attn]

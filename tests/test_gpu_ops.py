@@ -37,3 +37,12 @@ def test_decoder_no_mask(C):
 def test_decoder_longest_sequence(C):
     """config 4 (long structured-sequence decode) up to the reference's 1024-entry position tables"""
     _assert_all(C.check_decoder_long('fp32'))
+
+
+def test_contexts_isolate_state(C):
+    """omp_ctx: private selectors and graph tables per context"""
+    _assert_all(C.check_contexts('bf16'))
+
+
+def test_cu_masked_stream(C):
+    _assert_all(C.check_masked_stream())
