@@ -51,7 +51,7 @@ def bench_cross(dtype=torch.bfloat16):
         q = torch.randn(R, d, device=DEV).to(dtype)
         out = torch.empty(R, d, device=DEV, dtype=dtype)
         alg = B * 2 * M * d * esz + 2 * R * d * esz
-        for S, ring in [(S, r) for r in ((0, 1) if rows_per_img > 32 else (0,)) for S in (1, 2, 4, 8, 16)]:
+        for S, ring in [(S, r) for r in ((0, 2, 1) if rows_per_img > 32 else (0,)) for S in (1, 2, 4, 8, 16)]:   # ring: q4 mode (0 = register streaming, 2 = LDS ring one block per step, 1 = 64-key chunks)
             ops.cross_q4(ring)
             partial = torch.empty(R, nH, S, 68, device=DEV)
             state = [0]
