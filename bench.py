@@ -152,6 +152,19 @@ def pmc_traffic(images_per_launch):
         return None
 
 
+def pmc_gemm_traffic(size, dtype):
+    """Measured HBM bytes of the large GEMMs from the rocprofv3 PMC passes over one encoder chunk + its K / V^T projection
+    (tools/encode_pmc.py, tools/pmc_gemm_json.py -> profiles/pmc_gemm.json): (bytes per launch, measured / algorithmic)."""
+    if size != 1024 or dtype != 'bf16':
+        return None
+    try:
+        with open(os.environ.get('OMP355_PMC_GEMM_JSON', os.path.join(ROOT, 'profiles', 'pmc_gemm.json'))) as f:
+            s_ = json.load(f)['summary']
+        return float(s_['gemm_measured_bytes_per_launch']), float(s_['gemm_measured_over_alg'])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-run this script under torch.distributed.run, one rank per GPU."""
     import socket
@@ -673,10 +686,16 @@ def main():
         recs = []
         if n_gemm:
             tf = f_gemm / (t_gemm / 1e3) / 1e12
-            recs.append((t_gemm, dict(bound='mfma', kernel='gemm_256 + gemm_dma<128,128,2> (Swin qkv / proj / fc1 / fc2 / merge, FPN, input_proj, K-V projection)',
-                                      achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None,
-                                      launches=int(n_gemm), avg_us=t_gemm / n_gemm * 1e3, flops_per_launch=f_gemm / n_gemm,
-                                      gpu_ms_per_image=t_gemm / (n_groups * BI))))
+            gt = pmc_gemm_traffic(a.size, a.dtype)
+            grec = dict(bound='mfma', kernel='gemm_256 + gemm_dma<128,128,2> (Swin qkv / proj / fc1 / fc2 / merge, FPN, input_proj, K-V projection)',
+                        achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=gt[0] if gt else None,
+                        launches=int(n_gemm), avg_us=t_gemm / n_gemm * 1e3, flops_per_launch=f_gemm / n_gemm,
+                        gpu_ms_per_image=t_gemm / (n_groups * BI))
+            if gt:
+                grec['traffic_over_algorithmic'] = gt[1]
+                grec['traffic_scope'] = ('HBM bytes per GEMM launch of one 32-image encoder chunk + its K / V^T projection (profiles/pmc_gemm.json); '
+                                         'the decoder-phase GEMMs of this class are not in that pass')
+            recs.append((t_gemm, grec))
         if n_mlp:
             tf = f_mlp / (t_mlp / 1e3) / 1e12
             recs.append((t_mlp, dict(bound='mfma', kernel='mlp_fused_kernel (Swin stages 0/1: LayerNorm + fc1 + GELU + fc2 + residual)',
@@ -697,7 +716,7 @@ def main():
         recs.sort(key=lambda r: -r[0])
         note = ('hipEvent-bracketed eager launches of %d engine calls of %d images on one stream (graph replay cannot be bracketed); '
                 'ordered by GPU time; traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch from the committed '
-                'PMC passes (profiles/pmc_cross_attn.json), null for classes / sizes without a pass' % (n_groups, BI))
+                'PMC passes (profiles/pmc_cross_attn.json, profiles/pmc_gemm.json), null for classes / sizes without a pass' % (n_groups, BI))
         if recs:
             roof = dict(recs[0][1], note=note)
             roof_other = [r for _, r in recs[1:]]

@@ -303,3 +303,17 @@ def test_omp_ctx_is_per_thread_and_default_is_protected():
     assert ops.current_context_handle() == default
     assert h.omp_ctx_destroy(ctypes.c_void_p(default)) != 0        # refused
     ctx.destroy()
+
+
+def test_cu_mask_words_are_balanced_over_xcds():
+    """ops.cu_mask_words: n CUs on EVERY XCD under the mask numbering measured on the MI355X (bit i -> XCD i % 8, profiles/
+    r02u_cu_mask_probe.txt) and under an XCD-major numbering; a mask and its complement partition the 256 CUs."""
+    from advancedliteratemachinery_amd import ops
+    for n in (8, 16, 24):
+        w, c = ops.cu_mask_words(n), ops.cu_mask_words(n, complement=True)
+        bits = [i for i in range(256) if (w[i // 32] >> (i % 32)) & 1]
+        cbits = [i for i in range(256) if (c[i // 32] >> (i % 32)) & 1]
+        assert len(bits) == 8 * n and sorted(bits + cbits) == list(range(256))
+        for xcd in range(8):
+            assert sum(1 for i in bits if i % 8 == xcd) == n            # interleaved numbering (measured)
+            assert sum(1 for i in bits if i // 32 == xcd) == n          # XCD-major numbering

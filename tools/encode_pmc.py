@@ -1,0 +1,62 @@
+"""One encoder pass (Swin-B + FPN + input_proj on 32 images of 1024x1024, the chunk bench.py's engine calls encode) plus the
+K / V^T projection of those 32 images, launched eagerly for the rocprofv3 --pmc passes that measure the HBM traffic of the
+large GEMMs (FETCH_SIZE, WRITE_SIZE; separate passes).  Prints the ALGORITHMIC bytes of every GEMM / fused-MLP launch it
+made -- (M K + N K + M N (+ M N residual / second destination)) x 2 bytes, x in + y out + packed weights for the fused
+MLP -- so that tools/pmc_gemm_json.py can put measured next to algorithmic traffic.
+    python tools/encode_pmc.py [images] > gpurun_out/.../encode_alg.json"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from advancedliteratemachinery_amd import ops  # noqa: E402
+from advancedliteratemachinery_amd.model import OmniParser  # noqa: E402
+from advancedliteratemachinery_amd.utils import synthetic as weights  # noqa: E402
+from advancedliteratemachinery_amd.utils.parser import make_args  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True)
+    model = OmniParser(args, engine_dtype='bf16')
+    model.load_state_dict(weights.make_state_dict(args, seed=0))
+    model = model.to('cuda:0')
+    enc, dec = model.engine()
+    img = torch.randn(B, 3, 1024, 1024, generator=torch.Generator().manual_seed(3)).to('cuda:0')
+    mask = torch.zeros(B, 1024, 1024, dtype=torch.bool, device='cuda:0')
+    log = dict(gemm_launches=0, gemm_alg_bytes=0.0, gemm_flops=0.0, mlp_launches=0, mlp_alg_bytes=0.0)
+    real_gemm, real_mlp = ops.gemm, ops.swin_mlp_fused
+
+    def gemm(A, W, bias=None, residual=None, **kw):
+        K = kw.get('K') or A.shape[-1]
+        N = kw.get('N') or W.shape[0]
+        M = kw.get('M') or A.numel() // A.shape[-1]
+        n_out = 1 + (1 if residual is not None else 0) + (1 if kw.get('out_noresidual') is not None else 0)
+        log['gemm_launches'] += 1
+        log['gemm_alg_bytes'] += (M * K + N * K + n_out * M * N) * 2.0
+        log['gemm_flops'] += 2.0 * M * N * K
+        return real_gemm(A, W, bias, residual=residual, **kw)
+
+    def mlp(x, g, b, wpack, b2, out=None, eps=1e-5):
+        log['mlp_launches'] += 1
+        log['mlp_alg_bytes'] += 2.0 * x.numel() * 2 + wpack.numel()
+        return real_mlp(x, g, b, wpack, b2, out=out, eps=eps)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        e = enc.encode(img, mask)            # warm-up (allocations, attribute calls) outside the counted pass is not
+        torch.cuda.synchronize()             # separable under rocprofv3: two identical passes, the summary halves them
+        ops.gemm, ops.swin_mlp_fused = gemm, mlp   # model/backbone.py and model/transformer.py call through this module object
+        e = enc.encode(img, mask)
+        dec.project_memory(e['memory'], e['mem_pos'], B, e['M'], None)
+        torch.cuda.synchronize()
+        ops.gemm, ops.swin_mlp_fused = real_gemm, real_mlp
+    log['images'] = B
+    log['note'] = 'second of two identical encoder passes + one K / V^T projection; the first pass has no projection'
+    print(json.dumps(log))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,47 @@
+"""FETCH_SIZE / WRITE_SIZE summaries (tools/pmc_summary.py) of `python tools/encode_pmc.py` + its algorithmic byte count ->
+profiles/pmc_gemm.json: measured HBM traffic of the large GEMMs (gemm_256 + gemm_dma<128,128,2>) and of the fused MLP per
+encoder chunk, next to the algorithmic bytes.   python tools/pmc_gemm_json.py <fetch.txt> <write.txt> <encode_alg.json>
+FETCH_SIZE is in KiB and counts 16-byte-per-lane streaming reads (global_load and global_load_lds alike) at half their
+bytes on gfx950 (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE in KiB.  encode_pmc.py runs the encoder twice (warm-up + counted)
+and the projection once: per-kernel totals are attributed as (encoder kernels / 2) + projection."""
+import json
+import sys
+
+
+def totals(path, pred):
+    n, tot = 0, 0.0
+    for line in open(path):
+        if line.startswith('#') or line.startswith('kernel'):
+            continue
+        f = line.split()
+        if len(f) < 5 or not pred(line):
+            continue
+        n += int(f[-4])
+        tot += float(f[-1])
+    return n, tot
+
+
+def main():
+    fetch, write, alg = sys.argv[1], sys.argv[2], json.load(open(sys.argv[3]))
+    out = {}
+    for name, pred in (('gemm', lambda l: 'gemm_256' in l or ('gemm_dma' in l and 'Li128ELi128E' in l) or 'gemm_dma<' in l and '128, 128' in l),
+                       ('gemm_slab_epilogues', lambda l: 'gemm_256' in l and ('Li2EEE' in l or 'Li3EEE' in l)),
+                       ('mlp_fused', lambda l: 'mlp_fused_kernel' in l)):
+        nf, tf = totals(fetch, pred)
+        nw, tw = totals(write, pred)
+        out[name] = dict(launches_in_trace=nf, fetch_kib_total=tf, write_kib_total=tw)
+    g, s, m = out['gemm'], out['gemm_slab_epilogues'], out['mlp_fused']
+    # encoder GEMMs ran twice, the two projection GEMMs once
+    enc_fetch = (g['fetch_kib_total'] - s['fetch_kib_total']) / 2 + s['fetch_kib_total']
+    enc_write = (g['write_kib_total'] - s['write_kib_total']) / 2 + s['write_kib_total']
+    meas = enc_fetch * 1024 * 2 + enc_write * 1024
+    out['summary'] = dict(images=alg['images'], gemm_launches=alg['gemm_launches'], gemm_alg_bytes=alg['gemm_alg_bytes'], gemm_measured_bytes=meas,
+                          gemm_measured_over_alg=meas / alg['gemm_alg_bytes'], gemm_measured_bytes_per_launch=meas / alg['gemm_launches'],
+                          mlp_launches=alg['mlp_launches'], mlp_alg_bytes=alg['mlp_alg_bytes'],
+                          mlp_measured_bytes=(m['fetch_kib_total'] * 2 + m['write_kib_total']) * 1024 / 2,
+                          note='one encoder chunk of %d images + its K / V^T projection; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE' % alg['images'])
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
