@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16 = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
@@ -108,6 +108,7 @@ _SIGS = {
     'omp_debug_where': (c_int, [c_void_p, c_int, c_void_p]),
     'omp_prof_enable': (c_int, [c_int]),
     'omp_prof_read': (c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
+    'omp_prof_read_roofline': (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     'omp_prof_read_class': (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64), ctypes.POINTER(ctypes.c_double)]),
 }
 EXPORTS = sorted(list(_SIGS) + ['omp_last_error'])

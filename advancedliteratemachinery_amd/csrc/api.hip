@@ -12,7 +12,9 @@
 struct OmpProfClass {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t used = 0;
-  double work = 0.0;   // flops (GEMM / MLP) or algorithmic bytes (cross-attention) of the bracketed launches
+  double work = 0.0;   // flops (GEMM / MLP) of the bracketed launches
+  double bytes = 0.0;  // their algorithmic HBM bytes
+  double roof_s = 0.0; // sum over launches of max(flops / 2.5 PF, bytes / 8 TB/s): the time the launches take on their own rooflines
 };
 
 namespace {
@@ -64,7 +66,7 @@ extern "C" omp_ctx* omp_ctx_current(void) { return &omp_cur(); }
 
 bool omp_prof_active(int cls) { return (omp_cur().prof_mask >> cls) & 1; }
 
-int omp_prof_begin(int cls, hipStream_t st, double work) {
+int omp_prof_begin(int cls, hipStream_t st, double work, double bytes) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   OmpProfClass& c = omp_cur().prof[cls];
   if (c.used == c.ev.size()) {
@@ -73,6 +75,8 @@ int omp_prof_begin(int cls, hipStream_t st, double work) {
     c.ev.emplace_back(a, b);
   }
   c.work += work;
+  c.bytes += bytes;
+  { const double tm = work / 2.5e15, tb = bytes / 8.0e12; c.roof_s += tm > tb ? tm : tb; }
   (void)hipEventRecord(c.ev[c.used].first, st);
   return (int)c.used++;
 }
@@ -87,7 +91,7 @@ extern "C" int omp_prof_enable(int mask) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   omp_ctx& x = omp_cur();
   x.prof_mask = mask & ((1 << OMP_PROF_NCLASS) - 1);
-  for (int c = 0; c < OMP_PROF_NCLASS; ++c) { x.prof[c].used = 0; x.prof[c].work = 0.0; }
+  for (int c = 0; c < OMP_PROF_NCLASS; ++c) { x.prof[c].used = 0; x.prof[c].work = 0.0; x.prof[c].bytes = 0.0; x.prof[c].roof_s = 0.0; }
   return OMP_OK;
 }
 
@@ -107,6 +111,15 @@ extern "C" int omp_prof_read_class(int cls, double* total_ms, int64_t* count, do
   if (total_ms) *total_ms = tot;
   if (count) *count = (int64_t)c.used;
   if (work) *work = c.work;
+  return OMP_OK;
+}
+
+extern "C" int omp_prof_read_roofline(int cls, double* bytes, double* roofline_seconds) {
+  OMP_CHECK_ARG(cls >= 0 && cls < OMP_PROF_NCLASS, "omp_prof_read_roofline: bad class %d", cls);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  const OmpProfClass& c = omp_cur().prof[cls];
+  if (bytes) *bytes = c.bytes;
+  if (roofline_seconds) *roofline_seconds = c.roof_s;
   return OMP_OK;
 }
 

@@ -79,7 +79,7 @@ struct omp_ctx {
 omp_ctx& omp_cur();   // the calling thread's current context
 
 bool omp_prof_active(int cls);
-int omp_prof_begin(int cls, hipStream_t st, double work);   // -> slot
+int omp_prof_begin(int cls, hipStream_t st, double work, double bytes = 0.0);   // -> slot; bytes = algorithmic HBM bytes of the launch
 void omp_prof_end(int cls, int slot, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------

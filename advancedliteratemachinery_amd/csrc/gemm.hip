@@ -665,6 +665,12 @@ int launch_small(const GemmP& p, hipStream_t st) {
   return ln ? launch_small_t<T, TOut, 4, true>(p, st) : launch_small_t<T, TOut, 4, false>(p, st);
 }
 
+// minimum HBM traffic of one product: A and W once, every destination once, the residual once
+inline double gemm_alg_bytes(const GemmP& p, size_t esz, size_t osz) {
+  return ((double)p.M * p.K + (double)p.N * p.K) * (double)esz +
+         (double)p.M * p.N * (double)osz * (1.0 + (p.residual != nullptr ? 1.0 : 0.0) + (p.C2 != nullptr ? 1.0 : 0.0));
+}
+
 template <typename T, typename TOut>
 int launch_gemm(const GemmP& p0, hipStream_t st) {
   GemmP p = p0;
@@ -695,7 +701,7 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
   }
   if (which == 5) {
     // bench.py's matrix-core roofline leg: hipEvent bracket + flop count of the large-M GEMMs
-    const int slot = omp_prof_active(OMP_PROF_GEMM) ? omp_prof_begin(OMP_PROF_GEMM, st, 2.0 * (double)p.M * p.N * p.K) : -1;
+    const int slot = omp_prof_active(OMP_PROF_GEMM) ? omp_prof_begin(OMP_PROF_GEMM, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
     int rc = launch_dma<T, TOut, 128, 128, 2>(p, st);
     if (slot >= 0) omp_prof_end(OMP_PROF_GEMM, slot, st);
     if (rc != OMP_OK) return rc;
@@ -712,7 +718,7 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
         omp_set_error("omp_gemm_bias_act: selector 9 (256x256 tiles) needs bf16 in/out, plain store, K %% 64 == 0, K >= 128, N %% 8 == 0");
         return OMP_ERR_UNSUPPORTED;
       }
-      const int slot = omp_prof_active(OMP_PROF_GEMM) ? omp_prof_begin(OMP_PROF_GEMM, st, 2.0 * (double)p.M * p.N * p.K) : -1;
+      const int slot = omp_prof_active(OMP_PROF_GEMM) ? omp_prof_begin(OMP_PROF_GEMM, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
       int rc = launch_256<TOut>(p, st);
       if (slot >= 0) omp_prof_end(OMP_PROF_GEMM, slot, st);
       if (rc != OMP_OK) return rc;

@@ -295,7 +295,7 @@ extern "C" int omp_swin_mlp_fused(const void* x, int64_t ldx, const float* ln_ga
   p.M = M; p.nsub = hidden / 32; p.trace = omp_cur().mlp_trace;
   hipStream_t st = (hipStream_t)s;
   const int v = omp_cur().mlp_variant;
-  const int slot = omp_prof_active(OMP_PROF_MLP) ? omp_prof_begin(OMP_PROF_MLP, st, 4.0 * (double)M * C * hidden) : -1;
+  const int slot = omp_prof_active(OMP_PROF_MLP) ? omp_prof_begin(OMP_PROF_MLP, st, 4.0 * (double)M * C * hidden, 4.0 * (double)M * C + (double)(hidden / 32) * (C * 128 + 1024)) : -1;
   const int rc = dispatch_mlp(p, C, v, st);
   if (slot >= 0) omp_prof_end(OMP_PROF_MLP, slot, st);
   return rc;

@@ -675,9 +675,14 @@ def main():
             tot, cnt, work = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
             h.omp_prof_read_class(cls, ctypes.byref(tot), ctypes.byref(cnt), ctypes.byref(work))
             return tot.value, cnt.value, work.value
+        def read_roof(cls):
+            by, rs = ctypes.c_double(0), ctypes.c_double(0)
+            h.omp_prof_read_roofline(cls, ctypes.byref(by), ctypes.byref(rs))
+            return by.value, rs.value
         t_cross, n_cross, _ = read(0)
         t_gemm, n_gemm, f_gemm = read(1)
         t_mlp, n_mlp, f_mlp = read(2)
+        (b_gemm, r_gemm), (b_mlp, r_mlp) = read_roof(1), read_roof(2)
         h.omp_prof_enable(0)
         model.use_graph = was
         M = (a.size // 16) ** 2
@@ -691,6 +696,10 @@ def main():
                         achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=gt[0] if gt else None,
                         launches=int(n_gemm), avg_us=t_gemm / n_gemm * 1e3, flops_per_launch=f_gemm / n_gemm,
                         gpu_ms_per_image=t_gemm / (n_groups * BI))
+            # the class mixes matrix-core-bound (stage 2 / 3) and HBM-bound products (K = 128 / 256, fp32 decoder outputs): the time
+            # its launches would take on their OWN rooflines, max(flops / 2.5 PF, algorithmic bytes / 8 TB/s) each, over the measured time
+            grec['alg_bytes_per_launch'] = b_gemm / n_gemm
+            grec['frac_of_launch_rooflines'] = r_gemm / (t_gemm / 1e3)
             if gt:
                 grec['traffic_over_algorithmic'] = gt[1]
                 grec['traffic_scope'] = ('HBM bytes per GEMM launch of one 32-image encoder chunk + its K / V^T projection (profiles/pmc_gemm.json); '
@@ -701,6 +710,7 @@ def main():
             recs.append((t_mlp, dict(bound='mfma', kernel='mlp_fused_kernel (Swin stages 0/1: LayerNorm + fc1 + GELU + fc2 + residual)',
                                      achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None,
                                      launches=int(n_mlp), avg_us=t_mlp / n_mlp * 1e3, flops_per_launch=f_mlp / n_mlp,
+                                     alg_bytes_per_launch=b_mlp / n_mlp, frac_of_launch_rooflines=r_mlp / (t_mlp / 1e3),
                                      gpu_ms_per_image=t_mlp / (n_groups * BI))))
         if n_cross:
             # algorithmic bytes per launch: K + V^T of the images in the call (d = 512) + q in / o out of the

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 11
+#define OMP_ABI_VERSION 12
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -349,6 +349,9 @@ int omp_resize_normalize_pad(const uint8_t* src, int64_t src_pitch, int in_h, in
 int omp_prof_enable(int mask);
 int omp_prof_read(double* total_ms, int64_t* count);
 int omp_prof_read_class(int cls, double* total_ms, int64_t* count, double* work);
+/* classes 1 and 2: summed algorithmic HBM bytes of the bracketed launches and the sum over launches of
+ * max(flops / 2.5 PFLOP/s, bytes / 8 TB/s) -- the time they would take on their own rooflines */
+int omp_prof_read_roofline(int cls, double* bytes, double* roofline_seconds);
 int omp_debug_force_gemm_kernel(int which);
 /* development: device buffer uint64 [n_workgroups][8] that omp_debug_force_gemm_kernel(15) fills with s_memtime stamps
  * per workgroup: 0 start, 1 first K tile landed, 2 K loop done, 3 accumulators in LDS, 4 stores retired, 5 XCC id */
