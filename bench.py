@@ -13,9 +13,10 @@ reference's state-dict layout.  Random weights never emit a sensible EOS, so dec
 25+2 recognition steps, every step a full 4-layer decoder pass for every row.  Nothing is skipped
 or cached across steps; images are resident in HBM before the timed region.
 
-Engine scheduling (all inside the timed region): `--coalesce` consecutive steps are merged into one engine
-call (dynamic batching: the latency-bound decoder steps then advance coalesce*batch images per launch)
-and `--lanes` such groups are in flight at once on separate HIP streams (engine/pipeline.py).
+Engine scheduling (all inside the timed region): `--coalesce` consecutive steps (default 64) are merged into one engine
+call (dynamic batching: the decoder steps then advance coalesce*batch images per launch, the encoder runs them 32 at a
+time) and `--lanes` such groups are in flight at once on separate HIP streams (engine/pipeline.py; default 1: with every
+phase throughput-bound, one call of 512 images beats two of 256 in flight at the same latency, profiles/r02ze).
 
 Scaling is weak: every rank processes its own `--batch` images per step; ranks exchange one all-gather
 of the decoded (padded) sequences per engine call, as a real image-sharded deployment would.
@@ -73,9 +74,9 @@ def parse():
     p.add_argument('--phase-times', action='store_true', help='also print a per-phase time breakdown (stderr)')
     p.add_argument('--overlap', type=int, default=1, help='polygon || recognition decoders on two streams')
     p.add_argument('--q4-mode', type=int, default=1, help='A/B: omp_debug_cross_q4 selector (1 default, 2 = one 32-key block per step, 4 = chunks with temporal loads)')
-    p.add_argument('--lanes', type=int, default=int(os.environ.get('OMP355_LANES', '2')),
+    p.add_argument('--lanes', type=int, default=int(os.environ.get('OMP355_LANES', '1')),
                    help='step groups in flight per GPU (engine/pipeline.py): they overlap on separate HIP streams')
-    p.add_argument('--coalesce', type=int, default=int(os.environ.get('OMP355_COALESCE', '32')),
+    p.add_argument('--coalesce', type=int, default=int(os.environ.get('OMP355_COALESCE', '64')),
                    help='consecutive steps (batches of --batch images) merged into one engine call: the decoders then '
                         'advance coalesce*batch images per launch (dynamic batching across steps); 1 = every step alone; '
                         'capped at ceil(steps / lanes) so that every lane gets work')
@@ -478,6 +479,7 @@ def main():
     from advancedliteratemachinery_amd.engine.pipeline import LanePool
     lanes = max(1, a.lanes)
     pool = LanePool(device, lanes) if lanes > 1 else None
+    pools = {'active': pool, 'b8': None}   # the batch-8 leg pipelines its small engine calls over two lanes of its own
 
     # steps per engine call: `coalesce`, but never so many that a lane would stay idle in a short run
     G = max(1, min(a.coalesce, -(-a.steps // lanes)))
@@ -525,12 +527,13 @@ def main():
         sizes = [group] * (k // group) + ([k % group] if k % group else [])
         firsts = [sum(sizes[:i]) for i in range(len(sizes))]
         out = None
-        if pool is None:
+        pl = pools['active']
+        if pl is None:
             for f0, g_ in zip(firsts, sizes):
                 ids, probs = run_group(f0, g_, forced=forced)
                 out = exchange(ids, probs, g_)
             return out
-        futs = [pool.submit(lambda lane, f0=f0, g_=g_: run_group(f0, g_, lane, forced)) for f0, g_ in zip(firsts, sizes)]
+        futs = [pl.submit(lambda lane, f0=f0, g_=g_: run_group(f0, g_, lane, forced)) for f0, g_ in zip(firsts, sizes)]
         for f, g_ in zip(futs, sizes):
             (ids, probs), ev = f.result()
             torch.cuda.current_stream().wait_event(ev)
@@ -598,8 +601,12 @@ def main():
 
     def batch8_leg():
         # BASELINE config 2 literally: every batch of 8 images its own engine call (no cross-step coalescing)
+        lanes8 = max(lanes, 2)
+        if pools['active'] is None:
+            pools['b8'] = LanePool(device, lanes8)
+            pools['active'] = pools['b8']
         with torch.cuda.stream(stream):
-            for _ in range(lanes):
+            for _ in range(lanes8):
                 run_steps(2, group=1)
             k8 = min(a.steps, 32)
             r8 = []
@@ -608,9 +615,10 @@ def main():
             while (sum(r8) < min(a.min_seconds, 6.0) or len(r8) < 4) and len(r8) < 12:
                 r8.append(timed(k8, group=1)[0])
         e8 = pct(r8, 0.5)
+        pools['active'] = pool
         return dict(images_per_sec=B * k8 / e8, ms_per_step=e8 / k8 * 1e3, steps=k8, repeats=len(r8),
                     ms_per_step_p10=pct(r8, 0.1) / k8 * 1e3, ms_per_step_p90=pct(r8, 0.9) / k8 * 1e3,
-                    note='coalesce 1: one engine call per 8-image batch, %d lanes' % lanes)
+                    note='coalesce 1: one engine call per 8-image batch, %d lanes' % lanes8)
     def eos_leg():
         # EOS honoured (no forced instance count) on the sharpened synthetic checkpoint; the point sequence is
         # capped at --eos-pt-len tokens so that an image yields at most 64 instances, as in the forced workload
@@ -752,8 +760,9 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             rec['cpu_baseline'] = cpu_baseline(args, sd, a.size, N, 2 * N + 1)
         print(json.dumps(rec), flush=True)
-    if pool is not None:
-        pool.close()
+    for pl in (pool, pools['b8']):
+        if pl is not None:
+            pl.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
