@@ -1,0 +1,51 @@
+"""bench.py's host-side helpers (no GPU): percentile, the committed PMC records it reads for `roofline.traffic`, argument
+defaults the docs quote."""
+import importlib.util
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_percentile_interpolates():
+    b = _bench()
+    assert b.pct([3.0, 1.0, 2.0], 0.5) == 2.0
+    assert abs(b.pct([1.0, 2.0], 0.9) - 1.9) < 1e-12
+    assert b.pct([], 0.5) is None
+
+
+def test_committed_pmc_records_feed_the_roofline_traffic():
+    """profiles/pmc_cross_attn.json (keyed by images per launch) and profiles/pmc_gemm.json: measured HBM bytes within a few
+    per cent of (cross-attention) / a small factor above (GEMM class, re-reads through L2) the algorithmic bytes"""
+    b = _bench()
+    for images in (256, 512):
+        t = b.pmc_traffic(images)
+        alg = images * 2 * 4096 * 512 * 2
+        assert t is not None and 1.0 <= t / alg < 1.03, (images, t, alg)
+    assert b.pmc_traffic(77) is None          # no pass at that size -> null in the bench line, never a guess
+    g = b.pmc_gemm_traffic(1024, 'bf16')
+    assert g is not None and g[0] > 1e8 and 1.0 <= g[1] < 1.5
+    assert b.pmc_gemm_traffic(640, 'bf16') is None and b.pmc_gemm_traffic(1024, 'fp32') is None
+    rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_gemm.json')))['summary']
+    assert abs(rec['gemm_measured_bytes'] / rec['gemm_alg_bytes'] - rec['gemm_measured_over_alg']) < 1e-9
+
+
+def test_defaults_are_the_documented_ones(monkeypatch):
+    b = _bench()
+    monkeypatch.setattr(sys, 'argv', ['bench.py'])
+    for k in ('OMP355_LANES', 'OMP355_COALESCE', 'OMP355_GRAPH'):
+        monkeypatch.delenv(k, raising=False)
+    b = _bench()
+    a = b.parse()
+    assert (a.gpus, a.steps, a.warmup, a.lanes, a.coalesce, a.workload, a.dtype) == (1, 192, 32, 1, 64, 'spotting', 'bf16')
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '1', '--steps', '20', '--warmup', '5'])
+    a = b.parse()
+    assert max(1, min(a.coalesce, -(-a.steps // max(1, a.lanes)))) == 20   # one engine call of 160 images per repetition
