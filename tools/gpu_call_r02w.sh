@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: selector 10 (persistent 256x256 GEMM) measured here was removed afterwards; kept as the record of the commands
 # r02w: chunked q4 cross-attention + persistent 256x256 GEMM (parity + A/B), side workloads of bench.py
 OUT=gpurun_out/r02w; mkdir -p $OUT; export TMPDIR=/tmp
 timeout 700 python -m pytest tests/test_gpu_ops.py tests/test_gpu_e2e.py -m gpu -q -x -k "gemm or cross or decoder or spot_odd or kie_sroie or batch_equals" > $OUT/tests_sel.log 2>&1; echo "tests_sel rc=$?" >> $OUT/rc.log; tail -3 $OUT/tests_sel.log

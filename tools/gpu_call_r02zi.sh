@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the --split-points flag these runs used was removed with the (not kept) split point decoder; kept as the record of the commands
 # r02zi: point decoder as two halves on two streams -- end-to-end parity tests, then A/B at the driver's step count and at the default
 OUT=gpurun_out/r02zi; mkdir -p $OUT; export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_e2e.py -m gpu -q -x > $OUT/tests_e2e.log 2>&1; echo "tests_e2e rc=$?" >> $OUT/rc.log; tail -3 $OUT/tests_e2e.log

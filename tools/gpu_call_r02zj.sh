@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the --split-points flag these runs used was removed with the (not kept) split point decoder; kept as the record of the commands
 # r02zj: split point decoder only for small calls (<= 16 images): small-call legs A/B, small e2e tests
 OUT=gpurun_out/r02zj; mkdir -p $OUT; export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_e2e.py -m gpu -q -x -k "spot_odd or kie_sroie or batch_equals or graph or lanes" > $OUT/tests_sel.log 2>&1; echo "tests_sel rc=$?" >> $OUT/rc.log; tail -2 $OUT/tests_sel.log
