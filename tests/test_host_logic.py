@@ -317,3 +317,45 @@ def test_cu_mask_words_are_balanced_over_xcds():
         for xcd in range(8):
             assert sum(1 for i in bits if i % 8 == xcd) == n            # interleaved numbering (measured)
             assert sum(1 for i in bits if i // 32 == xcd) == n          # XCD-major numbering
+
+
+def test_make_tiles_partitions_rows_by_image():
+    """Decoder.make_tiles: every row belongs to exactly one group, groups never straddle images, a group holds at most
+    16 * q_tiles rows, q_tiles follows the largest per-image count (1 / 2 / 4 query tiles)."""
+    import random
+    from advancedliteratemachinery_amd.model.transformer import Decoder
+    rng = random.Random(0)
+    for _ in range(200):
+        counts = [rng.choice([0, 1, 1, 3, 16, 17, 32, 33, 64]) for _ in range(rng.randint(1, 9))]
+        if not any(counts):
+            counts[0] = 1
+        groups, qt = Decoder.make_tiles(counts)
+        mx = max(counts)
+        assert qt == (1 if mx <= 16 else (2 if mx <= 32 else 4))
+        starts = [sum(counts[:i]) for i in range(len(counts))]
+        covered = []
+        for (r0, n, img) in groups:
+            assert 1 <= n <= 16 * qt
+            assert starts[img] <= r0 and r0 + n <= starts[img] + counts[img]      # inside ONE image's rows
+            covered += list(range(r0, r0 + n))
+        assert covered == list(range(sum(counts)))                                 # each row once, in order
+
+
+def test_n_split_is_a_power_of_two_that_fills_the_chip_without_oversplitting():
+    """Decoder._n_split: power of two <= 16; never more than ~4 workgroups per CU worth of (group, head, split) triples once
+    a split exists; the LDS-ring kernel (64 rows per image) splits only while that still leaves >= 8 key blocks per split."""
+    import types
+    from advancedliteratemachinery_amd.model.transformer import Decoder
+    d = types.SimpleNamespace(dtype=torch.bfloat16, nH=8, n_split_override=0)
+    for n_img in (1, 2, 8, 40, 80, 128, 160, 256, 512):
+        for M in (400, 1024, 4096, 4800):
+            tiles1 = ([(r, 1, r) for r in range(n_img)], 1)
+            s1 = Decoder._n_split(d, tiles1, M)
+            assert s1 in (1, 2, 4, 8, 16)
+            assert s1 == 1 or n_img * 8 * s1 <= 1024
+            tiles4 = ([(r * 64, 64, r) for r in range(n_img)], 4)
+            s4 = Decoder._n_split(d, tiles4, M)
+            assert s4 in (1, 2, 4, 8, 16)
+            assert s4 == 1 or M >= 8 * 32 * (s4 // 2)
+            if n_img * 8 >= 512:
+                assert s4 == 1
