@@ -9,8 +9,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
-OMP_F32, OMP_BF16 = 0, 1
-ABI_VERSION = 12
+OMP_F32, OMP_BF16, OMP_BF16X2 = 0, 1, 2   # BF16X2: split-bf16 pair rows [hi | lo] (include/omp355.h)
+ABI_VERSION = 13
 STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
@@ -30,7 +30,7 @@ class GemmArgs(ctypes.Structure):
                 ('trans_rows', c_int64), ('trans_ld', c_int64), ('ln_gamma', c_void_p), ('ln_beta', c_void_p),
                 ('ln_eps', c_float), ('small_m_splitk', c_int32), ('store_mode', c_int32), ('bias_along_m', c_int32),
                 ('kv_images', c_int32), ('kv_tokens', c_int32), ('kv_mpad', c_int32), ('kv_heads', c_int32),
-                ('kv_key_block', c_int32), ('C2', c_void_p), ('ldc2', c_int64)]
+                ('kv_key_block', c_int32), ('C2', c_void_p), ('ldc2', c_int64), ('a_wrap', c_int32)]
 
 
 class SampleCfg(ctypes.Structure):
@@ -71,9 +71,11 @@ _SIGS = {
     'omp_debug_swin_mlp_trace': (c_int, [c_void_p]),
     'omp_patch_embed_ln': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p]),
     'omp_swin_window_attn': (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
-    'omp_swin_window_attn2': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    'omp_swin_window_attn2': (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     'omp_swin_expand_bias': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     'omp_patch_merge_gather_ln': (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_void_p]),
+    'omp_patch_merge_gather_ln2': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_float, c_void_p]),
+    'omp_split_bf16': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     'omp_fpn_fuse': (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p]),
     'omp_mask_nearest': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_sine_posembed': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),

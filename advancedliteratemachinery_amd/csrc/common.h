@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "../../include/omp355.h"
+#include "omp355_debug.h"
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -35,15 +35,17 @@ struct GemmP {
   int store_mode; int bias_m;                           // OMP_STORE_*; bias indexed by m instead of n
   int kv_B, kv_tok, kv_mpad, kv_nH, kv_kb;              // blocked K / V^T destination geometry
   void* C2; int64_t ldc2;                               // optional second destination without the residual
+  int a_wrap;                                           // > 0: A rows are split-bf16 pairs [hi | lo] of a_wrap elements, K columns beyond wrap back (bf16x3)
+  int split_out;                                        // bf16 destination written as split pairs: hi at column n, lo at column N + n
   unsigned long long* trace;                            // debug: per-workgroup phase timestamps (gemm_dma<..., TRACE>)
 };
 
 // bf16 destinations take the bf16 engine's GELU everywhere (vectorised or not: a value must not depend on which
 // kernel or epilogue path produced it), fp32 destinations the < 1 ulp erf form
 template <typename TOut>
-__device__ __forceinline__ float apply_act(float v, int act) {
+__device__ __forceinline__ float apply_act(float v, int act, bool precise = false) {
   if (act == OMP_ACT_GELU) {
-    if constexpr (std::is_same<TOut, bf16_t>::value) return gelu_fast2(f32x2{v, 0.0f})[0];
+    if constexpr (std::is_same<TOut, bf16_t>::value) return precise ? gelu_erf(v) : gelu_fast2(f32x2{v, 0.0f})[0];
     else return gelu_erf(v);
   }
   if (act == OMP_ACT_RELU) return fmaxf(v, 0.0f);
@@ -109,6 +111,18 @@ __device__ __forceinline__ void store4(const GemmP& p, int64_t m, int n, const f
       if (n + r < p.N) base[(int64_t)(n + r) * p.trans_ld] = from_f32<TOut>(v[r]);
     return;
   }
+  if constexpr (sizeof(TOut) == 2) {
+    if (p.split_out) {   // split-bf16 pair rows (no residual: checked on the host)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p.N) {
+          const bf16_t hi = (bf16_t)v[r];
+          C[m * p.ldc + n + r] = hi;
+          C[m * p.ldc + p.N + n + r] = (bf16_t)(v[r] - (float)hi);
+        }
+      return;
+    }
+  }
   const bool full = (n + 3 < p.N) && ((p.ldc & 3) == 0) && (res == nullptr || (p.ldr & 3) == 0);
   if (full) {
     if (res != nullptr) {
@@ -151,7 +165,7 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, const float* bias
   for (int r = 0; r < 4; ++r) {
     float b = 0.0f;
     if (bias != nullptr) b = p.bias_m ? bias[m] : (n + r < p.N ? bias[n + r] : 0.0f);
-    v[r] = apply_act<TOut>(acc[r] + b, p.act);
+    v[r] = apply_act<TOut>(acc[r] + b, p.act, p.split_out != 0);
   }
   store4<TOut>(p, m, n, v);
 }
@@ -238,11 +252,13 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
   }
   auto issue = [&](int kt, int buf) {
     const int koff = kt * KT;
+    int kaoff = koff;
+    if (p.a_wrap > 0 && kaoff >= p.a_wrap) kaoff -= p.a_wrap;   // bf16x3: [hi | lo] rows read as [hi | lo | hi]
     char* abase = smem + buf * STAGE + (wave * (BM / 4)) * ROWB;
     char* wbase = smem + buf * STAGE + BM * ROWB + (wave * (BN / 4)) * ROWB;
 #pragma unroll
     for (int j = 0; j < AI; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + koff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[j] + kaoff),
                                        (__attribute__((address_space(3))) void*)(abase + j * 8 * ROWB), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < WI; ++j)
@@ -384,7 +400,24 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
             if constexpr (decltype(ACT)::value == OMP_ACT_GELU && !std::is_same<TOut, bf16_t>::value) v[q] = gelu_erf(v[q]);
             if constexpr (decltype(ACT)::value == OMP_ACT_RELU) v[q] = fmaxf(v[q], 0.0f);
           }
-          if constexpr (decltype(ACT)::value == OMP_ACT_GELU && std::is_same<TOut, bf16_t>::value) gelu_fast_n<CH>(v);
+          if constexpr (decltype(ACT)::value == OMP_ACT_GELU && std::is_same<TOut, bf16_t>::value) {
+            if (p.split_out) {   // fp32-grade destination: the < 1 ulp erf form
+#pragma unroll
+              for (int q = 0; q < CH; ++q) v[q] = gelu_erf(v[q]);
+            } else {
+              gelu_fast_n<CH>(v);
+            }
+          }
+          if constexpr (std::is_same<TOut, bf16_t>::value) {
+            if (p.split_out) {
+              bf16x8 hi, lo;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { hi[q] = (bf16_t)v[q]; lo[q] = (bf16_t)(v[q] - (float)hi[q]); }
+              *reinterpret_cast<bf16x8*>(C + m * p.ldc + n) = hi;
+              *reinterpret_cast<bf16x8*>(C + m * p.ldc + p.N + n) = lo;
+              continue;
+            }
+          }
           if (res != nullptr) {
             if (p.C2 != nullptr) {   // memory and memory + pos from one product
               typename Vec16<TOut>::type o2;
@@ -425,7 +458,7 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
       if (bias != nullptr && p.bias_m && m0 + r < p.M) bm = bias[m0 + r];
       float v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = apply_act<TOut>(t[u] + bcol[q + u] + bm, p.act);
+      for (int u = 0; u < 4; ++u) v[u] = apply_act<TOut>(t[u] + bcol[q + u] + bm, p.act, p.split_out != 0);
       store4<TOut>(p, m0 + r, n + q, v);
     }
   }
@@ -469,18 +502,22 @@ __global__ __launch_bounds__(256) void gemm_rows(GemmP p) {
   // so a row's result does not depend on which kernel (i.e. which batch size) computed it.
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int nsteps = p.K / MM::KSTEP;
+  auto xk = [&](int st) -> int {   // A-side K offset of step st (bf16x3: [hi | lo] rows read as [hi | lo | hi])
+    const int k = st * MM::KSTEP;
+    return (p.a_wrap > 0 && k >= p.a_wrap) ? k - p.a_wrap : k;
+  };
   int s = 0;
   for (; s + 8 <= nsteps; s += 8) {
     frag fw[8], fx[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       fw[u] = ld16<T>(wp + (s + u) * MM::KSTEP);
-      fx[u] = ld16<T>(xp + (s + u) * MM::KSTEP);
+      fx[u] = ld16<T>(xp + xk(s + u));
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) MM::mma(acc, fw[u], fx[u]);
   }
-  for (; s < nsteps; ++s) MM::mma(acc, ld16<T>(wp + s * MM::KSTEP), ld16<T>(xp + s * MM::KSTEP));
+  for (; s < nsteps; ++s) MM::mma(acc, ld16<T>(wp + s * MM::KSTEP), ld16<T>(xp + xk(s)));
   const float* bias = p.bias;
   if (bias != nullptr && p.bias_row != nullptr) bias += (int64_t)(*p.bias_row) * p.bias_row_stride;
   epilogue_store<TOut>(p, bias, mb + lrow, nb + lg * 4, acc);
@@ -678,6 +715,10 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
   int which = cx.force_gemm;
   const int kq = 4 * Mma<T>::KSTEP;
   if (p.ln_g != nullptr || which == 4 || (which == 0 && p.small_hint && p.M <= 64 && p.K % kq == 0)) {
+    if (p.a_wrap > 0 || p.split_out) {
+      omp_set_error("omp_gemm_bias_act: the split-K small-M kernel takes no split-bf16 operands / destinations");
+      return OMP_ERR_UNSUPPORTED;
+    }
     if (p.M > 64 || p.K % kq != 0 || p.trans_out) {
       omp_set_error("omp_gemm_bias_act: split-K small-M kernel needs M <= 64, K %% %d == 0, no trans_out", kq);
       return OMP_ERR_UNSUPPORTED;
@@ -695,9 +736,13 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
     // 256x256 phase-interleaved tiles once they fill the chip (>= one tile per CU) and the output is wide enough for a
     // 256-column tile to pay (profiles/r02g_kbench_gemm_256.txt: wins on every Swin qkv / fc1 / fc2 / proj shape of
     // stages 1-3 with >= 256 tiles, loses at N = 128 and on half-empty grids)
-    if constexpr (std::is_same<T, bf16_t>::value && std::is_same<TOut, bf16_t>::value) {
-      if (which == 5 && p.N >= 256 && ceil_div64(p.M, 256) * ceil_div64(p.N, 256) >= 256 && gemm256_ok(p, true, true)) which = 9;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (which == 5 && p.N >= 256 && ceil_div64(p.M, 256) * ceil_div64(p.N, 256) >= 256 && gemm256_ok(p, true, std::is_same<TOut, bf16_t>::value)) which = 9;
     }
+  }
+  if (p.C2 != nullptr && which != 5 && which != 6 && which != 9 && which != 15) {
+    omp_set_error("omp_gemm_bias_act: kernel selector %d has no second destination (C2)", which);
+    return OMP_ERR_UNSUPPORTED;
   }
   if (which == 5) {
     // bench.py's matrix-core roofline leg: hipEvent bracket + flop count of the large-M GEMMs
@@ -713,9 +758,9 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
                                                                  : launch_dma<T, TOut, 64, 64, 4>(p, st);
     if (rc != OMP_OK) return rc;
   } else if (which == 9) {           // 256x256 phase-interleaved kernel (gemm256.inc)
-    if constexpr (std::is_same<T, bf16_t>::value && std::is_same<TOut, bf16_t>::value) {
-      if (!gemm256_ok(p, true, true)) {
-        omp_set_error("omp_gemm_bias_act: selector 9 (256x256 tiles) needs bf16 in/out, plain store, K %% 64 == 0, K >= 128, N %% 8 == 0");
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (!gemm256_ok(p, true, std::is_same<TOut, bf16_t>::value)) {
+        omp_set_error("omp_gemm_bias_act: selector 9 (256x256 tiles) needs bf16 operands, K %% 64 == 0, K >= 128, N %% 8 == 0 (blocked K / V^T slabs: bf16 only)");
         return OMP_ERR_UNSUPPORTED;
       }
       const int slot = omp_prof_active(OMP_PROF_GEMM) ? omp_prof_begin(OMP_PROF_GEMM, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
@@ -765,8 +810,15 @@ extern "C" int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s) {
   OMP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "omp_gemm_bias_act: bad shape M=%lld N=%d K=%d",
                 (long long)a->M, a->N, a->K);
   OMP_CHECK_ARG(a->dtype == OMP_F32 || a->dtype == OMP_BF16, "omp_gemm_bias_act: bad dtype %d", a->dtype);
-  OMP_CHECK_ARG(a->out_dtype == a->dtype || a->out_dtype == OMP_F32,
-                "omp_gemm_bias_act: out_dtype must equal dtype or be f32");
+  OMP_CHECK_ARG(a->out_dtype == a->dtype || a->out_dtype == OMP_F32 || (a->out_dtype == OMP_BF16X2 && a->dtype == OMP_BF16),
+                "omp_gemm_bias_act: out_dtype must equal dtype, be f32, or be split-bf16 pairs with bf16 operands");
+  const bool split_out = a->out_dtype == OMP_BF16X2;
+  OMP_CHECK_ARG(!split_out || (a->residual == nullptr && a->C2 == nullptr && a->store_mode == OMP_STORE_PLAIN && !a->trans_out &&
+                               a->ldc >= 2 * (int64_t)a->N),
+                "omp_gemm_bias_act: split-bf16 destinations are plain [M, 2N] rows without residual / second destination");
+  OMP_CHECK_ARG(a->a_wrap >= 0 && (a->a_wrap == 0 || (a->dtype == OMP_BF16 && a->a_wrap % 64 == 0 && a->a_wrap < a->K && a->K <= 2 * a->a_wrap &&
+                                                      a->ln_gamma == nullptr)),
+                "omp_gemm_bias_act: a_wrap needs bf16 operands, a_wrap %% 64 == 0 and a_wrap < K <= 2 * a_wrap");
   const int esz = a->dtype == OMP_F32 ? 4 : 2;
   const int ktile = 128 / esz;
   OMP_CHECK_ARG(a->K % ktile == 0, "omp_gemm_bias_act: K=%d must be a multiple of %d", a->K, ktile);
@@ -786,6 +838,7 @@ extern "C" int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s) {
   p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.small_hint = a->small_m_splitk;
   p.store_mode = a->store_mode; p.bias_m = a->bias_along_m; p.trace = nullptr;
   p.C2 = a->C2; p.ldc2 = a->ldc2;
+  p.a_wrap = a->a_wrap; p.split_out = split_out ? 1 : 0;
   if (p.C2 != nullptr) {
     OMP_CHECK_ARG(a->residual != nullptr && a->store_mode == OMP_STORE_PLAIN && !a->trans_out && a->ln_gamma == nullptr && a->M > 64 &&
                       a->N % (16 / (a->out_dtype == OMP_F32 ? 4 : 2)) == 0 && a->ldc2 % (16 / (a->out_dtype == OMP_F32 ? 4 : 2)) == 0 &&

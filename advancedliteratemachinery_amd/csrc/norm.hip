@@ -32,6 +32,7 @@ __device__ __forceinline__ void store_vals(TO* p, const float* v) {
 struct LnP {
   const void* x; const float* g; const float* b; void* y; float* yf;
   int64_t rows; int C; int lpr_log2; float eps;
+  int split;   // y is bf16 and holds split pairs: row pitch 2C, hi at column c, lo at column C + c (OMP_BF16X2)
   // gather mode (PatchMerging): x is [B,H,W,Cin], row = (b, y2, x2), C = 4*Cin
   int gather; int H, W, Cin, H2, W2;
 };
@@ -112,7 +113,19 @@ __global__ __launch_bounds__(256) void ln_kernel(LnP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[i + j] = (v[it][i + j] - mean) * rstd * gg[j] + bb[j];
       }
-      if (Y != nullptr) store_vals<TO, NV>(Y + row * p.C + c * NV, o);
+      if constexpr (sizeof(TO) == 2) {
+        if (Y != nullptr && p.split) {
+          float hi[NV], lo[NV];
+#pragma unroll
+          for (int i = 0; i < NV; ++i) { hi[i] = (float)(bf16_t)o[i]; lo[i] = o[i] - hi[i]; }
+          store_vals<TO, NV>(Y + row * 2 * p.C + c * NV, hi);
+          store_vals<TO, NV>(Y + row * 2 * p.C + p.C + c * NV, lo);
+        } else if (Y != nullptr) {
+          store_vals<TO, NV>(Y + row * p.C + c * NV, o);
+        }
+      } else {
+        if (Y != nullptr) store_vals<TO, NV>(Y + row * p.C + c * NV, o);
+      }
       if (p.yf != nullptr) store_vals<float, NV>(p.yf + row * p.C + c * NV, o);
     }
   }
@@ -142,6 +155,8 @@ int launch_ln(LnP p, hipStream_t st, const char* name) {
 }
 
 int dispatch_ln(LnP p, int x_dtype, int y_dtype, hipStream_t st, const char* name) {
+  p.split = 0;
+  if (y_dtype == OMP_BF16X2) { p.split = 1; y_dtype = OMP_BF16; }
   if (x_dtype == OMP_F32 && y_dtype == OMP_F32) return launch_ln<float, float>(p, st, name);
   if (x_dtype == OMP_F32 && y_dtype == OMP_BF16) return launch_ln<float, bf16_t>(p, st, name);
   if (x_dtype == OMP_BF16 && y_dtype == OMP_BF16) return launch_ln<bf16_t, bf16_t>(p, st, name);
@@ -213,7 +228,42 @@ __global__ void patch_embed_kernel(const float* __restrict__ img, const float* _
   }
 }
 
+// fp32 rows -> split-bf16 pair rows (the operand format of the bf16x3 products): hi = bf16(x), lo = bf16(x - hi).
+// triple = 0: [hi | lo] (A operands, read with a_wrap), 1: [hi | hi | lo] (the W-side image of an activation)
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y, int64_t ldy,
+                                                         int64_t rows, int C, int triple) {
+  const int cpr = C >> 2;   // 4-element chunks per row
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * cpr) return;
+  const int64_t r = idx / cpr;
+  const int c = (int)(idx - r * cpr) * 4;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+  bf16x4 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { hi[i] = (bf16_t)v[i]; lo[i] = (bf16_t)(v[i] - (float)hi[i]); }
+  bf16_t* yr = y + r * ldy + c;
+  *reinterpret_cast<bf16x4*>(yr) = hi;
+  if (triple) {
+    *reinterpret_cast<bf16x4*>(yr + C) = hi;
+    *reinterpret_cast<bf16x4*>(yr + 2 * C) = lo;
+  } else {
+    *reinterpret_cast<bf16x4*>(yr + C) = lo;
+  }
+}
+
 }  // namespace
+
+extern "C" int omp_split_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, int triple, omp_stream_t s) {
+  OMP_CHECK_ARG(x && y, "omp_split_bf16: null pointer");
+  OMP_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= (triple ? 3 : 2) * (int64_t)C,
+                "omp_split_bf16: bad shape rows=%lld C=%d", (long long)rows, C);
+  OMP_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0, "omp_split_bf16: misaligned pointers");
+  const int64_t n = rows * (C / 4);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)s, x, ldx, (bf16_t*)y, ldy, rows, C,
+                     triple ? 1 : 0);
+  OMP_CHECK_LAUNCH("omp_split_bf16");
+  return OMP_OK;
+}
 
 extern "C" int omp_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
                              int y_dtype, float* y_f32, int64_t rows, int C, float eps, omp_stream_t s) {
@@ -229,6 +279,12 @@ extern "C" int omp_layernorm(const void* x, int x_dtype, const float* gamma, con
 extern "C" int omp_patch_merge_gather_ln(const void* x, const float* gamma, const float* beta, void* y,
                                          int dtype, int B, int H, int W, int C, float eps,
                                          omp_stream_t s) {
+  return omp_patch_merge_gather_ln2(x, dtype, gamma, beta, y, dtype, B, H, W, C, eps, s);
+}
+
+extern "C" int omp_patch_merge_gather_ln2(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
+                                          int y_dtype, int B, int H, int W, int C, float eps, omp_stream_t s) {
+  const int dtype = x_dtype;
   OMP_CHECK_ARG(x && gamma && beta && y, "omp_patch_merge_gather_ln: null pointer");
   OMP_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0, "omp_patch_merge_gather_ln: bad shape");
   LnP p{};
@@ -237,7 +293,7 @@ extern "C" int omp_patch_merge_gather_ln(const void* x, const float* gamma, cons
   p.rows = (int64_t)B * p.H2 * p.W2; p.C = 4 * C;
   const int nv = dtype == OMP_F32 ? 4 : 8;
   OMP_CHECK_ARG(C % nv == 0, "omp_patch_merge_gather_ln: C=%d must be a multiple of %d", C, nv);
-  return dispatch_ln(p, dtype, dtype, (hipStream_t)s, "omp_patch_merge_gather_ln");
+  return dispatch_ln(p, x_dtype, y_dtype, (hipStream_t)s, "omp_patch_merge_gather_ln");
 }
 
 extern "C" int omp_patch_embed_ln(const float* img, const float* w, const float* b, const float* gamma,

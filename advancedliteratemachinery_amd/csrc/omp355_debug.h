@@ -1,0 +1,52 @@
+/* libomp355 -- DEVELOPMENT hooks.  Not part of the product ABI (include/omp355.h): kernel selectors for A/B measurements
+ * and cross-check kernels, per-workgroup trace buffers, hipEvent measurement brackets (bench.py's roofline legs), streams
+ * on a CU subset (the negative overlap experiment of DESIGN.md 5) and the teacher-forced logits step of the parity tests.
+ * The symbols are exported by libomp355.so for this repository's tests / tools / bench only; all of their state lives in
+ * the omp_ctx of the calling thread. */
+#ifndef OMP355_DEBUG_H
+#define OMP355_DEBUG_H
+
+#include "../../include/omp355.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int omp_debug_swin_mlp_variant(int v); /* alternative (rows per wave, waves, ring depth) instantiations of the fused MLP; 100 = traced default */
+int omp_debug_swin_mlp_trace(void* buffer); /* uint64 [workgroups][8] cycle sums written by variant 100 (csrc/mlp.hip) */
+
+/* ---- streams on a subset of the compute units (engine/pipeline.py: HBM-bound decoder phases of one engine call
+ * next to the matrix-core-bound encoder of another) ---------------------------------------------------------------
+ * mask: n_words x 32 bits, bit i = compute unit i in the runtime's numbering (hipExtStreamCreateWithCUMask).
+ * omp_debug_where: every workgroup of a short probe grid records (XCC_ID, HW_ID) -> out[2 * n_workgroups]. */
+int omp_stream_create_cu_mask(const uint32_t* mask, int n_words, omp_stream_t* out);
+int omp_stream_destroy(omp_stream_t s);
+int omp_debug_where(int32_t* out, int n_workgroups, omp_stream_t s);
+
+/* Measurement hooks (bench.py roofline legs): hipEvent-bracket every EAGERLY launched kernel of a class on its launch
+ * stream.  Classes (bit c of `mask`): 0 = decoder cross-attention kernels, 1 = large-M GEMMs (gemm_dma 128x128),
+ * 2 = fused Swin MLP.  omp_prof_read_class returns total milliseconds, launch count and the summed work of the
+ * bracketed launches (flops for classes 1 and 2; 0 for class 0, whose bytes the caller computes).  omp_prof_read =
+ * class 0 (kept for round-1 callers). */
+int omp_prof_enable(int mask);
+int omp_prof_read(double* total_ms, int64_t* count);
+int omp_prof_read_class(int cls, double* total_ms, int64_t* count, double* work);
+/* classes 1 and 2: summed algorithmic HBM bytes of the bracketed launches and the sum over launches of
+ * max(flops / 2.5 PFLOP/s, bytes / 8 TB/s) -- the time they would take on their own rooflines */
+int omp_prof_read_roofline(int cls, double* bytes, double* roofline_seconds);
+int omp_debug_force_gemm_kernel(int which);
+/* development: device buffer uint64 [n_workgroups][8] that omp_debug_force_gemm_kernel(15) fills with s_memtime stamps
+ * per workgroup: 0 start, 1 first K tile landed, 2 K loop done, 3 accumulators in LDS, 4 stores retired, 5 XCC id */
+int omp_debug_set_gemm_trace(void* buffer, int64_t n_workgroups);
+int omp_debug_swin_attn_impl(int which); /* 0 = matrix-core kernel (default), 1 = scalar cross-check kernel, 2 = matrix cores with per-score table lookups */
+int omp_debug_self_attn_impl(int which); /* 0 auto, 1 = one wave per (row, head), 2 = one wave per row (all 8 heads) */
+int omp_debug_cross_nt(int on);          /* 1 = non-temporal K / V^T loads in the 1-query-tile cross-attention kernel */
+int omp_debug_cross_q4(int on);          /* 1 = LDS-ring cross-attention for 33..64 rows/image in 64-key chunks, non-temporal DMA (default), 2 = one 32-key block per step, 4 = chunks with temporal loads, 0 = register-streaming kernel */
+
+/* Single teacher-forced step that also leaves logits in plan->logits (parity tests). */
+int omp_decoder_step_logits(const omp_decoder_plan* plan, int pos, omp_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMP355_DEBUG_H */

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, (EXPB && sizeof(T) == 2) ? 4 : 2) void swin_at
                                                               const float* __restrict__ qkv_bias,
                                                               const float* __restrict__ table,
                                                               T* __restrict__ out, int B, int H, int W, int C,
-                                                              int nH, int shift, int nWy, int nWx) {
+                                                              int nH, int shift, int nWy, int nWx, int out_split) {
   typedef Mma<T> MM;
   typedef SwinTraits<T> ST;
   typedef typename MM::frag frag;
@@ -427,6 +427,15 @@ __global__ __launch_bounds__(256, (EXPB && sizeof(T) == 2) ? 4 : 2) void swin_at
       for (int dt = 0; dt < 2; ++dt) {
         const f32x4 o = oacc[dt][t4];
         if constexpr (sizeof(T) == 4) {
+          if (out_split) {   // fp32 engine with bf16x3 products: the proj GEMM reads split pairs [hi | lo] (OMP_BF16X2)
+            bf16_t* ds = reinterpret_cast<bf16_t*>(out) + qtok[t4] * 2 * C + head * HD + g * 4 + dt * 16;
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)o[e]; lo[e] = (bf16_t)(o[e] - (float)hi[e]); }
+            *reinterpret_cast<bf16x4*>(ds) = hi;
+            *reinterpret_cast<bf16x4*>(ds + C) = lo;
+            continue;
+          }
           *reinterpret_cast<f32x4*>(dst + dt * 16) = o;
         } else {
           bf16x4 ov = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
@@ -466,12 +475,16 @@ extern "C" int omp_swin_expand_bias(const float* rel_bias_table, int nH, float* 
 extern "C" int omp_swin_window_attn(const void* qkv, const float* qkv_bias, const float* rel_bias_table,
                                     void* out, int dtype, int B, int H, int W, int C, int nH, int window,
                                     int shift, omp_stream_t s) {
-  return omp_swin_window_attn2(qkv, qkv_bias, rel_bias_table, nullptr, out, dtype, B, H, W, C, nH, window, shift, s);
+  return omp_swin_window_attn2(qkv, qkv_bias, rel_bias_table, nullptr, out, dtype, dtype, B, H, W, C, nH, window, shift, s);
 }
 
 extern "C" int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, const float* rel_bias_table,
-                                     const float* bias_expanded, void* out, int dtype, int B, int H, int W, int C, int nH,
+                                     const float* bias_expanded, void* out, int dtype, int out_dtype, int B, int H, int W, int C, int nH,
                                      int window, int shift, omp_stream_t s) {
+  OMP_CHECK_ARG(out_dtype == dtype || (out_dtype == OMP_BF16X2 && dtype == OMP_F32),
+                "omp_swin_window_attn: out_dtype must equal dtype (or be split-bf16 pairs for fp32 inputs)");
+  const int out_split = out_dtype == OMP_BF16X2 ? 1 : 0;
+  OMP_CHECK_ARG(!out_split || omp_cur().swin_impl != 1, "omp_swin_window_attn: the scalar cross-check kernel has no split-bf16 output");
   OMP_CHECK_ARG(qkv && qkv_bias && (rel_bias_table || bias_expanded) && out, "omp_swin_window_attn: null pointer");
   OMP_CHECK_ARG(window == WS, "omp_swin_window_attn: only window 7 is built (got %d)", window);
   OMP_CHECK_ARG(shift >= 0 && shift < WS, "omp_swin_window_attn: bad shift %d", shift);
@@ -493,11 +506,11 @@ extern "C" int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, con
     OMP_CHECK_ARG(expb || rel_bias_table != nullptr, "omp_swin_window_attn: the table form of the bias is needed for this path");
     const float* tb = expb ? bias_expanded : rel_bias_table;
     if (dtype == OMP_F32) {
-      if (expb) hipLaunchKernelGGL((swin_attn_mfma_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx);
-      else hipLaunchKernelGGL((swin_attn_mfma_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx);
+      if (expb) hipLaunchKernelGGL((swin_attn_mfma_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, out_split);
+      else hipLaunchKernelGGL((swin_attn_mfma_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, out_split);
     } else {
-      if (expb) hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, qkv_bias, tb, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx);
-      else hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, qkv_bias, tb, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx);
+      if (expb) hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, qkv_bias, tb, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx, 0);
+      else hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, qkv_bias, tb, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx, 0);
     }
   }
   OMP_CHECK_LAUNCH("omp_swin_window_attn");

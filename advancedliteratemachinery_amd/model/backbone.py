@@ -9,6 +9,14 @@ input_proj call of OmniParser.forward (model/omniparser.py:19-31).
 
 Layout: activations stay token-major [B*H*W, C] in the engine dtype for the whole backbone -- the
 reference's NCHW permutes, window partition/reverse copies, rolls and pads never materialise.
+
+Engine precisions (model/omniparser.py `engine_dtype`):
+  * 'bf16'    bf16 activations and weights, fp32 accumulation (the throughput configuration);
+  * 'fp32'    everything in fp32 on the fp32 matrix-core path (the reference's own precision);
+  * 'bf16x3'  the PARITY engine: fp32 storage and fp32 non-GEMM kernels exactly as 'fp32', but every large product runs on
+              the bf16 matrix cores as three bf16 products of split operands (x = hi + lo: hi.w_hi + lo.w_hi + hi.w_lo;
+              include/omp355.h, omp_gemm_args.a_wrap).  GEMM inputs travel as split pair rows [hi | lo] (same bytes as
+              fp32) written by their producers (LayerNorm, window attention, the fc1 epilogue); weights are split once.
 """
 import torch
 
@@ -34,13 +42,24 @@ class Encoder(object):
     """Packs the backbone/FPN/input_proj weights once (matrices -> engine dtype, vectors stay fp32)
     and runs images -> (memory, memory+pos, key padding mask)."""
 
-    def __init__(self, sd, args, swin_cfg, dtype):
+    def __init__(self, sd, args, swin_cfg, dtype, x3=False):
         self.dtype = dtype
+        self.x3 = bool(x3)
+        if self.x3 and dtype != torch.float32:
+            raise ValueError('bf16x3 products run inside the fp32 engine')
         self.args = args
         self.window = swin_cfg['window']
         self.embed_dim = swin_cfg['embed_dim']
         f32 = lambda k: sd[k].detach().float().contiguous()          # noqa: E731
-        mat = lambda k: sd[k].detach().to(dtype).contiguous()        # noqa: E731
+        if self.x3:   # [w_hi | w_hi | w_lo] images of the fp32 matrices (ops.split_weight3); K % 64 == 0 for the bf16 K tiles
+            def mat(k):
+                w = sd[k].detach().float()
+                w = w.reshape(w.shape[0], -1)
+                if w.shape[1] % 64 != 0:
+                    raise ValueError('bf16x3 engine: %s has K = %d, not a multiple of 64' % (k, w.shape[1]))
+                return ops.split_weight3(w)
+        else:
+            mat = lambda k: sd[k].detach().to(dtype).contiguous()    # noqa: E731
         bb = 'backbone.0.'
         self.pe_w = f32(bb + 'patch_embed.proj.weight').reshape(self.embed_dim, 48).contiguous()
         self.pe_b = f32(bb + 'patch_embed.proj.bias')
@@ -88,8 +107,37 @@ class Encoder(object):
         self.proj_b = f32('input_proj.bias')
 
     # -- Swin ---------------------------------------------------------------------------------
+    def _backbone_x3(self, img, want_f32):
+        """The bf16x3 engine's backbone: fp32 residual stream x, split-pair GEMM operands, fp32 window attention.
+        -> list of (normed map as split pairs [B*h*w, 2C], h, w, fp32 copy or None) per stage."""
+        B = img.shape[0]
+        S = ops.SPLIT
+        x, H, W = ops.patch_embed_ln(img, self.pe_w, self.pe_b, self.pe_g, self.pe_bt, torch.float32, LN_EPS)
+        x = x.view(B * H * W, self.embed_dim)
+        outs = []
+        for st in self.stages:
+            C = st.C
+            for blk in st.blocks:
+                y = ops.layernorm(x, blk.n1g, blk.n1b, out_dtype=S, eps=LN_EPS)
+                qkv = ops.gemm(y, blk.qkv_w, blk.qkv_b, out_dtype=torch.float32, a_wrap=2 * C)
+                att = ops.swin_window_attn(qkv, blk.qkv_b, blk.table, B, H, W, C, st.nH, blk.shift, out=y, window=self.window,
+                                           bias_expanded=blk.bias_exp, out_split=True)
+                ops.gemm(att, blk.proj_w, blk.proj_b, residual=x, out=x, a_wrap=2 * C)
+                y = ops.layernorm(x, blk.n2g, blk.n2b, out=y, out_dtype=S, eps=LN_EPS)
+                h = ops.gemm(y, blk.fc1_w, blk.fc1_b, act=ops.ACT_GELU, out_dtype=S, a_wrap=2 * C)
+                ops.gemm(h, blk.fc2_w, blk.fc2_b, residual=x, out=x, a_wrap=8 * C)
+            f32c = torch.empty_like(x) if want_f32 else None
+            outs.append((ops.layernorm(x, st.out_g, st.out_b, out_dtype=S, out_f32=f32c, eps=LN_EPS), H, W, f32c))
+            if st.down_w is not None:
+                y, H2, W2 = ops.patch_merge_gather_ln(x, st.down_g, st.down_b, B, H, W, C, LN_EPS, out_dtype=S)
+                x = ops.gemm(y, st.down_w, out_dtype=torch.float32, a_wrap=8 * C)
+                H, W = H2, W2
+        return outs
+
     def backbone(self, img):
         """img [B,3,H,W] fp32 -> list of (normed map [B*h*w, C], h, w) per stage."""
+        if self.x3:
+            return [(f, h, w) for _, h, w, f in self._backbone_x3(img, True)]
         B = img.shape[0]
         x, H, W = ops.patch_embed_ln(img, self.pe_w, self.pe_b, self.pe_g, self.pe_bt, self.dtype, LN_EPS)
         x = x.view(B * H * W, self.embed_dim)
@@ -127,13 +175,22 @@ class Encoder(object):
         no_padding: the caller knows `mask` is all False -> the sine embedding (a function of the mask only) is taken from a
         per-shape cache.  out: optional (memory, mem_pos) destination views of a larger engine call (_encode_chunked)."""
         B = img.shape[0]
-        feats = self.backbone(img)
+        x3 = self.x3
+        if x3:
+            sfeats = self._backbone_x3(img, want_intermediates)
+            feats = [(f, h, w) for _, h, w, f in sfeats]
+        else:
+            feats = self.backbone(img)
         if self.use_fpn:
             (c2, h2, w2), (c3, h3, w3), (c4, h4, w4), (c5, h5, w5) = feats
-            l5 = ops.gemm(c5, self.fpn_w[0])
-            l4 = ops.gemm(c4, self.fpn_w[1])
-            l3 = ops.gemm(c3, self.fpn_w[2])
-            l2 = ops.gemm(c2, self.fpn_w[3])
+            if x3:
+                lat = lambda i, lvl: ops.gemm(sfeats[lvl][0], self.fpn_w[i], out_dtype=torch.float32, a_wrap=sfeats[lvl][0].shape[1])  # noqa: E731
+                l5, l4, l3, l2 = lat(0, 3), lat(1, 2), lat(2, 1), lat(3, 0)
+            else:
+                l5 = ops.gemm(c5, self.fpn_w[0])
+                l4 = ops.gemm(c4, self.fpn_w[1])
+                l3 = ops.gemm(c3, self.fpn_w[2])
+                l2 = ops.gemm(c2, self.fpn_w[3])
             sizes = ((h2, w2), (h3, w3), (h4, w4), (h5, w5))
             src, ho, wo = ops.fpn_fuse(l2, l3, l4, l5, B, sizes, 2)
             lvl = (h4, w4)
@@ -141,6 +198,8 @@ class Encoder(object):
                 raise RuntimeError('stride-2 projection grid %s != stage-2 grid %s' % ((ho, wo), lvl))
         else:
             src, ho, wo = feats[-1]
+            if x3:
+                src = sfeats[-1][0]   # already split pairs
             lvl = (ho, wo)
         lm = self.level_mask(mask, *lvl)
         M = ho * wo
@@ -163,15 +222,21 @@ class Encoder(object):
             memory, mem_pos_out = out
         else:
             memory, mem_pos_out = torch.empty((B * M, self.proj_w.shape[0]), dtype=self.dtype, device=src.device), None
+        gk = {}
+        if x3:
+            ssrc = src if src.dtype == torch.bfloat16 else ops.split_bf16(src)   # FPN output: fp32 -> split pairs
+            gk = dict(a_wrap=ssrc.shape[1], out_dtype=torch.float32)
+        else:
+            ssrc = src
         if B * M > 64:
-            mem_pos = ops.gemm(src, self.proj_w, self.proj_b, residual=pos, out_noresidual=memory, out=mem_pos_out)
+            mem_pos = ops.gemm(ssrc, self.proj_w, self.proj_b, residual=pos, out_noresidual=memory, out=mem_pos_out, **gk)
         else:   # tiny inputs run on the small-M kernels, which have no second destination
-            ops.gemm(src, self.proj_w, self.proj_b, out=memory)
-            mem_pos = ops.gemm(src, self.proj_w, self.proj_b, residual=pos, out=mem_pos_out)
+            ops.gemm(ssrc, self.proj_w, self.proj_b, out=memory, **gk)
+            mem_pos = ops.gemm(ssrc, self.proj_w, self.proj_b, residual=pos, out=mem_pos_out, **gk)
         out = dict(memory=memory, mem_pos=mem_pos, M=M, hw=(ho, wo), pos=pos, key_mask=lm.reshape(B, M))
         if want_intermediates:
             out['feats'] = feats
-            out['src'] = src
+            out['src'] = src if not (x3 and not self.use_fpn) else feats[-1][0]
             if self.use_fpn:
                 out['src_full'] = ops.fpn_fuse(l2, l3, l4, l5, B, sizes, 1)[0]
         return out

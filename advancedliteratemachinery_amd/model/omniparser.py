@@ -20,7 +20,9 @@ from . import params
 from .backbone import Encoder
 from .transformer import Decoder, index2class
 
-_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32, torch.bfloat16: torch.bfloat16,
+# 'bf16x3' = the parity engine: fp32 storage / fp32 non-GEMM kernels, large products as three bf16 products of split
+# operands on the bf16 matrix cores (model/backbone.py, include/omp355.h omp_gemm_args.a_wrap)
+_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'bf16x3': 'bf16x3', torch.bfloat16: torch.bfloat16,
            torch.float32: torch.float32}
 
 
@@ -70,9 +72,11 @@ class OmniParser(nn.Module):
                 raise RuntimeError('OmniParser runs on MI355X only: move the model to a cuda (HIP) device; '
                                    'there is no CPU fallback')
             sd = {k: v for k, v in self.state_dict().items()}
+            x3 = self.engine_dtype == 'bf16x3'
+            tdt = torch.float32 if x3 else self.engine_dtype
             with torch.cuda.device(dev):
-                enc = Encoder(sd, self.args, self.swin_cfg, self.engine_dtype)
-                dec = Decoder(sd, self.args, self.engine_dtype, dev)
+                enc = Encoder(sd, self.args, self.swin_cfg, tdt, x3=x3)
+                dec = Decoder(sd, self.args, tdt, dev, x3=x3)
             self._engine, self._engine_key = (enc, dec), key
         self._engine[1].use_graph = self.use_graph
         return self._engine

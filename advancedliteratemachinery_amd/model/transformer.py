@@ -129,8 +129,9 @@ class _Phase(object):
 
 
 class Decoder(object):
-    def __init__(self, sd, args, dtype, device):
+    def __init__(self, sd, args, dtype, device, x3=False):
         self.args, self.dtype, self.device = args, dtype, device
+        self.x3 = bool(x3)   # bf16x3 engine: the K / V^T projection of the memory runs as split-bf16 products (decoder steps stay fp32)
         self.d, self.nH, self.L = args.tfm_hidden_dim, args.tfm_nheads, args.tfm_dec_layers
         self.ff, self.V = args.tfm_dim_feedforward, args.num_classes
         if self.d != self.nH * 64:
@@ -178,8 +179,14 @@ class Decoder(object):
             hp = '%s%s_pred_layer.layers.' % (tr, kind)
             self.head[kind] = [(mat(f32(hp + '%d.weight' % i)), f32(hp + '%d.bias' % i)) for i in range(3)]
         # one stacked projection for the memory K and V of all (decoder, layer) pairs
-        self.Wk_all, self.bk_all = mat(torch.cat(wk, 0)), torch.cat(bk, 0).contiguous()
-        self.Wv_all, self.bv_all = mat(torch.cat(wv, 0)), torch.cat(bv, 0).contiguous()
+        if self.x3:
+            # K: tokens are the A operand (split pairs, a_wrap), the weight its [hi | hi | lo] image; V^T: operands swapped,
+            # the weight is the [hi | lo] A side and the tokens arrive as [hi | hi | lo] (ops.split_bf16(triple=True))
+            self.Wk_all, self.Wv_all = ops.split_weight3(torch.cat(wk, 0)), ops.split_weight2(torch.cat(wv, 0))
+            self.bk_all, self.bv_all = torch.cat(bk, 0).contiguous(), torch.cat(bv, 0).contiguous()
+        else:
+            self.Wk_all, self.bk_all = mat(torch.cat(wk, 0)), torch.cat(bk, 0).contiguous()
+            self.Wv_all, self.bv_all = mat(torch.cat(wv, 0)), torch.cat(bv, 0).contiguous()
         self.NL = len(KINDS) * self.L
 
     # -- memory K/V: once per batch ---------------------------------------------------------------
@@ -205,6 +212,13 @@ class Decoder(object):
             mask_buf.copy_(key_mask.reshape(B, M))
             key_mask = mask_buf
         geom = (B, M, Mpad, self.nH, KB)
+        if self.x3:
+            d = self.d
+            ops.gemm(ops.split_bf16(mem_pos), self.Wk_all, self.bk_all, out=K_all, store_mode=_lib.STORE_KBLK, kv=geom, a_wrap=2 * d,
+                     M=B * M, N=self.Wk_all.shape[0], K=3 * d)
+            ops.gemm(self.Wv_all, ops.split_bf16(memory, triple=True), self.bv_all, out=Vt_all, store_mode=_lib.STORE_VBLK, kv=geom,
+                     bias_along_m=True, a_wrap=2 * d, M=self.Wv_all.shape[0], N=B * M, K=3 * d)
+            return dict(K=K_all, Vt=Vt_all, B=B, M=M, Mpad=Mpad, KB=KB, key_mask=key_mask)
         ops.gemm(mem_pos, self.Wk_all, self.bk_all, out=K_all, store_mode=_lib.STORE_KBLK, kv=geom)
         # swapped operands: rows = value features, columns = memory tokens, so a lane owns 4 consecutive keys
         ops.gemm(self.Wv_all, memory, self.bv_all, out=Vt_all, store_mode=_lib.STORE_VBLK, kv=geom, bias_along_m=True,

@@ -8,9 +8,10 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, OMP_BF16, OMP_F32  # noqa: F401
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, OMP_BF16, OMP_BF16X2, OMP_F32  # noqa: F401
 
 _DT = {torch.float32: OMP_F32, torch.bfloat16: OMP_BF16}
+SPLIT = 'bf16x2'   # out_dtype of producers that write split-bf16 pair rows [hi | lo] (OMP_BF16X2): a bf16 tensor [rows, 2C]
 
 
 def dt(t):
@@ -43,10 +44,12 @@ def layernorm(x, gamma, beta, out_dtype=None, out=None, out_f32=None, eps=1e-5, 
     _c(x, 'x')
     rows, C = x.numel() // x.shape[-1], x.shape[-1]
     out_dtype = out_dtype or x.dtype
+    split = out_dtype == SPLIT
     if out is None and want_out:
-        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        out = (torch.empty((rows, 2 * C), dtype=torch.bfloat16, device=x.device) if split
+               else torch.empty(x.shape, dtype=out_dtype, device=x.device))
     rc = _lib.lib().omp_layernorm(ptr(x), dt(x), ptr(gamma), ptr(beta), ptr(out),
-                                  dt(out) if out is not None else OMP_F32, ptr(out_f32), rows, C,
+                                  OMP_BF16X2 if split else (dt(out) if out is not None else OMP_F32), ptr(out_f32), rows, C,
                                   float(eps), stream())
     _lib.check(rc, 'omp_layernorm')
     return out
@@ -54,19 +57,22 @@ def layernorm(x, gamma, beta, out_dtype=None, out=None, out_f32=None, eps=1e-5, 
 
 def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None, M=None, lda=None,
          ldw=None, ldc=None, N=None, K=None, bias_row=None, bias_row_stride=0, trans_rows=0, trans_ld=0,
-         ln=None, ln_eps=1e-5, small_m=False, store_mode=0, kv=None, bias_along_m=False, out_noresidual=None):
+         ln=None, ln_eps=1e-5, small_m=False, store_mode=0, kv=None, bias_along_m=False, out_noresidual=None, a_wrap=0):
     """out[M,N] = act(A[M,K] @ W[N,K]^T + bias) + residual.  A/W may be strided row views (lda/ldw).
-    out_noresidual (optional, with a residual): also receives act(A W^T + bias) without the residual."""
-    K = K or A.shape[-1]
+    out_noresidual (optional, with a residual): also receives act(A W^T + bias) without the residual.
+    a_wrap > 0: bf16x3 product -- A is a split-bf16 pair tensor [M, a_wrap] = [hi | lo], W the [N, K] = [hi | hi | lo] image of an
+    fp32 weight (split_weight3), K = 3/2 a_wrap.  out_dtype=SPLIT: the result is written as split pairs [M, 2N]."""
+    K = K or (W.shape[-1] if a_wrap else A.shape[-1])
     N = N or W.shape[0]
     M = M or A.numel() // A.shape[-1]
     lda = lda or A.stride(-2) if A.dim() > 1 else K
     ldw = ldw or W.stride(0)
     out_dtype = out_dtype or W.dtype
+    split = out_dtype == SPLIT
     if out is None:
         if trans_rows:
             raise ValueError('trans_out needs a preallocated (zeroed) output')
-        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+        out = torch.empty((M, 2 * N if split else N), dtype=torch.bfloat16 if split else out_dtype, device=A.device)
     ldc = ldc or (out.stride(-2) if out.dim() > 1 and not store_mode else N)
     a = _lib.GemmArgs()
     a.A, a.lda, a.W, a.ldw = ptr(A), lda, ptr(W), ldw
@@ -74,7 +80,8 @@ def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     a.residual, a.ldr = ptr(residual), (residual.stride(-2) if residual is not None else 0)
     a.C, a.ldc = ptr(out), ldc
     a.M, a.N, a.K = M, N, K
-    a.dtype, a.out_dtype, a.act = dt(W), dt(out), act
+    a.dtype, a.out_dtype, a.act = dt(W), (OMP_BF16X2 if split else dt(out)), act
+    a.a_wrap = int(a_wrap)
     if ln is not None:
         a.ln_gamma, a.ln_beta, a.ln_eps = ptr(ln[0]), ptr(ln[1]), float(ln_eps)
     a.small_m_splitk = 1 if small_m else 0
@@ -123,24 +130,58 @@ def swin_expand_bias(table):
     return out
 
 
-def swin_window_attn(qkv, qkv_bias, table, B, H, W, C, nH, shift, out=None, window=7, bias_expanded=None):
+def swin_window_attn(qkv, qkv_bias, table, B, H, W, C, nH, shift, out=None, window=7, bias_expanded=None, out_split=False):
+    """out_split (fp32 qkv only): out is [B*H*W, 2C] bf16 split pairs [hi | lo] for the bf16x3 proj GEMM."""
     _c(qkv, 'qkv')
     if out is None:
-        out = torch.empty((B * H * W, C), dtype=qkv.dtype, device=qkv.device)
-    rc = _lib.lib().omp_swin_window_attn2(ptr(qkv), ptr(qkv_bias), ptr(table), ptr(bias_expanded), ptr(out), dt(qkv), B, H, W, C,
-                                          nH, window, shift, stream())
+        out = (torch.empty((B * H * W, 2 * C), dtype=torch.bfloat16, device=qkv.device) if out_split
+               else torch.empty((B * H * W, C), dtype=qkv.dtype, device=qkv.device))
+    rc = _lib.lib().omp_swin_window_attn2(ptr(qkv), ptr(qkv_bias), ptr(table), ptr(bias_expanded), ptr(out), dt(qkv),
+                                          OMP_BF16X2 if out_split else dt(qkv), B, H, W, C, nH, window, shift, stream())
     _lib.check(rc, 'omp_swin_window_attn')
     return out
 
 
-def patch_merge_gather_ln(x, gamma, beta, B, H, W, C, eps=1e-5):
+def patch_merge_gather_ln(x, gamma, beta, B, H, W, C, eps=1e-5, out_dtype=None):
+    """out_dtype: x.dtype (default), torch.bfloat16 for an fp32 x, or SPLIT (split pairs [rows, 8C])."""
     _c(x, 'x')
     H2, W2 = (H + 1) // 2, (W + 1) // 2
-    out = torch.empty((B * H2 * W2, 4 * C), dtype=x.dtype, device=x.device)
-    rc = _lib.lib().omp_patch_merge_gather_ln(ptr(x), ptr(gamma), ptr(beta), ptr(out), dt(x), B, H, W, C,
-                                              float(eps), stream())
+    out_dtype = out_dtype or x.dtype
+    split = out_dtype == SPLIT
+    out = torch.empty((B * H2 * W2, (8 if split else 4) * C), dtype=torch.bfloat16 if split else out_dtype, device=x.device)
+    rc = _lib.lib().omp_patch_merge_gather_ln2(ptr(x), dt(x), ptr(gamma), ptr(beta), ptr(out), OMP_BF16X2 if split else dt(out),
+                                               B, H, W, C, float(eps), stream())
     _lib.check(rc, 'omp_patch_merge_gather_ln')
     return out, H2, W2
+
+
+def split_bf16(x, triple=False, out=None):
+    """fp32 [rows, C] -> bf16 split pairs [rows, 2C] = [hi | lo] (triple: [rows, 3C] = [hi | hi | lo]); omp_split_bf16."""
+    if x.dtype != torch.float32:
+        raise TypeError('split_bf16 takes fp32 rows')
+    rows, C = x.numel() // x.shape[-1], x.shape[-1]
+    n = 3 if triple else 2
+    if out is None:
+        out = torch.empty((rows, n * C), dtype=torch.bfloat16, device=x.device)
+    rc = _lib.lib().omp_split_bf16(ptr(x), x.stride(-2) if x.dim() > 1 else C, ptr(out), out.stride(-2), rows, C, 1 if triple else 0, stream())
+    _lib.check(rc, 'omp_split_bf16')
+    return out
+
+
+def split_weight3(w):
+    """fp32 weight [N, K] -> bf16 [N, 3K] = [w_hi | w_hi | w_lo]: the W-side image of a bf16x3 product (once per checkpoint)."""
+    w = w.detach().float()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, hi, lo], dim=1).contiguous()
+
+
+def split_weight2(w):
+    """fp32 weight [N, K] -> bf16 [N, 2K] = [w_hi | w_lo]: the A-side operand of a bf16x3 product with swapped operands."""
+    w = w.detach().float()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo], dim=1).contiguous()
 
 
 def fpn_fuse(l2, l3, l4, l5, B, sizes, stride):

@@ -92,7 +92,7 @@ _FLAGS = [
 
 # Engine-only flags (not in the reference): precision of the HIP path.
 _ENGINE_FLAGS = [
-    ('--engine_dtype', dict(type=str, default='bf16', choices=['bf16', 'fp32'])),
+    ('--engine_dtype', dict(type=str, default='bf16', choices=['bf16', 'fp32', 'bf16x3'])),
 ]
 
 

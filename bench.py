@@ -67,7 +67,9 @@ def parse():
     p.add_argument('--batch', type=int, default=None, help='images per GPU per step (default: 8 spotting, 32 kie, 512 mgp_str)')
     p.add_argument('--size', type=int, default=1024)
     p.add_argument('--instances', type=int, default=64, help='forced text instances per image')
-    p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'bf16x3'],
+                   help='engine precision: bf16 (BASELINE config 2), fp32, or bf16x3 = the parity engine (fp32 storage, split-bf16 products)')
+    p.add_argument('--no-parity-leg', action='store_true', help='skip the parity_engine leg (bf16x3 engine on the same workload)')
     p.add_argument('--graph', type=int, default=int(os.environ.get('OMP355_GRAPH', '1')))
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
@@ -490,7 +492,7 @@ def main():
     mask1 = torch.zeros(B, a.size, a.size, dtype=torch.bool, device=device)
     calls = []   # (start event, end event, images) of every engine call, recorded on its lane stream
 
-    def run_group(first_step, g_, lane=None, forced=N):
+    def run_group(first_step, g_, lane=None, forced=N, model=model):
         """steps first_step .. first_step+g_-1 as ONE engine call: their batches arrive as separate tensors and are
         concatenated here, inside the timed region, as a serving engine would have to."""
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -642,6 +644,33 @@ def main():
         finally:
             args.pt_seq_length = keep
 
+    def parity_leg():
+        # The engine that MEETS the parity contract (tests/test_gpu_e2e.py::test_parity_engine_bf16x3: logits within 1e-3 of the
+        # reference, ids identical on every fixture) on the same workload and the same engine-call size, one lane
+        m2, _, _ = build_model('bf16x3', a.graph, device)
+        m2.overlap_decoders = bool(a.overlap)
+        m2.engine()
+        kp = min(a.steps, G)
+        with torch.cuda.stream(stream):
+            run_group(0, kp, model=m2)
+            torch.cuda.synchronize()
+            rp = []
+            while sum(rp) < 3.0 and len(rp) < 6:
+                t0 = time.perf_counter()
+                run_group(0, kp, model=m2)
+                torch.cuda.synchronize()
+                rp.append(time.perf_counter() - t0)
+        ep = pct(rp, 0.5)
+        del m2
+        torch.cuda.empty_cache()
+        return dict(engine='bf16x3', images_per_sec=B * kp / ep, chars_per_sec=B * kp / ep * N * args.rec_length, ms_per_step=ep / kp * 1e3,
+                    images_per_engine_call=B * kp, repeats=len(rp),
+                    note='cheapest engine precision that passes the fp32 parity gates (logits <= 1e-3, decoded ids identical, '
+                         'tests/test_gpu_e2e.py::test_parity_engine_bf16x3): fp32 storage, large products as 3 bf16 matrix-core products '
+                         'of split operands; same workload, one lane')
+
+    if rank == 0 and world == 1 and not a.no_parity_leg and a.dtype == 'bf16':
+        leg('parity_engine', parity_leg)
     if rank == 0 and world == 1 and not a.no_batch8:
         leg('batch8', batch8_leg)
     if rank == 0 and world == 1 and not a.no_eos_run:
@@ -694,7 +723,7 @@ def main():
         h.omp_prof_enable(0)
         model.use_graph = was
         M = (a.size // 16) ** 2
-        esz = 2 if a.dtype == 'bf16' else 4
+        esz = 2 if a.dtype == 'bf16' else 4   # K / V^T slabs: bf16, or fp32 (fp32 and bf16x3 engines)
         BI = B * G   # images per launch
         recs = []
         if n_gemm:

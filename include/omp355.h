@@ -16,6 +16,8 @@
  *     weights keep the reference's nn.Linear layout [out_features, in_features];
  *   - dtype enum: OMP_F32 / OMP_BF16 for activations+weights; biases, LayerNorm affine
  *     parameters, embedding and bias tables are always fp32; accumulation is fp32.
+ *   - development hooks (kernel selectors, trace buffers, measurement brackets, CU-masked streams) are declared in
+ *     csrc/omp355_debug.h, not here: they are exported for the tests and tools of this repository only.
  */
 #ifndef OMP355_H
 #define OMP355_H
@@ -26,11 +28,14 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 12
+#define OMP_ABI_VERSION 13
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
-enum { OMP_F32 = 0, OMP_BF16 = 1 };
+/* OMP_BF16X2 = split-bf16 pair rows: a [rows, C] tensor is stored as rows of 2C bf16, hi = bf16(x) in columns 0..C-1 and
+ * lo = bf16(x - hi) in columns C..2C-1 (16 mantissa bits, the same bytes as fp32).  It is the GEMM-operand format of the
+ * bf16x3 engine: x.w ~ hi.w_hi + lo.w_hi + hi.w_lo on the bf16 matrix cores (see omp_gemm_args.a_wrap). */
+enum { OMP_F32 = 0, OMP_BF16 = 1, OMP_BF16X2 = 2 };
 enum { OMP_ACT_NONE = 0, OMP_ACT_GELU = 1, OMP_ACT_RELU = 2 };
 enum { OMP_STORE_PLAIN = 0, OMP_STORE_KBLK = 2, OMP_STORE_VBLK = 3 };
 /* decoder kinds (reference: model/transformer.py:26-33 pt/poly/rec decoders) */
@@ -44,7 +49,7 @@ int omp_abi_version(void);
 /* ---- LayerNorm ---------------------------------------------------------------------------
  * y = (x - mean) / sqrt(var + eps) * gamma + beta over the last dim (biased variance).
  * Replaces nn.LayerNorm call sites: swin_transformer.py:208,250,288,441,616 and
- * transformer.py:326,374,437,441,450.  Writes y (dtype y_dtype, may be NULL) and/or y_f32. */
+ * transformer.py:326,374,437,441,450.  Writes y (dtype y_dtype, may be NULL; OMP_BF16X2 = split pairs [rows, 2C]) and/or y_f32. */
 int omp_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
                   int y_dtype, float* y_f32, int64_t rows, int C, float eps, omp_stream_t s);
 
@@ -74,7 +79,7 @@ typedef struct {
   int32_t N;
   int32_t K;
   int32_t dtype;     /* of A and W */
-  int32_t out_dtype; /* of C and residual: dtype or OMP_F32 */
+  int32_t out_dtype; /* of C and residual: dtype, OMP_F32, or OMP_BF16X2 (dtype OMP_BF16, no residual: C is [M, 2N] split pairs) */
   int32_t act;
   int32_t trans_out;
   int64_t trans_rows; /* rows (tokens) per batch item */
@@ -102,6 +107,14 @@ typedef struct {
    * adds pos inside nn.MultiheadAttention's key path); requires a residual, OMP_STORE_PLAIN, no trans_out. */
   void* C2;
   int64_t ldc2;
+  /* bf16x3 products (fp32-grade results at a third of the bf16 matrix-core rate; the parity engine):
+   * A is a split-bf16 pair tensor [M, 2*K0] = [a_hi | a_lo] (OMP_BF16X2 rows, dtype stays OMP_BF16), W is the once-per-
+   * checkpoint image [N, 3*K0] = [w_hi | w_hi | w_lo] of an fp32 weight, K = 3*K0 and a_wrap = 2*K0: A columns at and
+   * beyond a_wrap are read from column (k - a_wrap), i.e. A is consumed as [a_hi | a_lo | a_hi] without being stored
+   * that way.  The contraction is then a_hi.w_hi + a_lo.w_hi + a_hi.w_lo (the a_lo.w_lo term, 2^-16 relative, is
+   * dropped).  With swapped operands (OMP_STORE_VBLK) the weight is the [hi | lo] side and the activation arrives as
+   * [hi | hi | lo] (omp_split_bf16, triple = 1).  0 = plain product. */
+  int32_t a_wrap;
 } omp_gemm_args;
 int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s);
 
@@ -114,8 +127,6 @@ int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s);
 int omp_swin_mlp_fused(const void* x, int64_t ldx, const float* ln_gamma, const float* ln_beta, float eps,
                        const void* wpack, const float* b2, void* y, int64_t ldy, int64_t M, int C, int hidden,
                        omp_stream_t s);
-int omp_debug_swin_mlp_variant(int v); /* development: alternative (rows per wave, waves, ring depth) instantiations; 100 = traced default */
-int omp_debug_swin_mlp_trace(void* buffer); /* development: uint64 [workgroups][8] cycle sums written by variant 100 (csrc/mlp.hip) */
 
 /* ---- Swin patch embedding: zero-pad to x4, 4x4/4 conv (as K=48 dot products), LayerNorm -----
  * Replaces PatchEmbed.forward, swin_transformer.py:427-443.  img is NCHW fp32 (as the reference
@@ -136,9 +147,11 @@ int omp_swin_window_attn(const void* qkv, const float* qkv_bias, const float* re
                          int shift, omp_stream_t s);
 /* The same with the relative-position bias EXPANDED once per checkpoint (swin_transformer.py:133-135 re-gathers
  * table[index] on every call): bias_expanded fp32 [nH][64][64] from omp_swin_expand_bias (bias / scale per (query, key),
- * -inf on the padding key slots); rel_bias_table may then be NULL. */
+ * -inf on the padding key slots); rel_bias_table may then be NULL.  out_dtype = dtype, or OMP_BF16X2 with dtype OMP_F32
+ * (out is then [B*H*W, 2C] split pairs for the bf16x3 proj GEMM). */
 int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, const float* rel_bias_table, const float* bias_expanded,
-                          void* out, int dtype, int B, int H, int W, int C, int nH, int window, int shift, omp_stream_t s);
+                          void* out, int dtype, int out_dtype, int B, int H, int W, int C, int nH, int window, int shift,
+                          omp_stream_t s);
 int omp_swin_expand_bias(const float* rel_bias_table, int nH, float* out, omp_stream_t s);
 
 /* ---- PatchMerging gather + LayerNorm(4C) ------------------------------------------------------------
@@ -146,6 +159,16 @@ int omp_swin_expand_bias(const float* rel_bias_table, int nH, float* out, omp_st
  * LN).  x: [B,H,W,C] -> y: [B, ceil(H/2)*ceil(W/2), 4C]; the 4C->2C reduction is a GEMM. */
 int omp_patch_merge_gather_ln(const void* x, const float* gamma, const float* beta, void* y,
                               int dtype, int B, int H, int W, int C, float eps, omp_stream_t s);
+/* the same with distinct input / output types: fp32 residual stream in, bf16 or split-bf16 (OMP_BF16X2) rows out */
+int omp_patch_merge_gather_ln2(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                               int B, int H, int W, int C, float eps, omp_stream_t s);
+
+/* ---- fp32 rows -> split-bf16 pair rows (OMP_BF16X2) ---------------------------------------------------------------
+ * y[r, c] = hi = bf16(x[r, c]); y[r, C + c] = lo = bf16(x[r, c] - hi)            (triple = 0: [hi | lo], ldy >= 2C)
+ * triple = 1 writes [hi | hi | lo] (ldy >= 3C): the W-side image of an activation (K / V^T projection with swapped
+ * operands).  Producers that can write split rows themselves do (omp_layernorm, omp_gemm_bias_act, omp_swin_window_attn2);
+ * this is the conversion for the others (FPN output, decoder memory).  No reference counterpart: storage format. */
+int omp_split_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, int triple, omp_stream_t s);
 
 /* ---- FPN top-down + resample + concat, evaluated only where input_proj samples it -------------
  * Replaces fpn.py:25-44 (nearest top-down adds, bilinear resample of p2/p4/p5 to c3's grid,
@@ -307,8 +330,8 @@ int omp_a3_pool(const float* sel, int ld_sel, const void* feat, int dtype, float
 int omp_row_argmax_prob(const float* logits, int64_t ld, int R, int V, int32_t* ids, float* prob, omp_stream_t s);
 
 /* ---- context: ALL mutable state of the library ---------------------------------------------------
- * An omp_ctx holds the kernel selectors (omp_debug_*), the development trace buffers, the table of hipGraphs that
- * omp_decoder_run captures under its graph_slot ids, and the measurement brackets (omp_prof_*).  Every entry point
+ * An omp_ctx holds the table of hipGraphs that omp_decoder_run captures under its graph_slot ids, plus the development
+ * state declared in csrc/omp355_debug.h (kernel selectors, trace buffers, measurement brackets).  Every entry point
  * works on the CURRENT context of the calling host thread: the process default context until the thread calls
  * omp_ctx_make_current.  Two engines in one process (or one per pipeline lane) get independent state by creating
  * their own; destroying a context destroys the graphs it captured.  Beyond the context the library keeps only a
@@ -319,14 +342,6 @@ int omp_ctx_create(omp_ctx** out);
 int omp_ctx_destroy(omp_ctx* ctx);          /* not the default context */
 int omp_ctx_make_current(omp_ctx* ctx);     /* NULL = back to the process default context */
 omp_ctx* omp_ctx_current(void);             /* the calling thread's context (never NULL) */
-
-/* ---- streams on a subset of the compute units (engine/pipeline.py: HBM-bound decoder phases of one engine call
- * next to the matrix-core-bound encoder of another) ---------------------------------------------------------------
- * mask: n_words x 32 bits, bit i = compute unit i in the runtime's numbering (hipExtStreamCreateWithCUMask).
- * omp_debug_where: every workgroup of a short probe grid records (XCC_ID, HW_ID) -> out[2 * n_workgroups]. */
-int omp_stream_create_cu_mask(const uint32_t* mask, int n_words, omp_stream_t* out);
-int omp_stream_destroy(omp_stream_t s);
-int omp_debug_where(int32_t* out, int n_workgroups, omp_stream_t s);
 
 /* ---- test-time image pre-processing (the step before the hot path) -----------------
  * Replaces dataset/transforms.py:249-298 (RandomResize([test_min_size], test_max_size) = Pillow bilinear resize
@@ -340,29 +355,6 @@ int omp_resize_normalize_pad(const uint8_t* src, int64_t src_pitch, int in_h, in
                              const int32_t* xcoef, int ksx, const int32_t* ybounds, const int32_t* ycoef, int ksy,
                              const float* lut, float* dst, uint8_t* mask, int out_h, int out_w, int dst_h,
                              int dst_w, omp_stream_t s);
-
-/* Measurement hooks (bench.py roofline legs): hipEvent-bracket every EAGERLY launched kernel of a class on its launch
- * stream.  Classes (bit c of `mask`): 0 = decoder cross-attention kernels, 1 = large-M GEMMs (gemm_dma 128x128),
- * 2 = fused Swin MLP.  omp_prof_read_class returns total milliseconds, launch count and the summed work of the
- * bracketed launches (flops for classes 1 and 2; 0 for class 0, whose bytes the caller computes).  omp_prof_read =
- * class 0 (kept for round-1 callers). */
-int omp_prof_enable(int mask);
-int omp_prof_read(double* total_ms, int64_t* count);
-int omp_prof_read_class(int cls, double* total_ms, int64_t* count, double* work);
-/* classes 1 and 2: summed algorithmic HBM bytes of the bracketed launches and the sum over launches of
- * max(flops / 2.5 PFLOP/s, bytes / 8 TB/s) -- the time they would take on their own rooflines */
-int omp_prof_read_roofline(int cls, double* bytes, double* roofline_seconds);
-int omp_debug_force_gemm_kernel(int which);
-/* development: device buffer uint64 [n_workgroups][8] that omp_debug_force_gemm_kernel(15) fills with s_memtime stamps
- * per workgroup: 0 start, 1 first K tile landed, 2 K loop done, 3 accumulators in LDS, 4 stores retired, 5 XCC id */
-int omp_debug_set_gemm_trace(void* buffer, int64_t n_workgroups);
-int omp_debug_swin_attn_impl(int which); /* 0 = matrix-core kernel (default), 1 = scalar cross-check kernel, 2 = matrix cores with per-score table lookups */
-int omp_debug_self_attn_impl(int which); /* 0 auto, 1 = one wave per (row, head), 2 = one wave per row (all 8 heads) */
-int omp_debug_cross_nt(int on);          /* 1 = non-temporal K / V^T loads in the 1-query-tile cross-attention kernel */
-int omp_debug_cross_q4(int on);          /* 1 = LDS-ring cross-attention for 33..64 rows/image in 64-key chunks, non-temporal DMA (default), 2 = one 32-key block per step, 4 = chunks with temporal loads, 0 = register-streaming kernel */
-
-/* Single teacher-forced step that also leaves logits in plan->logits (parity tests). */
-int omp_decoder_step_logits(const omp_decoder_plan* plan, int pos, omp_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@ from oracle import weights
 
 DEV = 'cuda'
 DTYPES = {'fp32': torch.float32, 'bf16': torch.bfloat16}
+ENGINES = dict(DTYPES, bf16x3='bf16x3')   # engine precisions of the end-to-end checks; bf16x3 is held to the fp32 gates
 
 
 def rec(name, err, tol, note=''):
@@ -600,7 +601,7 @@ def _first_div(a, b):
 
 
 def _check_e2e(name, dtype_name, graph):
-    dt = DTYPES[dtype_name]
+    dt = ENGINES[dtype_name]
     gold = golden(name)
     case = gold['case']
     args, sd, img, mask, seqs = G.case_inputs(case)
@@ -625,7 +626,7 @@ def _check_e2e(name, dtype_name, graph):
 
 def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
     """One image of an engine call against the reference outputs recorded for it."""
-    f32 = dtype_name == 'fp32'
+    f32 = dtype_name in ('fp32', 'bf16x3')   # the parity engine answers to the fp32 gates (north_star: 1e-3 on logits, ids identical)
     out = []
     fs, ss = gold.get('feat_stride', (8, 3, 3)), gold.get('src_stride', (16, 2, 2))
     for i, ((f, h, w), shp, smp) in enumerate(zip(e['feats'], gold['feat_shapes'], gold['feat_sample'])):
@@ -709,7 +710,7 @@ def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
 
 def check_batch_equivalence(dtype_name='fp32', graph=False):
     """B images decoded together == each decoded alone (new capability vs the reference's B == 1)."""
-    dt = DTYPES[dtype_name]
+    dt = ENGINES[dtype_name]
     args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=10)
     depths = (2, 2, 2, 2)
     sd = weights.make_state_dict(args, seed=4, depths=depths)
@@ -746,7 +747,7 @@ def check_batch_equivalence(dtype_name='fp32', graph=False):
     # the number of rows in flight, so summation order (not the math) differs -> near-tie flips allowed.
     frac = same / max(1, tot)
     REPORT.append(dict(name='batch_equivalence[%s,graph=%s]' % (dtype_name, graph), match=frac, tokens=tot))
-    return [rec('batch_equivalence[%s,graph=%s]' % (dtype_name, graph), 1.0 - frac, 0.0 if dtype_name == 'fp32' else 0.05,
+    return [rec('batch_equivalence[%s,graph=%s]' % (dtype_name, graph), 1.0 - frac, 0.0 if dtype_name in ('fp32', 'bf16x3') else 0.05,
                 'token agreement %.3f' % frac)]
 
 
@@ -868,5 +869,104 @@ def check_masked_stream():
     return [rec('masked stream gemm', maxerr(y, ref.float().cpu()), 0.0), rec('masked stream CUs used (<= 64)', max(0, cus - 64), 0, '%d distinct (xcc, se/sh/cu)' % cus)]
 
 
+def _split_ref(x):
+    hi = x.to(torch.bfloat16).float()
+    return hi, (x - hi).to(torch.bfloat16).float()
+
+
+def _unsplit(y, C):
+    y = y.float().cpu()
+    return y[:, :C] + y[:, C:2 * C]
+
+
+def check_split_ops():
+    """Producers of split-bf16 pair rows (OMP_BF16X2, the operand format of the bf16x3 products): bit-exact hi / lo planes."""
+    out = []
+    x = rnd(333, 512, seed=5) * 3
+    hi, lo = _split_ref(x)
+    y = ops.split_bf16(x.to(DEV)).float().cpu()
+    out.append(rec('split_bf16 [hi|lo]', max(maxerr(y[:, :512], hi), maxerr(y[:, 512:], lo)), 0.0))
+    y3 = ops.split_bf16(x.to(DEV), triple=True).float().cpu()
+    out.append(rec('split_bf16 [hi|hi|lo]', max(maxerr(y3[:, :512], hi), maxerr(y3[:, 512:1024], hi), maxerr(y3[:, 1024:], lo)), 0.0))
+    w3 = ops.split_weight3(x).float()
+    out.append(rec('split_weight3', max(maxerr(w3[:, :512], hi), maxerr(w3[:, 512:1024], hi), maxerr(w3[:, 1024:], lo)), 0.0))
+    for rows, C in ((1000, 128), (77, 512), (19, 2048)):
+        xx = rnd(rows, C, seed=C) * 2 + 0.3
+        g, b = rnd(C, seed=1) * 0.1 + 1, rnd(C, seed=2) * 0.1
+        ref = F.layer_norm(xx, (C,), g, b, 1e-5)
+        yf = torch.empty(rows, C, device=DEV)
+        ys = ops.layernorm(xx.to(DEV), g.to(DEV), b.to(DEV), out_dtype=ops.SPLIT, out_f32=yf)
+        h2, l2 = _split_ref(yf.cpu())
+        out.append(rec('layernorm[f32->split,%dx%d] planes vs own fp32 copy' % (rows, C), max(maxerr(ys[:, :C], h2), maxerr(ys[:, C:], l2)), 0.0))
+        out.append(rec('layernorm[f32->split,%dx%d] vs reference' % (rows, C), maxerr(_unsplit(ys, C), ref), 6e-5))
+    # PatchMerging gather + LN: fp32 stream in, split pairs / bf16 out
+    B, H, W, C = 2, 9, 12, 128
+    xx = rnd(B, H, W, C, seed=11)
+    sd = {'n.weight': rnd(4 * C, seed=1) * 0.1 + 1, 'n.bias': rnd(4 * C, seed=2) * 0.1}
+    xp = F.pad(xx, (0, 0, 0, W % 2, 0, H % 2))
+    cat = torch.cat([xp[:, 0::2, 0::2], xp[:, 1::2, 0::2], xp[:, 0::2, 1::2], xp[:, 1::2, 1::2]], -1).reshape(-1, 4 * C)
+    ref = F.layer_norm(cat, (4 * C,), sd['n.weight'], sd['n.bias'], 1e-5)
+    ys, _, _ = ops.patch_merge_gather_ln(xx.reshape(-1, C).to(DEV), sd['n.weight'].to(DEV), sd['n.bias'].to(DEV), B, H, W, C, out_dtype=ops.SPLIT)
+    out.append(rec('patch_merge_gather_ln[f32->split]', maxerr(_unsplit(ys, 4 * C), ref), 6e-5))
+    yb, _, _ = ops.patch_merge_gather_ln(xx.reshape(-1, C).to(DEV), sd['n.weight'].to(DEV), sd['n.bias'].to(DEV), B, H, W, C, out_dtype=torch.bfloat16)
+    out.append(rec('patch_merge_gather_ln[f32->bf16]', maxerr(yb, ref), 4e-2))
+    return out
+
+
+def check_gemm_x3():
+    """bf16x3 products (omp_gemm_args.a_wrap): split-pair A x [hi|hi|lo] weight image on the bf16 matrix cores against an fp64
+    product of the ORIGINAL fp32 operands -- every kernel that can serve the engine, fp32 / split / residual / GELU epilogues."""
+    out = []
+    shapes = [(300, 384, 128), (1000, 512, 2048), (12, 1536, 512), (70, 1104, 512), (513, 1128, 512), (2049, 256, 1024),
+              (777, 1536, 512), (70000, 768, 256), (40000, 256, 256)]
+    for which in (0, 3, 5, 6, 9):
+        ops.force_gemm_kernel(which)
+        for (M, N, K) in shapes:
+            if which == 3 and M > 600:
+                continue
+            if which in (5, 6) and M > 3000:
+                continue
+            A, W = rnd(M, K, seed=M), rnd(N, K, seed=N + 1) / math.sqrt(K)
+            bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+            As, W3 = ops.split_bf16(A.to(DEV)), ops.split_weight3(W.to(DEV))
+            ref = (A.double() @ W.double().t() + bias.double())
+            tag = 'gemm_x3[k%d,%dx%dx%d]' % (which, M, N, K)
+            # three bf16 products of 16-bit-mantissa operands: relative operand error 2^-17 each, random signs
+            tol = 4e-5 * max(1.0, ref.abs().max().item())
+            y = ops.gemm(As, W3, bias.to(DEV), out_dtype=torch.float32, a_wrap=2 * K)
+            out.append(rec(tag + ' fp32 out', (y.double().cpu() - ref).abs().max().item(), tol))
+            y = ops.gemm(As, W3, bias.to(DEV), residual=res.to(DEV), out_dtype=torch.float32, a_wrap=2 * K)
+            out.append(rec(tag + ' fp32 out + residual', (y.double().cpu() - ref - res.double()).abs().max().item(), tol))
+            ys = ops.gemm(As, W3, bias.to(DEV), act=ops.ACT_GELU, out_dtype=ops.SPLIT, a_wrap=2 * K)
+            out.append(rec(tag + ' GELU, split out', (_unsplit(ys, N).double() - F.gelu(ref)).abs().max().item(), 2 * tol))
+    ops.force_gemm_kernel(0)
+    # bf16 operands with an fp32 destination + fp32 residual through the 256x256 kernel (fp32 residual stream of the bf16 engine)
+    M, N, K = 70000, 512, 512
+    A, W = q(rnd(M, K, seed=1), torch.bfloat16), q(rnd(N, K, seed=2) / math.sqrt(K), torch.bfloat16)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = A.double() @ W.double().t() + bias.double() + res.double()
+    for which in (0, 5, 9):
+        ops.force_gemm_kernel(which)
+        y = ops.gemm(A.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16), bias.to(DEV), residual=res.to(DEV), out_dtype=torch.float32)
+        out.append(rec('gemm[bf16 -> f32 + f32 residual,k%d]' % which, (y.double().cpu() - ref).abs().max().item(), 2e-4))
+    ops.force_gemm_kernel(0)
+    return out
+
+
+def check_window_attn_split():
+    """fp32 window attention writing split pairs == its own fp32 output split (the proj GEMM's bf16x3 operand)."""
+    out = []
+    B, H, W, C, nH = 2, 17, 20, 128, 4
+    qkv = rnd(B * H * W, 3 * C, seed=21).to(DEV)
+    qb, table = rnd(3 * C, seed=22).to(DEV), (rnd(169, nH, seed=23) * 0.2).to(DEV)
+    be = ops.swin_expand_bias(table)
+    for shift in (0, 3):
+        ref = ops.swin_window_attn(qkv, qb, table, B, H, W, C, nH, shift, bias_expanded=be).cpu()
+        ys = ops.swin_window_attn(qkv, qb, table, B, H, W, C, nH, shift, bias_expanded=be, out_split=True)
+        hi, lo = _split_ref(ref)
+        out.append(rec('window_attn[f32->split,shift %d]' % shift, max(maxerr(ys[:, :C], hi), maxerr(ys[:, C:], lo)), 0.0))
+    return out
+
+
 ALL_OP_CHECKS = [check_layernorm, check_gemm, check_mlp_fused, check_self_attn, check_gemm_small, check_patch_embed, check_window_attn, check_patch_merge, check_fpn,
-                 check_posembed, check_sampling, check_cross_attn]
+                 check_posembed, check_sampling, check_cross_attn, check_split_ops, check_gemm_x3, check_window_attn_split]

@@ -24,6 +24,17 @@ def test_golden_fp32(C, name):
     _assert_all(C.check_e2e(name, 'fp32'))
 
 
+@pytest.mark.parametrize('name', ['spot_odd', 'spot_224', 'kie_sroie', 'postnorm_nofpn', 'spot_1024', 'spot_640', 'kie_960x1280', 'spot_padded'])
+def test_parity_engine_bf16x3(C, name):
+    """The PARITY engine (fp32 storage, large products as three bf16 products of split operands on the bf16 matrix cores,
+    model/backbone.py) is held to the fp32 gates on every fixture: memory / logits within 1e-3, decoded ids identical."""
+    _assert_all(C.check_e2e(name, 'bf16x3'))
+
+
+def test_parity_engine_bf16x3_graph(C):
+    _assert_all(C.check_e2e('spot_1024', 'bf16x3', graph=True))
+
+
 @pytest.mark.parametrize('name', ['spot_odd', 'spot_224'])
 def test_golden_bf16(C, name):
     """bf16 engine (the benchmarked precision): relative-error gates on every intermediate and on the teacher-forced
@@ -50,7 +61,7 @@ def test_config2_shape_graph_lanes_bf16(C):
     _assert_all(C.check_e2e('spot_1024', 'bf16', graph=True))
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'bf16x3'])
 def test_batch_equals_single(C, dtype):
     _assert_all(C.check_batch_equivalence(dtype))
 
