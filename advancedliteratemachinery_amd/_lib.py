@@ -67,6 +67,8 @@ _SIGS = {
     'omp_gemm_bias_act': (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
     'omp_swin_mlp_fused': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                    c_int, c_int, c_void_p]),
+    'omp_swin_mlp_fused2': (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                    c_int, c_int, c_void_p]),
     'omp_debug_swin_mlp_variant': (c_int, [c_int]),
     'omp_debug_swin_mlp_trace': (c_int, [c_void_p]),
     'omp_patch_embed_ln': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float, c_void_p]),

@@ -22,19 +22,25 @@
 //     so the hidden activations never leave registers -- no LDS round trip, no barrier between the two products;
 //   * epilogue: + fc2 bias + residual (re-read from x, an L2 hit), 8-byte stores (a lane owns 4 consecutive
 //     features of one row).
-// The fp32 engine (the parity gate) keeps the unfused path; this kernel is bf16-only.
+// The fp32 engine (the parity gate) keeps the unfused path; the matrix-core operands of this kernel are bf16.
+// TX = type of the residual stream x / y: bf16, or float (round 3: the bf16 engine carries its residual stream in fp32 so
+// that 24 blocks of residual adds do not each round to 8 mantissa bits; the rows are then loaded as fp32, normalised with
+// exact two-pass statistics in registers and only the normalised values are rounded to bf16 fragments).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
 
 struct MlpP {
-  const bf16_t* X; int64_t ldx;
+  const void* X; int64_t ldx;
   const float* ln_g; const float* ln_b; float eps;
   const char* Wp;      // packed sub-chunks, C*128 + 1024 bytes each
   const float* b2;
-  bf16_t* Y; int64_t ldy;
+  void* Y; int64_t ldy;
   int64_t M; int nsub;
   unsigned long long* trace;   // development (TRACE instantiation): [workgroup][8] cycle sums of wave 0
+  int x_f32;                   // X / Y are fp32 rows (fp32 residual stream of the bf16 engine)
 };
 
 template <int N>
@@ -43,8 +49,11 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // WPS = waves per SIMD the register allocation is held to (VGPR + AGPR <= 512 / WPS)
-template <int C, int RG, int NW, int NS, int WPS, bool TRACE = false>
+template <typename TX, int C, int RG, int NW, int NS, int WPS, bool TRACE = false>
 __global__ __launch_bounds__(64 * NW, WPS) void mlp_fused_kernel(MlpP p) {
+  constexpr bool XF32 = sizeof(TX) == 4;
+  const TX* X = reinterpret_cast<const TX*>(p.X);
+  TX* Y = reinterpret_cast<TX*>(p.Y);
   // TRACE: s_memtime sums per phase (0 whole, 1 rows + LayerNorm, 2 DMA wait + barrier, 3 first product, 4 GELU,
   // 5 second product, 6 epilogue); the stamps serialise the LDS queue, so the TOTAL is pessimistic, the split is the point
   unsigned long long tr[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -78,19 +87,19 @@ __global__ __launch_bounds__(64 * NW, WPS) void mlp_fused_kernel(MlpP p) {
 
   // ---- the rows: load, LayerNorm in registers, keep as B fragments -----------------------------------------------
   bf16x8 xf[RG][KS];
+  if constexpr (!XF32) {
 #pragma unroll
-  for (int rg = 0; rg < RG; ++rg) {
-    int64_t m = m0 + rg * 16 + li;
-    if (m > p.M - 1) m = p.M - 1;            // clamped rows are computed and never stored
-    const bf16_t* xr = p.X + m * p.ldx + lg * 8;
+    for (int rg = 0; rg < RG; ++rg) {
+      int64_t m = m0 + rg * 16 + li;
+      if (m > p.M - 1) m = p.M - 1;            // clamped rows are computed and never stored
+      const bf16_t* xr = X + m * p.ldx + lg * 8;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xf[rg][ks] = *reinterpret_cast<const bf16x8*>(xr + ks * 32);
-  }
-  // the first ring stages do not depend on the rows: request them now, under the LayerNorm arithmetic
+      for (int ks = 0; ks < KS; ++ks) xf[rg][ks] = *reinterpret_cast<const bf16x8*>(xr + ks * 32);
+    }
+    // the first ring stages do not depend on the rows: request them now, under the LayerNorm arithmetic
 #pragma unroll
-  for (int t = 0; t < NS - 1; ++t)
-    if (t < p.nsub) issue(t, t);
-  {
+    for (int t = 0; t < NS - 1; ++t)
+      if (t < p.nsub) issue(t, t);
     float mean[RG], rstd[RG];
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
@@ -124,6 +133,56 @@ __global__ __launch_bounds__(64 * NW, WPS) void mlp_fused_kernel(MlpP p) {
         for (int e = 0; e < 4; ++e) {
           o[e] = (bf16_t)(((float)xf[rg][ks][e] - mean[rg]) * rstd[rg] * g0[e] + b0[e]);
           o[e + 4] = (bf16_t)(((float)xf[rg][ks][e + 4] - mean[rg]) * rstd[rg] * g1[e] + b1[e]);
+        }
+        xf[rg][ks] = o;
+      }
+    }
+  } else {
+    // fp32 residual stream: one row group at a time (the fp32 values of a group live only until its fragments are made)
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+      if (t < p.nsub) issue(t, t);
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) {
+      int64_t m = m0 + rg * 16 + li;
+      if (m > p.M - 1) m = p.M - 1;
+      const float* xr = reinterpret_cast<const float*>(X) + m * p.ldx + lg * 8;
+      f32x4 v[KS][2];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        v[ks][0] = *reinterpret_cast<const f32x4*>(xr + ks * 32);
+        v[ks][1] = *reinterpret_cast<const f32x4*>(xr + ks * 32 + 4);
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += v[ks][0][e] + v[ks][1][e];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const float mean = s / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d0 = v[ks][0][e] - mean, d1 = v[ks][1][e] - mean;
+          q += d0 * d0 + d1 * d1;
+        }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const float rstd = 1.0f / sqrtf(q / (float)C + p.eps);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_g + ks * 32 + lg * 8);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.ln_g + ks * 32 + lg * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_b + ks * 32 + lg * 8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.ln_b + ks * 32 + lg * 8 + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (bf16_t)((v[ks][0][e] - mean) * rstd * g0[e] + b0[e]);
+          o[e + 4] = (bf16_t)((v[ks][1][e] - mean) * rstd * g1[e] + b1[e]);
         }
         xf[rg][ks] = o;
       }
@@ -213,24 +272,25 @@ __global__ __launch_bounds__(64 * NW, WPS) void mlp_fused_kernel(MlpP p) {
   for (int rg = 0; rg < RG; ++rg) {
     const int64_t m = m0 + rg * 16 + li;
     if (m < p.M) {
-      const bf16_t* xr = p.X + m * p.ldx + lg * 4;
-      bf16_t* yr = p.Y + m * p.ldy + lg * 4;
+      const TX* xr = X + m * p.ldx + lg * 4;
+      TX* yr = Y + m * p.ldy + lg * 4;
       constexpr int EG = 4;   // feature tiles per batch of residual loads (bounds the live registers)
+      typedef typename std::conditional<XF32, f32x4, bf16x4>::type xv4;
 #pragma unroll
       for (int n0 = 0; n0 < NT; n0 += EG) {
-        bf16x4 res[EG];
+        xv4 res[EG];
         f32x4 bo[EG];
 #pragma unroll
         for (int u = 0; u < EG; ++u) {
-          res[u] = *reinterpret_cast<const bf16x4*>(xr + (n0 + u) * 16);
+          res[u] = *reinterpret_cast<const xv4*>(xr + (n0 + u) * 16);
           bo[u] = *reinterpret_cast<const f32x4*>(p.b2 + (n0 + u) * 16 + lg * 4);
         }
 #pragma unroll
         for (int u = 0; u < EG; ++u) {
-          bf16x4 o;
+          xv4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc2[n0 + u][rg][e] + bo[u][e] + (float)res[u][e]);
-          *reinterpret_cast<bf16x4*>(yr + (n0 + u) * 16) = o;
+          for (int e = 0; e < 4; ++e) o[e] = (TX)(acc2[n0 + u][rg][e] + bo[u][e] + (float)res[u][e]);
+          *reinterpret_cast<xv4*>(yr + (n0 + u) * 16) = o;
         }
       }
     }
@@ -245,10 +305,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void mlp_fused_kernel(MlpP p) {
   }
 }
 
-template <int C, int RG, int NW, int NS, int WPS, bool TRACE = false>
-int launch_mlp(const MlpP& p, hipStream_t st) {
+template <typename TX, int C, int RG, int NW, int NS, int WPS, bool TRACE = false>
+int launch_mlp_t(const MlpP& p, hipStream_t st) {
   constexpr size_t smem = (size_t)NS * (C * 128 + 1024);
-  auto kern = mlp_fused_kernel<C, RG, NW, NS, WPS, TRACE>;
+  auto kern = mlp_fused_kernel<TX, C, RG, NW, NS, WPS, TRACE>;
   static bool done = false;   // per template instantiation
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -261,6 +321,12 @@ int launch_mlp(const MlpP& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div64(p.M, rows_per_wg)), dim3(64 * NW), smem, st, p);
   OMP_CHECK_LAUNCH("omp_swin_mlp_fused");
   return OMP_OK;
+}
+
+template <int C, int RG, int NW, int NS, int WPS, bool TRACE = false>
+int launch_mlp(const MlpP& p, hipStream_t st) {
+  if (p.x_f32) return launch_mlp_t<float, C, RG, NW, NS, WPS, TRACE>(p, st);
+  return launch_mlp_t<bf16_t, C, RG, NW, NS, WPS, TRACE>(p, st);
 }
 
 int dispatch_mlp(const MlpP& p, int C, int v, hipStream_t st);
@@ -280,6 +346,13 @@ extern "C" int omp_debug_swin_mlp_trace(void* buffer) {
 extern "C" int omp_swin_mlp_fused(const void* x, int64_t ldx, const float* ln_gamma, const float* ln_beta, float eps,
                                   const void* wpack, const float* b2, void* y, int64_t ldy, int64_t M, int C, int hidden,
                                   omp_stream_t s) {
+  return omp_swin_mlp_fused2(x, OMP_BF16, ldx, ln_gamma, ln_beta, eps, wpack, b2, y, ldy, M, C, hidden, s);
+}
+
+extern "C" int omp_swin_mlp_fused2(const void* x, int x_dtype, int64_t ldx, const float* ln_gamma, const float* ln_beta, float eps,
+                                   const void* wpack, const float* b2, void* y, int64_t ldy, int64_t M, int C, int hidden,
+                                   omp_stream_t s) {
+  OMP_CHECK_ARG(x_dtype == OMP_BF16 || x_dtype == OMP_F32, "omp_swin_mlp_fused: x_dtype must be bf16 or f32");
   OMP_CHECK_ARG(x && ln_gamma && ln_beta && wpack && b2 && y, "omp_swin_mlp_fused: null pointer");
   OMP_CHECK_ARG(M > 0 && M < (1ll << 31), "omp_swin_mlp_fused: bad M=%lld", (long long)M);
   OMP_CHECK_ARG(hidden > 0 && hidden % 32 == 0, "omp_swin_mlp_fused: hidden=%d must be a multiple of 32", hidden);
@@ -288,14 +361,14 @@ extern "C" int omp_swin_mlp_fused(const void* x, int64_t ldx, const float* ln_ga
                     ((uintptr_t)ln_gamma % 16) == 0 && ((uintptr_t)ln_beta % 16) == 0,
                 "omp_swin_mlp_fused: pointers must be 16-byte aligned");
   MlpP p;
-  p.X = reinterpret_cast<const bf16_t*>(x); p.ldx = ldx;
+  p.X = x; p.ldx = ldx; p.x_f32 = x_dtype == OMP_F32 ? 1 : 0;
   p.ln_g = ln_gamma; p.ln_b = ln_beta; p.eps = eps;
   p.Wp = reinterpret_cast<const char*>(wpack); p.b2 = b2;
-  p.Y = reinterpret_cast<bf16_t*>(y); p.ldy = ldy;
+  p.Y = y; p.ldy = ldy;
   p.M = M; p.nsub = hidden / 32; p.trace = omp_cur().mlp_trace;
   hipStream_t st = (hipStream_t)s;
   const int v = omp_cur().mlp_variant;
-  const int slot = omp_prof_active(OMP_PROF_MLP) ? omp_prof_begin(OMP_PROF_MLP, st, 4.0 * (double)M * C * hidden, 4.0 * (double)M * C + (double)(hidden / 32) * (C * 128 + 1024)) : -1;
+  const int slot = omp_prof_active(OMP_PROF_MLP) ? omp_prof_begin(OMP_PROF_MLP, st, 4.0 * (double)M * C * hidden, (x_dtype == OMP_F32 ? 8.0 : 4.0) * (double)M * C + (double)(hidden / 32) * (C * 128 + 1024)) : -1;
   const int rc = dispatch_mlp(p, C, v, st);
   if (slot >= 0) omp_prof_end(OMP_PROF_MLP, slot, st);
   return rc;

@@ -97,15 +97,16 @@ def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
 
 
 def swin_mlp_fused(x, ln_g, ln_b, wpack, b2, out=None, eps=1e-5):
-    """x [M, C] bf16 -> x + fc2(GELU(fc1(LN(x)))) in one launch; wpack from model.packing.pack_mlp.  out may be x."""
+    """x [M, C] bf16 or fp32 (fp32 residual stream) -> x + fc2(GELU(fc1(LN(x)))) in one launch, same type; wpack from
+    model.packing.pack_mlp (bf16 matrix-core operands either way).  out may be x."""
     _c(x, 'x')
-    if x.dtype != torch.bfloat16:
-        raise TypeError('swin_mlp_fused is the bf16 engine path')
+    if x.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError('swin_mlp_fused takes a bf16 or fp32 residual stream')
     M, C = x.numel() // x.shape[-1], x.shape[-1]
     if out is None:
         out = torch.empty_like(x)
-    rc = _lib.lib().omp_swin_mlp_fused(ptr(x), C, ptr(ln_g), ptr(ln_b), float(eps), ptr(wpack), ptr(b2), ptr(out), C, M, C,
-                                       wpack.shape[0] * 32, stream())
+    rc = _lib.lib().omp_swin_mlp_fused2(ptr(x), dt(x), C, ptr(ln_g), ptr(ln_b), float(eps), ptr(wpack), ptr(b2), ptr(out), C, M, C,
+                                        wpack.shape[0] * 32, stream())
     _lib.check(rc, 'omp_swin_mlp_fused')
     return out
 

@@ -127,6 +127,11 @@ int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s);
 int omp_swin_mlp_fused(const void* x, int64_t ldx, const float* ln_gamma, const float* ln_beta, float eps,
                        const void* wpack, const float* b2, void* y, int64_t ldy, int64_t M, int C, int hidden,
                        omp_stream_t s);
+/* the same with x / y of type x_dtype: OMP_BF16, or OMP_F32 = the fp32 residual stream of the bf16 engine (the products
+ * still run on bf16 operands: LayerNorm(x) and the hidden activations are rounded to bf16, x itself never is) */
+int omp_swin_mlp_fused2(const void* x, int x_dtype, int64_t ldx, const float* ln_gamma, const float* ln_beta, float eps,
+                        const void* wpack, const float* b2, void* y, int64_t ldy, int64_t M, int C, int hidden,
+                        omp_stream_t s);
 
 /* ---- Swin patch embedding: zero-pad to x4, 4x4/4 conv (as K=48 dot products), LayerNorm -----
  * Replaces PatchEmbed.forward, swin_transformer.py:427-443.  img is NCHW fp32 (as the reference

@@ -219,7 +219,7 @@ def check_two_stage():
     from advancedliteratemachinery_amd.engine.two_stage import spot_and_recognize
     from advancedliteratemachinery_amd.utils.parser import make_args
     from oracle import two_stage_ref as T
-    from oracle import weights
+    from advancedliteratemachinery_amd.utils import synthetic as weights
     from tests.gpu_checks import build_model
     depths = (2, 2, 2, 2)
     args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=6, test_min_size=64, test_max_size=112)

@@ -28,7 +28,8 @@ def main():
     sc = sys.argv[1]
     from advancedliteratemachinery_amd.engine.pipeline import LanePool
     from advancedliteratemachinery_amd.utils.parser import make_args
-    from oracle import omniparser_ref as O, weights
+    from oracle import omniparser_ref as O
+    from advancedliteratemachinery_amd.utils import synthetic as weights
     args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=8)
     depths = (2, 2, 2, 2)
     sd = weights.make_state_dict(args, seed=6, depths=depths)
