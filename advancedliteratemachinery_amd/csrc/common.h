@@ -68,6 +68,7 @@ struct omp_ctx {
   int cross_q4 = 1;          // 1 = LDS-ring kernel for 33..64 rows per image, 64-key chunks, non-temporal DMA; 2 = one block per step; 4 = chunks, temporal; 0 = register streaming
   int cross_nt = 1;          // non-temporal K / V^T loads once >= 32 images share a launch
   int self_attn_impl = 0;    // 0 auto, 1 one wave per (row, head), 2 one wave per row
+  int dec_fused = 0;         // 0 = fused few-row decoder kernels where they apply (csrc/decoder.hip: fused_step_ok), 1 = the launch-per-op path everywhere
   int swin_impl = 0;         // 0 matrix cores, 1 scalar cross-check kernel, 2 matrix cores with per-score table lookups
   int mlp_variant = 0;       // alternative instantiations of the fused MLP; 100 = traced default
   unsigned long long* gemm_trace = nullptr;   // device buffers of the TRACE instantiations

@@ -11,6 +11,8 @@
 //   * the 3-layer head runs on the newest position only.
 // All rows of a phase sit at the same sequence position, kept in device memory (*d_pos) so the
 // step is position-independent on the host side and can be replayed as a hipGraph.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.h"
@@ -262,6 +264,236 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 2) void dec_self_attn_row
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] *= inv;
   store8(out + (int64_t)r * d + lane * 8, o);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Few-row phases (the point decoder: one row per image): FUSED  LayerNorm1 -> q, k, v of ONE head -> cache append ->
+// causal self-attention.  A captured decoder step of an 8-image call was 44 launches of ~3.5-19 us each
+// (profiles/r03b_prof8_pt_step_timeline.txt): no kernel body there is bound by anything but its own dependent memory round
+// trips plus the ~3.5 us a dependent launch costs in a graph.  Self-attention needs q, k, v of ONE head only, so the
+// all-to-all boundary between the QKV projection and the attention disappears once a workgroup owns (row tile, head):
+//   * grid = (ceil(R / 4), heads), 4 waves; the head's 192 weight rows (q | k | v: 192 KB bf16, L2 / MALL resident) are
+//     requested FIRST, all 48 sixteen-byte fragments per lane in flight, before anything that depends on the rows;
+//   * wave w normalises row 4 * tile + w (two-pass fp32 statistics; EMBED: LN(word[token] + position) first -- layer 0 --
+//     written to the residual stream by the head-0 workgroups) into LDS as the bf16 B operand;
+//   * D[feature][row] on the matrix cores (4 of 16 columns live), + per-position bias table, rounded to bf16 exactly where
+//     the unfused path stores qkv, into LDS;
+//   * wave w then attends row w: lane = (key slot js = l >> 3, 8-dim chunk dc = l & 7), 64 keys per chunk with all of a
+//     chunk's 16 loads per lane issued at once and three chunks in flight (192 cache positions per memory round trip), ONE
+//     running-max update per chunk (two-phase: all scores of the chunk, then the exponentials).
+// Replaces omp_dec_embed_ln (layer 0) + gemm_small<LN> + dec_self_attn_kernel: 3 launches of 8.5 + 19.3 us -> one of 10.7 us
+// per layer (8 rows, 135 positions; profiles/r03d_prof8_pt_step_timeline.txt).
+// ---------------------------------------------------------------------------------------------
+struct FusedSaP {
+  const float* x;                 // [R, 512] fp32 residual stream (EMBED: produced here)
+  const float* ln_g; const float* ln_b; float eps;
+  const bf16_t* W;                // self_attn.in_proj_weight [1536, 512]
+  const float* bias_tab;          // [Pmax, 1536] in_proj_bias + position term of q and k
+  bf16_t* kc; bf16_t* vc;         // [R, Lmax, 512]
+  bf16_t* out;                    // [R, 512]
+  const int32_t* d_pos;
+  int R, Lmax;
+  const int32_t* seq; int seq_ld; const float* word; const float* pos_tab; const float* emb_g; const float* emb_b;
+  float* x_out;                   // EMBED: the embedded rows (fp32 residual stream)
+};
+
+// two-pass LayerNorm of one 512-wide row held 8 values per lane
+__device__ __forceinline__ void ln512(float* v, const float* g, const float* b, int lane, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v[i];
+  s = wave_sum(s);
+  const float mean = s * (1.0f / 512.0f);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; q += d * d; }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / 512.0f) + eps);
+  const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + lane * 8), g1 = *reinterpret_cast<const f32x4*>(g + lane * 8 + 4);
+  const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + lane * 8), b1 = *reinterpret_cast<const f32x4*>(b + lane * 8 + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = (v[i] - mean) * rstd * g0[i] + b0[i];
+    v[i + 4] = (v[i + 4] - mean) * rstd * g1[i] + b1[i];
+  }
+}
+
+// RT = rows per workgroup (a multiple of 4: RT / 4 rows per wave, one after the other).  Only RT = 4 is built: 16 rows per
+// workgroup for the 512-row polygon / recognition phases measured 20-22 us against 25 us for the three launches it replaces
+// and slowed the two concurrent decoder streams down (19.4 -> 29.6 ms per 8-image call, profiles/r03d_*).
+template <bool EMBED, int RT>
+__global__ __launch_bounds__(256) void dec_fused_self_attn_kernel(FusedSaP p) {
+  constexpr int D = 512, XP = D + 8;   // row pitch of the LDS image (+16 B: spreads the fragment reads over the banks)
+  constexpr int RPW = RT / 4;          // rows per wave
+  __shared__ __attribute__((aligned(16))) bf16_t xs[RT][XP];
+  __shared__ __attribute__((aligned(16))) float qkv_s[RT][192];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, r0 = blockIdx.x * RT;
+  const int pos = *p.d_pos;
+
+  // ---- the head's weight rows: independent of the rows, so all of it is requested before anything else ----------------
+  bf16x8 wf[3][16];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int f0 = wave * 48 + t * 16;                       // first of 16 local features (q 0..63 | k 64..127 | v 128..191)
+    const bf16_t* wp = p.W + (int64_t)((f0 >> 6) * D + h * DH + (f0 & 63) + li) * D + g * 8;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) wf[t][s_] = ld16<bf16_t>(wp + s_ * 32);
+  }
+
+  // ---- this wave's rows: (embedding +) LayerNorm -> bf16 B operand in LDS ---------------------------------------------------
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const int lr = wave * RPW + u, r = r0 + lr;
+    const bool live = r < p.R;
+    const int rr = live ? r : p.R - 1;
+    float v[8];
+    if constexpr (EMBED) {
+      const int tok = p.seq[(int64_t)rr * p.seq_ld + pos];
+      const float* we = p.word + (int64_t)tok * D + lane * 8;
+      const float* pe = p.pos_tab + (int64_t)pos * D + lane * 8;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(we), a1 = *reinterpret_cast<const f32x4*>(we + 4);
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(pe), c1 = *reinterpret_cast<const f32x4*>(pe + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = a0[i] + c0[i]; v[i + 4] = a1[i] + c1[i]; }
+      ln512(v, p.emb_g, p.emb_b, lane, p.eps);
+      if (h == 0 && live) store8(p.x_out + (int64_t)r * D + lane * 8, v);
+    } else {
+      load8(p.x + (int64_t)rr * D + lane * 8, v);
+    }
+    ln512(v, p.ln_g, p.ln_b, lane, p.eps);
+    store8(&xs[lr][lane * 8], v);
+  }
+  __syncthreads();
+
+  // ---- q | k | v of head h: D[feature][row], 3 feature tiles per wave, K = 512 ------------------------------------------
+  f32x4 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+#pragma unroll
+  for (int s_ = 0; s_ < 16; ++s_) {
+    const bf16x8 xb = li < RT ? *reinterpret_cast<const bf16x8*>(&xs[li < RT ? li : 0][s_ * 32 + g * 8]) : zero8;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s_], xb, acc[t], 0, 0, 0);
+  }
+  if (li < RT) {
+    const float* bt = p.bias_tab + (int64_t)pos * (3 * D);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int f = wave * 48 + t * 16 + g * 4;              // acc[t][e] <-> local feature f + e of row li
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bt + (f >> 6) * D + h * DH + (f & 63));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qkv_s[li][f + e] = (float)(bf16_t)(acc[t][e] + bb[e]);   // rounded where the unfused path stores qkv
+    }
+  }
+  __syncthreads();
+
+  // ---- causal self-attention of this wave's rows, head h, over cache positions 0 .. pos (no barrier below) ---------------------
+  const int js = lane >> 3, dc = lane & 7;
+#pragma unroll 1
+  for (int u_ = 0; u_ < RPW; ++u_) {
+    const int lr = wave * RPW + u_, r = r0 + lr;
+    if (r >= p.R) break;   // wave-uniform
+    float q[8], kn[8], vn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      q[i] = qkv_s[lr][dc * 8 + i] * (0.125f * 1.4426950408889634f);   // 1/sqrt(64) on q like nn.MultiheadAttention; base-2 softmax
+      kn[i] = qkv_s[lr][64 + dc * 8 + i];
+      vn[i] = qkv_s[lr][128 + dc * 8 + i];
+    }
+    bf16_t* kbase = p.kc + (int64_t)r * p.Lmax * D + h * DH + dc * 8;
+    bf16_t* vbase = p.vc + (int64_t)r * p.Lmax * D + h * DH + dc * 8;
+    if (js == 0) {
+      store8(kbase + (int64_t)pos * D, kn);
+      store8(vbase + (int64_t)pos * D, vn);
+    }
+    constexpr int PF = 3;                       // 64-key chunks in flight
+    bf16x8 kr[PF][8], vr[PF][8];
+    const int nch = (pos >> 6) + 1;             // keys 0 .. pos
+    auto load_chunk = [&](int c, bf16x8* kq, bf16x8* vq) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = c * 64 + u * 8 + js;
+        if (j < pos) {
+          kq[u] = ld16<bf16_t>(kbase + (int64_t)j * D);
+          vq[u] = ld16<bf16_t>(vbase + (int64_t)j * D);
+        }
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (u < nch) load_chunk(u, kr[u], vr[u]);
+    float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    auto compute = [&](int c, const bf16x8* kq, const bf16x8* vq) {
+      float sc[8];
+      float cm = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = c * 64 + u * 8 + js;
+        float kk[8];
+        if (j < pos) unpack16(kq[u], kk);
+        else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) kk[i] = kn[i];
+        }
+        float sd = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sd = fmaf(q[i], kk[i], sd);
+        sd += __shfl_xor(sd, 1, 64);
+        sd += __shfl_xor(sd, 2, 64);
+        sd += __shfl_xor(sd, 4, 64);
+        sc[u] = j <= pos ? sd : -INFINITY;
+        cm = fmaxf(cm, sc[u]);
+      }
+      cm = fmaxf(cm, __shfl_xor(cm, 8, 64));
+      cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+      cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+      const float mn = fmaxf(m, cm);            // finite: key c * 64 (js = 0, u = 0) is always <= pos
+      const float a = __builtin_amdgcn_exp2f(m - mn);
+      l *= a;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] *= a;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = c * 64 + u * 8 + js;
+        const float pj = __builtin_amdgcn_exp2f(sc[u] - mn);   // exp2(-inf) = 0 beyond the current position
+        float vv[8];
+        if (j < pos) unpack16(vq[u], vv);
+        else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) vv[i] = vn[i];
+        }
+        l += pj;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = fmaf(pj, vv[i], o[i]);
+      }
+      m = mn;
+    };
+    for (int c0 = 0; c0 < nch; c0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int c = c0 + u;
+        if (c < nch) {
+          compute(c, kr[u], vr[u]);
+          if (c + PF < nch) load_chunk(c + PF, kr[u], vr[u]);
+        }
+      }
+    }
+    // the 8 key slots (lanes differing in bits 3..5) share m; their partial sums and outputs add
+    l += __shfl_xor(l, 8, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float t = o[i];
+      t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+      o[i] = t * inv;
+    }
+    if (js == 0) store8(p.out + (int64_t)r * D + h * DH + dc * 8, o);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -775,6 +1007,65 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(const float* __restrict
 
 __global__ void advance_pos_kernel(int32_t* d_pos) { *d_pos += 1; }
 
+// The same sampling with a WORKGROUP per row (4 waves x <= 5 logits per lane instead of one wave x 18: the wave-per-row kernel
+// took 10.5 us of a point-decoder step) and the position advance folded in: every workgroup has read *d_pos before it
+// takes a ticket, so the last ticket holder may publish pos + 1 for the next launch (no advance_pos launch): 5.3 us for both.
+__global__ __launch_bounds__(256) void dec_sample_block_kernel(const float* __restrict__ logits, int ld, int R, omp_sample_cfg c,
+                                                               int32_t* __restrict__ seq, float* __restrict__ probs, int seq_ld,
+                                                               int32_t* __restrict__ finished, int32_t* __restrict__ lengths,
+                                                               int32_t* d_pos, int32_t* ticket) {
+  __shared__ float s_f[8];
+  __shared__ int s_i[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = blockIdx.x;
+  const int p = *d_pos;
+  const int i = p + 1 - c.step0;
+  if (i >= 0) {
+    const bool slice = c.infer_vie && c.kind != OMP_DEC_PT;
+    const int Vs = c.vocab - (slice ? c.vie_categories : 0);
+    const float* lg = logits + (int64_t)r * ld;
+    float mx = -INFINITY, best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int t = tid; t < Vs; t += 256) {
+      const float v = lg[t];
+      mx = fmaxf(mx, v);
+      if (is_candidate(c, t, i) && v > best) { best = v; bi = t; }
+    }
+    mx = wave_max(mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { s_f[wave] = mx; s_f[4 + wave] = best; s_i[wave] = bi; }
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_f[0], s_f[1]), fmaxf(s_f[2], s_f[3]));
+    best = s_f[4]; bi = s_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (s_f[4 + w] > best || (s_f[4 + w] == best && s_i[w] < bi)) { best = s_f[4 + w]; bi = s_i[w]; }
+    float sum = 0.f;
+    for (int t = tid; t < Vs; t += 256) sum += expf(lg[t] - mx);
+    sum = wave_sum(sum);
+    __syncthreads();            // everybody has read s_f / s_i
+    if (lane == 0) s_f[wave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      sum = (s_f[0] + s_f[1]) + (s_f[2] + s_f[3]);
+      seq[(int64_t)r * seq_ld + p + 1] = bi;
+      probs[(int64_t)r * seq_ld + p + 1] = expf(best - mx) / sum;
+      if (c.kind == OMP_DEC_PT && finished != nullptr) {
+        if (!finished[r] && bi == c.pt_eos) { finished[r] = 1; lengths[r] = p + 1; }
+      }
+    }
+  }
+  if (ticket != nullptr && tid == 0) {
+    const int t = atomicAdd(ticket, 1);
+    if (t == (int)gridDim.x - 1) { *ticket = 0; *d_pos = p + 1; }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------------
@@ -989,11 +1280,41 @@ int ln_gemm(const omp_decoder_plan* P, const float* g, const float* b, const voi
   return gemm(P, P->y, d, W, d, N, bias, bias_row, bias_stride, nullptr, C, out_dtype, act, st);
 }
 
+// Few-row phases (the point decoder of a small engine call) take the fused kernel for the self-attention half of a layer,
+// with the embedding folded into layer 0 and the position advance into the sampling kernel: 44 -> 35 launches per step.
+// (The query projection inside the cross-attention kernel was built and measured too: every (image, head, key split)
+// workgroup repeating LayerNorm2 + 64 x 512 weights costs 26.4 us against 16.7 + 8.5 us for the two launches, also with the
+// projection operands requested ahead of the K / V^T prefetch -- profiles/r03d_prof8_pt_step_timeline.txt.  Removed.)
+int fused_sa_max_rows() {   // beyond: the workgroups' repeated weight streams (192 KB per 4 rows) cost more than the launches
+  static const int v = [] { const char* e = getenv("OMP355_FUSED_SA_MAX_ROWS"); return e ? atoi(e) : 63; }();
+  return v;
+}
+bool fused_step_ok(const omp_decoder_plan* P) {
+  return omp_cur().dec_fused != 1 && P->pre_norm && P->dtype == OMP_BF16 && P->d_model == 512 && P->n_heads == 8 && P->R <= fused_sa_max_rows();
+}
+
+int launch_fused_self_attn(const omp_decoder_plan* P, const omp_dec_layer& L, bool embed, hipStream_t st) {
+  FusedSaP fp;
+  fp.x = P->x; fp.ln_g = L.n1_g; fp.ln_b = L.n1_b; fp.eps = P->eps;
+  fp.W = reinterpret_cast<const bf16_t*>(L.sa_in_w); fp.bias_tab = L.sa_bias_tab;
+  fp.kc = reinterpret_cast<bf16_t*>(L.kcache); fp.vc = reinterpret_cast<bf16_t*>(L.vcache);
+  fp.out = reinterpret_cast<bf16_t*>(P->att); fp.d_pos = P->d_pos; fp.R = P->R; fp.Lmax = P->Lmax;
+  fp.seq = P->seq; fp.seq_ld = P->seq_ld; fp.word = P->word_emb; fp.pos_tab = P->pos_tab; fp.emb_g = P->emb_g; fp.emb_b = P->emb_b;
+  fp.x_out = P->x;
+  const dim3 grid((P->R + 3) / 4, P->n_heads);
+  if (embed) hipLaunchKernelGGL((dec_fused_self_attn_kernel<true, 4>), grid, dim3(256), 0, st, fp);
+  else hipLaunchKernelGGL((dec_fused_self_attn_kernel<false, 4>), grid, dim3(256), 0, st, fp);
+  OMP_CHECK_LAUNCH("omp_decoder_run(fused self-attention)");
+  return OMP_OK;
+}
+
 int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
   const int d = P->d_model, R = P->R, T = P->dtype;
-  // embedding: pre-norm needs only the fp32 stream; post-norm also the T copy
-  RUN(omp_dec_embed_ln(P->seq, P->seq_ld, P->d_pos, P->word_emb, P->pos_tab, P->emb_g, P->emb_b, P->x,
-                       P->pre_norm ? nullptr : P->y, T, R, d, P->eps, st));
+  const bool fused = fused_step_ok(P);
+  // embedding: pre-norm needs only the fp32 stream; post-norm also the T copy (fused: layer 0's first kernel embeds)
+  if (!fused)
+    RUN(omp_dec_embed_ln(P->seq, P->seq_ld, P->d_pos, P->word_emb, P->pos_tab, P->emb_g, P->emb_b, P->x,
+                         P->pre_norm ? nullptr : P->y, T, R, d, P->eps, st));
   CrossP cp;
   cp.q = P->q; cp.ldq = d; cp.img_stride = P->kv_img_stride; cp.Mpad = P->Mpad;
   cp.kmask = P->key_mask; cp.groups = P->tiles; cp.out = P->att; cp.ldo = d;
@@ -1002,8 +1323,12 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
     const omp_dec_layer& L = P->layers[li];
     cp.K = L.crossK; cp.V = L.crossVt;
     if (P->pre_norm) {
-      RUN(ln_gemm(P, L.n1_g, L.n1_b, L.sa_in_w, 3 * d, L.sa_bias_tab, P->d_pos, 3 * d, P->qkv, T, OMP_ACT_NONE, st));
-      RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, T, R, P->n_heads, d, P->Lmax, st));
+      if (fused) {
+        RUN(launch_fused_self_attn(P, L, li == 0, st));
+      } else {
+        RUN(ln_gemm(P, L.n1_g, L.n1_b, L.sa_in_w, 3 * d, L.sa_bias_tab, P->d_pos, 3 * d, P->qkv, T, OMP_ACT_NONE, st));
+        RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, T, R, P->n_heads, d, P->Lmax, st));
+      }
       RUN(gemm(P, P->att, d, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
       RUN(ln_gemm(P, L.n2_g, L.n2_b, L.ca_q_w, d, L.ca_qbias_tab, P->d_pos, d, P->q, T, OMP_ACT_NONE, st));
       RUN(launch_cross(cp, P->n_tiles, T, P->n_split, P->q_tiles, st));
@@ -1047,11 +1372,23 @@ int check_plan(const omp_decoder_plan* P) {
 }
 
 int sample_and_advance(const omp_decoder_plan* P, hipStream_t st) {
+  if (P->R <= 4096 && omp_cur().dec_fused != 1) {
+    // a workgroup per row; the last one to finish publishes the next position (P->d_pos[1] is the ticket word)
+    hipLaunchKernelGGL(dec_sample_block_kernel, dim3(P->R), dim3(256), 0, st, P->logits, P->vocab, P->R, P->sample, P->seq, P->probs,
+                       P->seq_ld, P->finished, P->lengths, P->d_pos, P->d_pos + 1);
+    OMP_CHECK_LAUNCH("omp_decoder_run(sample)");
+    return OMP_OK;
+  }
   return omp_head_softmax_mask_argmax(P->logits, P->vocab, P->R, &P->sample, P->seq, P->probs, P->seq_ld,
                                       P->finished, P->lengths, P->d_pos, 1, st);
 }
 
 }  // namespace
+
+extern "C" int omp_debug_dec_fused(int mode) {
+  omp_cur().dec_fused = mode == 1 ? 1 : 0;
+  return OMP_OK;
+}
 
 extern "C" int omp_debug_self_attn_impl(int which) {
   omp_cur().self_attn_impl = (which == 1 || which == 2) ? which : 0;

@@ -109,7 +109,7 @@ class _Phase(object):
         z = lambda *s, dtype=torch.int32: torch.zeros(s, dtype=dtype, device=dev)  # noqa: E731
         e = lambda *s, dtype=T: torch.empty(s, dtype=dtype, device=dev)             # noqa: E731
         self.seq, self.probs = z(R, seq_ld), z(R, seq_ld, dtype=torch.float32)
-        self.finished, self.lengths, self.d_pos = z(R), z(R), z(1)
+        self.finished, self.lengths, self.d_pos = z(R), z(R), z(2)   # d_pos: {position, ticket word of the sampling kernel}
         self.tiles = z(R + 64, 3)
         self.x, self.x2 = e(R, d, dtype=torch.float32), e(R, d, dtype=torch.float32)
         self.y, self.att, self.q, self.hh0, self.hh1 = e(R, d), e(R, d), e(R, d), e(R, d), e(R, d)

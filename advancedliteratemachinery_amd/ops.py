@@ -372,6 +372,11 @@ def cross_q4(on):
     _lib.check(_lib.lib().omp_debug_cross_q4(int(on)), 'omp_debug_cross_q4')
 
 
+def dec_fused(mode):
+    """debug/testing: 0 = fused few-row decoder step kernels where they apply (default), 1 = one launch per op everywhere."""
+    _lib.check(_lib.lib().omp_debug_dec_fused(int(mode)), 'omp_debug_dec_fused')
+
+
 def swin_attn_impl(which):
     """debug/testing: 0 = matrix-core window attention (default), 1 = scalar cross-check kernel, 2 = matrix cores with table lookups."""
     _lib.check(_lib.lib().omp_debug_swin_attn_impl(which), 'omp_debug_swin_attn_impl')

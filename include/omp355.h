@@ -277,7 +277,7 @@ typedef struct {
   /* state */
   int32_t* seq;
   int32_t seq_ld;
-  int32_t* d_pos;
+  int32_t* d_pos;  /* int32[2]: {current position, ticket word of the sampling kernel (zero-initialised by the caller)} */
   float* probs;
   int32_t* finished;
   int32_t* lengths;

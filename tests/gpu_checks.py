@@ -525,6 +525,76 @@ def check_decoder(dtype_name='fp32', pre_norm=True, with_mask=True):
     return out
 
 
+def check_decoder_fused(with_mask=True):
+    """Few-row phases of the bf16 engine run FUSED kernels (csrc/decoder.hip: LN1 + qkv(head) + self-attention in one launch, the
+    query projection inside the cross-attention kernel, the embedding inside layer 0, sampling + position advance in one launch).
+    Teacher-forced logits of every decoder kind against the oracle AND against the launch-per-op path (omp_debug_dec_fused(1)):
+    one row per image (the point decoder's shape), ragged groups of <= 16 rows with R % 4 != 0, sequences crossing the 64-key
+    chunk and the 192-key prefetch window of the fused self-attention."""
+    dt = torch.bfloat16
+    out = []
+    args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True)
+    sd = weights.make_state_dict(args, seed=2, depths=(2, 2, 2, 2))
+    model = build_model(args, sd, (2, 2, 2, 2), dt)
+    enc, dec = model.engine()
+    d = 512
+    g = torch.Generator().manual_seed(15)
+    for counts, M, L, kinds in (([1, 1, 1, 1, 1], 130, 70, ('pt',)), ([13, 2, 16], 77, 9, ('pt', 'poly', 'rec')), ([1, 1], 64, 200, ('pt',))):
+        B = len(counts)
+        mem = q(rnd(B * M, d, seed=1), dt)
+        pos = q(rnd(B * M, d, seed=2), dt)
+        kmask = torch.zeros(B, M, dtype=torch.bool)
+        if with_mask:
+            kmask[B - 1, M - 17:] = True
+        mem_pos = q(mem + pos, dt)
+        kv = dec.project_memory(mem.to(DEV, dt), mem_pos.to(DEV, dt), B, M, kmask.to(torch.uint8).to(DEV) if with_mask else None)
+        R = sum(counts)
+        for kind in kinds:
+            seqs = torch.randint(0, args.num_classes - 1, (R, L), generator=g)
+            ops.dec_fused(0)
+            lg = dec.teacher_forced_logits(kind, kv, seqs, counts, 3).cpu()
+            ops.dec_fused(1)
+            lg0 = dec.teacher_forced_logits(kind, kv, seqs, counts, 3).cpu()
+            ops.dec_fused(0)
+            worst, r0, scale = 0.0, 0, 0.0
+            for b in range(B):
+                n = counts[b]
+                mem_b = mem.reshape(B, M, d)[b].unsqueeze(1)
+                pos_b = mem_pos.reshape(B, M, d)[b].unsqueeze(1) - mem_b
+                ref = O.decode(sd, args, seqs[r0:r0 + n], mem_b, kmask[b:b + 1], pos_b, kind)
+                worst = max(worst, (lg[r0:r0 + n] - ref).abs().max().item())
+                scale = max(scale, ref.abs().max().item())
+                r0 += n
+            tag = 'decoder_fused[%s,rows=%s,L=%d]' % (kind, counts, L)
+            out.append(rec(tag + ' vs oracle', worst, 0.6, 'max|logit|=%.2f' % scale))
+            out.append(rec(tag + ' vs launch-per-op path', (lg - lg0).abs().max().item(), 0.35))
+            out.append(rec(tag + ' fused path differs from the unfused one (it ran)', 0.0 if not torch.equal(lg, lg0) else 1.0, 0.0))
+    return out
+
+
+def check_sampling_block():
+    """greedy sampling inside omp_decoder_run (workgroup per row + fused position advance) == the stand-alone sampling entry point:
+    covered end to end by the token-identity gates; here the free-running fp32 result with the fused kernels off and on."""
+    args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=10)
+    depths = (2, 2, 2, 2)
+    sd = weights.make_state_dict(args, seed=4, depths=depths)
+    imgs = rnd(3, 3, 96, 128, seed=3).to(DEV)
+    mask = torch.zeros(3, 96, 128, dtype=torch.bool, device=DEV)
+    seqs = O.default_prompts(args)
+    res = []
+    for mode in (0, 1):
+        ops.dec_fused(mode)
+        model = build_model(args, sd, depths, torch.float32)
+        res.append(model.infer(imgs, mask, seqs, forced_instances=3))
+    ops.dec_fused(0)
+    bad = 0
+    for b in range(3):
+        for k in range(3):
+            bad += 0 if bool((res[0][b][0][k] == res[1][b][0][k]).all()) else 1
+        bad += 0 if maxerr(res[0][b][1][0], res[1][b][1][0]) < 1e-5 else 1
+    return [rec('sampling: workgroup-per-row kernel with fused advance == wave-per-row kernel + advance launch [fp32 tokens, probs]', bad, 0)]
+
+
 def check_decoder_long(dtype_name='fp32'):
     """BASELINE config 4 as far as the reference allows it: the decoders' position tables hold 1024 entries
     (transformer.py:475), so the longest sequence is 1023 input positions.  Teacher-forced logits of the point

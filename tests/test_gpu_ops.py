@@ -31,6 +31,15 @@ def test_decoder_teacher_forced(C, dtype, pre_norm):
     _assert_all(C.check_decoder(dtype, pre_norm, with_mask=True))
 
 
+@pytest.mark.parametrize('with_mask', [True, False])
+def test_decoder_fused_few_row_kernels(C, with_mask):
+    _assert_all(C.check_decoder_fused(with_mask))
+
+
+def test_sampling_block_kernel(C):
+    _assert_all(C.check_sampling_block())
+
+
 def test_decoder_no_mask(C):
     _assert_all(C.check_decoder('fp32', True, with_mask=False))
 
@@ -38,6 +47,11 @@ def test_decoder_no_mask(C):
 def test_decoder_longest_sequence(C):
     """config 4 (long structured-sequence decode) up to the reference's 1024-entry position tables"""
     _assert_all(C.check_decoder_long('fp32'))
+
+
+def test_decoder_longest_sequence_bf16_fused(C):
+    """the same 1023-position sequence through the fused few-row kernels (16 key chunks, the prefetch ring wrapping 5 times)"""
+    _assert_all(C.check_decoder_long('bf16'))
 
 
 def test_contexts_isolate_state(C):
