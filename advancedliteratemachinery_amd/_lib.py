@@ -88,6 +88,8 @@ _SIGS = {
                                         c_int, c_void_p]),
     'omp_head_softmax_mask_argmax': (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(SampleCfg), c_void_p,
                                              c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'omp_pack_spotting': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_void_p, c_void_p, c_void_p]),
     'omp_decoder_run': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_int, c_int, c_void_p]),
     'omp_decoder_graph_reset': (c_int, [c_int]),
     'omp_decoder_step_logits': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_void_p]),

@@ -2,7 +2,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <mutex>
+#include <set>
 #include <utility>
 #include <vector>
 
@@ -20,7 +22,14 @@ struct OmpProfClass {
 namespace {
 thread_local char g_err[512] = "";
 thread_local omp_ctx* t_ctx = nullptr;   // this thread's context; nullptr = the process default
+thread_local uint64_t t_epoch = 0;       // value of g_epoch when t_ctx was last validated
 std::mutex g_prof_mu;                    // the event lists may be appended to from several lane threads of one context
+// Registry of live contexts: omp_ctx_destroy on one thread must not leave ANOTHER thread (a pipeline lane worker) with a dangling
+// thread-local pointer.  Every destroy bumps g_epoch; a thread whose cached epoch is stale re-validates its pointer against the
+// registry (one atomic load on the fast path) and falls back to the default context if its context is gone.
+std::mutex g_ctx_mu;
+std::set<omp_ctx*> g_live;
+std::atomic<uint64_t> g_epoch{1};
 
 omp_ctx& default_ctx() {
   static omp_ctx* c = [] {
@@ -32,12 +41,26 @@ omp_ctx& default_ctx() {
 }
 }  // namespace
 
-omp_ctx& omp_cur() { return t_ctx != nullptr ? *t_ctx : default_ctx(); }
+omp_ctx& omp_cur() {
+  if (t_ctx != nullptr) {
+    const uint64_t e = g_epoch.load(std::memory_order_acquire);
+    if (e != t_epoch) {
+      std::lock_guard<std::mutex> lk(g_ctx_mu);
+      if (g_live.find(t_ctx) == g_live.end()) t_ctx = nullptr;   // destroyed elsewhere: back to the default context
+      t_epoch = e;
+    }
+  }
+  return t_ctx != nullptr ? *t_ctx : default_ctx();
+}
 
 extern "C" int omp_ctx_create(omp_ctx** out) {
   OMP_CHECK_ARG(out != nullptr, "omp_ctx_create: null pointer");
   omp_ctx* c = new omp_ctx();
   c->prof = new OmpProfClass[OMP_PROF_NCLASS];
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_live.insert(c);
+  }
   *out = c;
   return OMP_OK;
 }
@@ -45,6 +68,14 @@ extern "C" int omp_ctx_create(omp_ctx** out) {
 extern "C" int omp_ctx_destroy(omp_ctx* c) {
   if (c == nullptr) return OMP_OK;
   OMP_CHECK_ARG(c != &default_ctx(), "omp_ctx_destroy: the default context is not destroyable");
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (g_live.erase(c) == 0) {
+      omp_set_error("omp_ctx_destroy: not a live context handle");
+      return OMP_ERR_INVALID;
+    }
+    g_epoch.fetch_add(1, std::memory_order_acq_rel);   // other threads drop their pointer on their next call
+  }
   if (t_ctx == c) t_ctx = nullptr;
   for (int i = 0; i < OMP_MAX_GRAPH_SLOTS; ++i) {
     if (c->slots[i].exec) (void)hipGraphExecDestroy(c->slots[i].exec);
@@ -58,7 +89,14 @@ extern "C" int omp_ctx_destroy(omp_ctx* c) {
 }
 
 extern "C" int omp_ctx_make_current(omp_ctx* c) {
-  t_ctx = (c == &default_ctx()) ? nullptr : c;
+  if (c == nullptr || c == &default_ctx()) { t_ctx = nullptr; return OMP_OK; }
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  if (g_live.find(c) == g_live.end()) {   // a stale handle (destroyed, or never a context) must not become current
+    omp_set_error("omp_ctx_make_current: not a live context handle");
+    return OMP_ERR_INVALID;
+  }
+  t_ctx = c;
+  t_epoch = g_epoch.load(std::memory_order_acquire);
   return OMP_OK;
 }
 

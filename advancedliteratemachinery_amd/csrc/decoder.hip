@@ -1067,6 +1067,30 @@ __global__ __launch_bounds__(256) void dec_sample_block_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// Text-spotting results of an engine call -> fixed-size padded tensors (the payload of the per-call all-gather of an image-
+// sharded deployment): one launch instead of a Python loop of ~12 tiny device copies per image.
+// ids[b, n, :] = point (2) | polygon (32) | recognition (rec_len) tokens of instance n of image b (rows row0[b] .. + cnt[b],
+// capped at N), zero padded; probs[b, n, :] = its recognition probabilities.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pack_spotting_kernel(const int32_t* __restrict__ points, const int32_t* __restrict__ poly, int poly_ld,
+                                                          const int32_t* __restrict__ rec, int rec_ld, const float* __restrict__ rprob,
+                                                          int prob_ld, const int32_t* __restrict__ row0, const int32_t* __restrict__ cnt,
+                                                          int N, int rec_len, int32_t* __restrict__ ids, float* __restrict__ probs) {
+  const int n = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int W = 34 + rec_len;
+  const bool live = n < cnt[b];
+  const int64_t r = (int64_t)row0[b] + n;
+  int32_t* io = ids + ((int64_t)b * N + n) * W;
+  float* po = probs + ((int64_t)b * N + n) * rec_len;
+  for (int c = t; c < W; c += 64) {
+    int32_t v = 0;
+    if (live) v = c < 2 ? points[r * 2 + c] : (c < 34 ? poly[r * poly_ld + (c - 2)] : rec[r * rec_ld + (c - 34)]);
+    io[c] = v;
+  }
+  for (int c = t; c < rec_len; c += 64) po[c] = live ? rprob[r * prob_ld + c] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------------
 // optional hipEvent bracketing of the cross-attention kernel (bench.py's roofline measurement)
@@ -1167,6 +1191,17 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
 }
 
 }  // namespace
+
+extern "C" int omp_pack_spotting(const int32_t* points, const int32_t* poly, int poly_ld, const int32_t* rec, int rec_ld,
+                                 const float* rec_probs, int prob_ld, const int32_t* row0, const int32_t* counts, int B, int N,
+                                 int rec_len, int32_t* ids, float* probs, omp_stream_t s) {
+  OMP_CHECK_ARG(points && poly && rec && rec_probs && row0 && counts && ids && probs, "omp_pack_spotting: null pointer");
+  OMP_CHECK_ARG(B > 0 && N > 0 && rec_len > 0 && poly_ld >= 32 && rec_ld >= rec_len && prob_ld >= rec_len, "omp_pack_spotting: bad shape");
+  hipLaunchKernelGGL(pack_spotting_kernel, dim3(N, B), dim3(64), 0, (hipStream_t)s, points, poly, poly_ld, rec, rec_ld, rec_probs, prob_ld,
+                     row0, counts, N, rec_len, ids, probs);
+  OMP_CHECK_LAUNCH("omp_pack_spotting");
+  return OMP_OK;
+}
 
 extern "C" int omp_dec_embed_ln(const int32_t* seq, int seq_ld, const int32_t* d_pos, const float* word_emb,
                                 const float* pos_tab, const float* gamma, const float* beta, float* x,

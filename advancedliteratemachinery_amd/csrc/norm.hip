@@ -251,6 +251,75 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
   }
 }
 
+// PatchEmbed, one THREAD per token (E <= 128): the 48 inputs of a token are 12 sixteen-byte loads (lane t reads the four kx
+// values of token t: consecutive lanes read consecutive 16 bytes of an image row -- fully coalesced), the E x 48 weights are
+// wave-uniform and arrive through the scalar cache, the LayerNorm over the token's E channels is in-thread arithmetic (no LDS,
+// no cross-lane traffic, no barrier).  The workgroup-per-16-tokens kernel above staged every patch value through LDS and was
+// LDS-issue bound at 0.12 of the HBM roofline (949 us per 32-image chunk, profiles/r02zl_*); kept for E > 128.
+template <typename TO, int EMAX>
+__global__ __launch_bounds__(256) void patch_embed_tok_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, const float* __restrict__ g,
+                                                              const float* __restrict__ be, TO* __restrict__ out, int B, int H, int W,
+                                                              int Hp, int Wp, int E, float eps) {
+  const int64_t tok = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t ntok = (int64_t)B * Hp * Wp;
+  const bool live = tok < ntok;
+  const int64_t tk = live ? tok : ntok - 1;
+  const int tx = (int)(tk % Wp), ty = (int)((tk / Wp) % Hp), b = (int)(tk / ((int64_t)Wp * Hp));
+  float x[48];
+  const bool vec = (W & 3) == 0 && tx * 4 + 3 < W;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int py = ty * 4 + ky;
+      const float* row = img + (((int64_t)b * 3 + ch) * H + (py < H ? py : H - 1)) * W + tx * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (py < H) {
+        if (vec) v = *reinterpret_cast<const f32x4*>(row);
+        else {
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx)
+            if (tx * 4 + kx < W) v[kx] = row[kx];
+        }
+      }
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) x[ch * 16 + ky * 4 + kx] = v[kx];
+    }
+  float y[EMAX];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < EMAX; ++c) {
+    float a = 0.f;
+    if (c < E) {                       // wave-uniform
+      const float* wc = w + c * 48;    // uniform address: scalar loads
+      a = bias[c];
+#pragma unroll
+      for (int e = 0; e < 48; ++e) a = fmaf(wc[e], x[e], a);
+    }
+    y[c] = a;
+    s += a;
+  }
+  const float mean = s / (float)E;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < EMAX; ++c)
+    if (c < E) { const float d = y[c] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(q / (float)E + eps);
+  if (!live) return;
+  TO* o = out + tok * E;
+  constexpr int NV = 16 / (int)sizeof(TO);
+#pragma unroll
+  for (int c = 0; c < EMAX; c += NV) {
+    if (c < E) {
+      float t[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) t[i] = (y[c + i] - mean) * rstd * g[c + i] + be[c + i];
+      store_vals<TO, NV>(o + c, t);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int omp_split_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, int triple, omp_stream_t s) {
@@ -302,9 +371,22 @@ extern "C" int omp_patch_embed_ln(const float* img, const float* w, const float*
   OMP_CHECK_ARG(img && w && b && gamma && beta && out, "omp_patch_embed_ln: null pointer");
   OMP_CHECK_ARG(B > 0 && H > 0 && W > 0 && E > 0 && E <= 1024, "omp_patch_embed_ln: bad shape");
   const int Hp = (H + 3) / 4, Wp = (W + 3) / 4;
+  if (E <= 128 && E % 8 == 0 && (out_dtype == OMP_F32 || out_dtype == OMP_BF16)) {   // thread-per-token kernel
+    const int64_t ntok = (int64_t)B * Hp * Wp;
+    const dim3 tgrid((unsigned)ceil_div64(ntok, 256));
+    if (out_dtype == OMP_F32)
+      hipLaunchKernelGGL((patch_embed_tok_kernel<float, 128>), tgrid, dim3(256), 0, (hipStream_t)s, img, w, b, gamma, beta, (float*)out, B, H,
+                         W, Hp, Wp, E, eps);
+    else
+      hipLaunchKernelGGL((patch_embed_tok_kernel<bf16_t, 128>), tgrid, dim3(256), 0, (hipStream_t)s, img, w, b, gamma, beta, (bf16_t*)out, B,
+                         H, W, Hp, Wp, E, eps);
+    OMP_CHECK_LAUNCH("omp_patch_embed_ln");
+    return OMP_OK;
+  }
   const int nthr = ((E + 63) / 64) * 64;
   dim3 grid((Wp + PE_TOK - 1) / PE_TOK, Hp, B);
   const size_t smem = (PE_TOK * 48 + PE_TOK * E) * sizeof(float);
+  OMP_CHECK_ARG(smem <= 64 * 1024, "omp_patch_embed_ln: E=%d needs %zu bytes of LDS (> 64 KB)", E, smem);   // E <= 976
   if (out_dtype == OMP_F32)
     hipLaunchKernelGGL((patch_embed_kernel<float>), grid, dim3(nthr), smem, (hipStream_t)s, img, w, b,
                        gamma, beta, (float*)out, B, H, W, Hp, Wp, E, eps);

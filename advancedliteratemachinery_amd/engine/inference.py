@@ -127,6 +127,31 @@ def _meta(t):
     return {'file_name': t['file_name'], 'orig_size': (float(h), float(w)), 'dataset_name': t.get('dataset_name', 'results')}
 
 
+def _rank_items(dataloader, rank, ws, sharded):
+    """This rank's part of the validation set WITHOUT decoding the other ranks' images (every rank used to iterate the
+    whole loader and discard what was not its own).  A torch DataLoader with a map-style dataset is re-pointed at
+    Subset(dataset, [lo, hi)) (same collate / workers / batch size 1 as the reference's val loader); a plain sequence is
+    sliced; a generic iterable is consumed lazily with islice -- skipped items are still produced by the iterable, but never
+    held: nothing is materialised with list().  -> (iterable of this rank's items, lo, hi)."""
+    import itertools
+    if ws == 1 or sharded:
+        return dataloader, 0, None
+    if not hasattr(dataloader, '__len__'):
+        raise TypeError('validate over %d ranks needs a dataloader with a length (to cut contiguous shards); pass a sized loader or '
+                        'one that is already rank-sharded (args.dataloader_is_sharded)' % ws)
+    n_items = len(dataloader)
+    lo, hi = udist.shard_range(n_items, rank, ws)
+    ds = getattr(dataloader, 'dataset', None)
+    if isinstance(dataloader, torch.utils.data.DataLoader) and ds is not None and hasattr(ds, '__getitem__') and \
+            (dataloader.batch_size in (1, None)) and len(ds) == n_items:
+        sub = torch.utils.data.Subset(ds, range(lo, hi))
+        return torch.utils.data.DataLoader(sub, batch_size=dataloader.batch_size, shuffle=False, num_workers=dataloader.num_workers,
+                                           collate_fn=dataloader.collate_fn, pin_memory=dataloader.pin_memory), lo, hi
+    if isinstance(dataloader, (list, tuple)):
+        return dataloader[lo:hi], lo, hi
+    return itertools.islice(iter(dataloader), lo, hi), lo, hi
+
+
 @torch.no_grad()
 def validate(model, dataloader, epoch, args, batch_size=1):
     """Drop-in for engine.validate (val.py:11-68), image-sharded over the ranks of torch.distributed.
@@ -141,10 +166,8 @@ def validate(model, dataloader, epoch, args, batch_size=1):
     model.eval()
     rank, ws = udist.world()
     dev = next(model.parameters()).device
-    items = list(dataloader) if not hasattr(dataloader, '__len__') else dataloader
-    n_items = len(items)
     sharded = bool(getattr(args, 'dataloader_is_sharded', False))
-    lo, hi = (0, n_items) if (ws == 1 or sharded) else udist.shard_range(n_items, rank, ws)
+    items, lo, hi = _rank_items(dataloader, rank, ws, sharded)
     kie = args.vie_categories > 0
     local_raw, local_meta = [], []
     pend_imgs, pend_tg = [], []
@@ -157,9 +180,7 @@ def validate(model, dataloader, epoch, args, batch_size=1):
         local_meta.extend(_meta(t) for t in pend_tg)
         del pend_imgs[:], pend_tg[:]
 
-    for i, (samples, targets) in enumerate(items):
-        if i < lo or i >= hi:
-            continue
+    for samples, targets in items:
         nt = _as_nested(samples)
         for img, t in zip(nt.unpad_tensors(), targets):
             pend_imgs.append(img)

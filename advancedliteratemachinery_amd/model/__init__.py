@@ -7,11 +7,13 @@ from .omniparser import OmniParser
 from .params import SWIN_B, expected_state_dict
 
 
-def load_swin_pretrained(model, path):
+def load_swin_pretrained(model, path, allow_unsafe_pickle=False):
     """ImageNet Swin-B init by key intersection, like build_swin_transformer_model
-    (reference backbone/swin_transformer.py:636-656): file = {'model': {un-prefixed keys}}."""
+    (reference backbone/swin_transformer.py:636-656): file = {'model': {un-prefixed keys}}.  The official Swin files also carry
+    a pickled 'config' object, which torch.load(weights_only=True) refuses: pass allow_unsafe_pickle (--allow_unsafe_pickle)
+    for a file you trust."""
     from ..utils.checkpointer import load_checkpoint_file
-    saved = load_checkpoint_file(path)['model']
+    saved = load_checkpoint_file(path, allow_unsafe_pickle)['model']
     own = model.state_dict()
     hit = {}
     for k in own:
@@ -30,7 +32,7 @@ def build_model(args, swin_cfg=None):
     model = OmniParser(args, swin_cfg)
     pf = getattr(args, 'pretrained_file', None)
     if pf and os.path.isfile(pf):
-        load_swin_pretrained(model, pf)
+        load_swin_pretrained(model, pf, bool(getattr(args, 'allow_unsafe_pickle', False)))
     if torch.cuda.is_available():
         model = model.to(torch.device('cuda'))
     return model

@@ -15,6 +15,7 @@ Return value per image (reference transformer.py:240-246,286):
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..utils.nested_tensor import NestedTensor
 from . import params
 from .backbone import Encoder
@@ -114,9 +115,12 @@ class OmniParser(nn.Module):
 
     # -- batched inference ------------------------------------------------------------------------
     @torch.no_grad()
-    def infer(self, img, mask, sequence, forced_instances=None, has_padding=None, lane=None):
+    def infer(self, img, mask, sequence, forced_instances=None, has_padding=None, lane=None, packed=None):
         """lane: a pipeline Lane (engine/pipeline.py) -- private decoder state + side streams, so several
-        batches can be in flight on different HIP streams; None = the model's own state."""
+        batches can be in flight on different HIP streams; None = the model's own state.
+        packed = N (text spotting only): return (ids int32 [B, N, 34 + rec_length], probs [B, N, rec_length], n_inst [B]) device
+        tensors -- the all-gather payload of utils/dist.py -- packed by ONE kernel from the decoders' buffers instead of the
+        per-image result lists (no per-image host work or device copies)."""
         enc, dec = self.engine()
         side = None
         if lane is not None:
@@ -142,10 +146,10 @@ class OmniParser(nn.Module):
                 outer = torch.cuda.current_stream()
                 dstream.wait_stream(outer)
                 with torch.cuda.stream(dstream):
-                    out = self._decode(dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side)
+                    out = self._decode(dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side, packed)
                 outer.wait_stream(dstream)
                 return out
-            return self._decode(dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side)
+            return self._decode(dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side, packed)
 
     def _encode_chunked(self, enc, img, mask, no_padding=False):
         """The encoder gains nothing from more than a few images per launch (its kernels already fill the chip) while
@@ -174,7 +178,7 @@ class OmniParser(nn.Module):
         out['key_mask'] = torch.cat(km, 0)
         return out
 
-    def _decode(self, dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side):
+    def _decode(self, dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side, packed=None):
         """point decoder -> polygon || recognition decoders (or the KIE walk) on the current stream"""
         a = self.args
         pts = dec.decode_points(kv, prompt, forced_instances=forced_instances)
@@ -182,13 +186,21 @@ class OmniParser(nn.Module):
         if a.infer_vie:
             sizes = sequence[3]
             return self._kie(dec, kv, pts, poly_sos, rec_sos, sizes, B, side)
+        if packed is not None and a.infer_vie:
+            raise ValueError('packed results are the text-spotting payload; KIE returns entity lists')
         counts = [int(ids.numel()) // 2 for ids, _ in pts]
         R = sum(counts)
         if R == 0:
+            if packed is not None:
+                return (torch.zeros(B, packed, 34 + a.rec_length, dtype=torch.int32, device=dev),
+                        torch.zeros(B, packed, a.rec_length, dtype=torch.float32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev))
             return [None] * B
         points = torch.cat([ids.reshape(-1, 2) for ids, _ in pts], 0).to(dev, torch.int32)
         (poly, _), (rec, rprob) = dec.decode_poly_and_rec(kv, points, counts, poly_sos, rec_sos, a.rec_length,
                                                           streams=side if side is not None else self._side_streams(dev))
+        if packed is not None:   # one launch from the decoders' own buffers (views into the phase tensors)
+            self._mark('poly_rec_decode')
+            return ops.pack_spotting(points, poly, rec, rprob, counts, int(packed), a.rec_length)
         poly, rec, rprob = poly.long(), rec.long(), rprob.clone()
         self._mark('poly_rec_decode')
         out, r0 = [], 0

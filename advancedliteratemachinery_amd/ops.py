@@ -247,6 +247,25 @@ def head_sample(logits, cfg, seq, probs, finished, lengths, d_pos, advance=True)
     _lib.check(rc, 'omp_head_softmax_mask_argmax')
 
 
+def pack_spotting(points, poly, rec, rprob, counts, N, rec_len):
+    """Decoded rows (device int32 [R,2] / [R,>=32] / [R,>=rec_len], fp32 [R,>=rec_len]; rows sorted by image, counts per image)
+    -> (ids int32 [B, N, 34 + rec_len], probs fp32 [B, N, rec_len], n_inst int32 [B]) in ONE launch (omp_pack_spotting)."""
+    dev = points.device
+    B = len(counts)
+    c = torch.tensor(counts, dtype=torch.int32)
+    row0 = (torch.cumsum(c, 0) - c).to(torch.int32)
+    cd, r0 = torch.minimum(c, torch.tensor(N, dtype=torch.int32)).to(dev, non_blocking=True), row0.to(dev, non_blocking=True)
+    ids = torch.empty((B, N, 34 + rec_len), dtype=torch.int32, device=dev)
+    probs = torch.empty((B, N, rec_len), dtype=torch.float32, device=dev)
+    for t in (points, poly, rec, rprob):
+        if t.stride(-1) != 1:
+            raise ValueError('pack_spotting: rows must be contiguous along the last dimension')
+    rc = _lib.lib().omp_pack_spotting(ptr(points), ptr(poly), poly.stride(0), ptr(rec), rec.stride(0), ptr(rprob), rprob.stride(0),
+                                      ptr(r0), ptr(cd), B, N, rec_len, ptr(ids), ptr(probs), stream())
+    _lib.check(rc, 'omp_pack_spotting')
+    return ids, probs, cd
+
+
 def vit_patch_embed(img, w, bias, cls, pos, out_dtype):
     """img [B,3,H,W] fp32 -> tokens [B, T, E] with T = (H/4)*(W/4) + 1 (token 0 = cls), pos_embed added."""
     _c(img, 'img')

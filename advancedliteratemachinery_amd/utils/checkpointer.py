@@ -8,6 +8,7 @@ torch.load(weights_only=True) with argparse.Namespace allow-listed (the only non
 under 'args'); full unpickling -- which can execute code -- happens only with `allow_unsafe_pickle=True`.
 """
 import argparse
+import pickle
 
 import torch
 
@@ -16,13 +17,18 @@ _VOCAB_KEYS = ['transformer.embedding.word_embeddings.weight'] + [
 
 
 def load_checkpoint_file(path, allow_unsafe_pickle=False):
+    """I/O errors (missing or truncated file, unsupported format) propagate as they are; only the weights-only unpickler's
+    refusal of a non-allow-listed object is turned into the "pass allow_unsafe_pickle" error -- or, with that flag, into a full
+    (code-executing) unpickle of a file the caller vouches for."""
     try:
         with torch.serialization.safe_globals([argparse.Namespace]):
             return torch.load(path, map_location='cpu', weights_only=True)
-    except Exception as e:  # noqa: BLE001 -- UnpicklingError and friends
+    except pickle.UnpicklingError as e:
+        if 'weights only' not in str(e).lower() and 'weights_only' not in str(e).lower():
+            raise    # a corrupt pickle stream, not an allow-list refusal
         if not allow_unsafe_pickle:
             raise RuntimeError('%s holds objects torch.load(weights_only=True) refuses (%s); pass allow_unsafe_pickle=True '
-                               'only for files you trust' % (path, str(e).splitlines()[0])) from e
+                               '(--allow_unsafe_pickle) only for files you trust' % (path, str(e).splitlines()[0])) from e
         return torch.load(path, map_location='cpu', weights_only=False)
 
 

@@ -93,6 +93,9 @@ _FLAGS = [
 # Engine-only flags (not in the reference): precision of the HIP path.
 _ENGINE_FLAGS = [
     ('--engine_dtype', dict(type=str, default='bf16', choices=['bf16', 'fp32', 'bf16x3'])),
+    # checkpoints (--resume, --pretrained_file) are read with torch.load(weights_only=True); files that hold other pickled
+    # objects (the official Swin ImageNet files carry a 'config') need this flag -- full unpickling can execute code
+    ('--allow_unsafe_pickle', dict(action='store_true')),
 ]
 
 

@@ -70,6 +70,7 @@ def parse():
     p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'bf16x3'],
                    help='engine precision: bf16 (BASELINE config 2), fp32, or bf16x3 = the parity engine (fp32 storage, split-bf16 products)')
     p.add_argument('--no-parity-leg', action='store_true', help='skip the parity_engine leg (bf16x3 engine on the same workload)')
+    p.add_argument('--no-config-legs', action='store_true', help='skip the summary legs of BASELINE configs 3 / 4 / 5 (kie, long_pt, mgp_str)')
     p.add_argument('--graph', type=int, default=int(os.environ.get('OMP355_GRAPH', '1')))
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
@@ -114,26 +115,19 @@ def prompts(args):
     return [pt, torch.full((1, 1), args.poly_sos_index, dtype=torch.long), torch.full((1, 1), args.rec_sos_index, dtype=torch.long)]
 
 
-def gather_results(results, B, N, rec_len, world, device):
-    """Image-sharded deployment: one all-gather of padded token tensors per batch."""
-    ids = torch.zeros(B, N, 2 + 32 + rec_len, dtype=torch.int32, device=device)
-    probs = torch.zeros(B, N, rec_len, dtype=torch.float32, device=device)
-    for b, r in enumerate(results):
-        if r is None:
-            continue
-        (pt, poly, rec), (pr,) = r
-        n = min(N, pt.numel() // 2)
-        ids[b, :n, 0:2] = pt.reshape(-1, 2)[:n].int()
-        ids[b, :n, 2:34] = poly.reshape(-1, 32)[:n].int()
-        ids[b, :n, 34:] = rec[0][:n].int()
-        probs[b, :n] = pr[:n]
-    if world > 1:
-        all_ids = torch.empty(world * B, N, ids.shape[2], dtype=torch.int32, device=device)
-        all_pr = torch.empty(world * B, N, rec_len, dtype=torch.float32, device=device)
-        dist.all_gather_into_tensor(all_ids, ids)
-        dist.all_gather_into_tensor(all_pr, probs)
-        return all_ids, all_pr
-    return ids, probs
+def pin_host_threads(local_rank, ranks_on_node):
+    """One rank per GPU on a shared host: give every rank its own slice of the cores it may use, so that N Python launch threads
+    (and their lane threads) do not migrate over each other.  Returns the cores this rank was pinned to (or None)."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        if ranks_on_node <= 1 or len(cores) < ranks_on_node:
+            return None
+        per = len(cores) // ranks_on_node
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (AttributeError, OSError):
+        return None
 
 
 def pmc_traffic(images_per_launch):
@@ -214,21 +208,38 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(args, sd, size, instances, pt_steps, budget_s=40.0):
+def cpu_baseline(args, sd, size, instances, pt_steps, budget_s=32.0):
     """Reference algorithm (oracle restatement: no KV cache, full prefix re-decoded every step, memory
-    broadcast per instance) on the host cores -- a BOUNDED sample scaled to the GPU workload:
-    backbone+FPN+projection of one image at (size/2)^2 (x4: Swin cost is linear in pixels), then single
-    decoder calls against a full-size (size/16)^2 memory: point decoder at a short and a mid prefix,
-    polygon / recognition at N=2 instances (reference decode cost is linear in instances and ~affine in
-    prefix length).  Every leg is skipped (and the number marked partial) once `budget_s` is spent."""
+    broadcast per instance) on the host cores.  Two parts:
+      * `measured_small`: ONE complete run of the path, measured end to end at a reduced size (512x512 image, 2 instances);
+      * `value`: an ESTIMATE of the full workload (1024x1024, 64 instances would take ~15 minutes per image) composed from a
+        bounded sample: backbone+FPN+projection of one image at (size/2)^2 (x4: Swin cost is linear in pixels), then single
+        decoder calls against a full-size (size/16)^2 memory: point decoder at a short and a mid prefix, polygon /
+        recognition at N=2 instances (reference decode cost is linear in instances and ~affine in prefix length).
+    Every leg of the estimate is skipped (and the number marked partial) once `budget_s` is spent."""
+    import copy
     from oracle import omniparser_ref as O
     cores = host_cores()
     torch.set_num_threads(min(cores, 64))
+    sd = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
+    # -- measured: the whole reference path once, 512x512, pt_seq_length 4 -> 2 instances x (32 polygon + rec_length steps)
+    small = copy.copy(args)
+    small.pt_seq_length = 4
+    gs = torch.Generator().manual_seed(4321)
+    with torch.no_grad():
+        img_s = torch.randn(1, 3, 512, 512, generator=gs)
+        t0 = time.time()
+        out_s = O.forward(sd, small, img_s, torch.zeros(1, 512, 512, dtype=torch.bool), O.default_prompts(small))
+        t_small = time.time() - t0
+    n_small = 0 if out_s is None else int(out_s[0][0].numel()) // 2
+    measured_small = dict(value=1.0 / t_small, unit='images/s', seconds=t_small, image_size=512, instances=n_small,
+                          chars_per_sec=n_small * args.rec_length / t_small,
+                          sample='oracle.forward end to end: 512x512 image, pt_seq_length 4 (%d instances), %d threads' % (n_small, min(cores, 64)))
+    print('[cpu_baseline] measured end to end: 512x512, %d instances: %.2fs' % (n_small, t_small), file=sys.stderr, flush=True)
     t_start = time.time()
     left = lambda: budget_s - (time.time() - t_start)   # noqa: E731
     log = lambda m: print('[cpu_baseline] ' + m, file=sys.stderr, flush=True)  # noqa: E731
     g = torch.Generator().manual_seed(1234)
-    sd = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
     half = max(64, size // 2)
     d = args.tfm_hidden_dim
     M = (size // 16) ** 2
@@ -273,8 +284,8 @@ def cpu_baseline(args, sd, size, instances, pt_steps, budget_s=40.0):
         notes.append('polygon/recognition steps estimated from the point step (budget)')
     t_pt = pt_steps * 0.5 * (t_pt_a + t_pt_b)
     t_total = t_enc + t_pt + (32 * t_poly + args.rec_length * t_rec) * (instances / n_s)
-    return dict(value=1.0 / t_total, unit='images/s', cores=cores, kind='port',
-                sample=('oracle (CPU restatement of the reference path, fp32, %d threads): encode of one %dx%d image '
+    return dict(value=1.0 / t_total, unit='images/s', cores=cores, kind='port', estimated=True, measured_small=measured_small,
+                sample=('ESTIMATE from a bounded sample (the measured end-to-end run is `measured_small`) -- oracle (CPU restatement of the reference path, fp32, %d threads): encode of one %dx%d image '
                         'measured and scaled x%.0f to %dx%d = %.2fs; point-decoder call %.3fs (L=7) / %.3fs (L=%d) '
                         'measured against a %d-token memory, x%d steps; polygon / recognition call %.3fs / %.3fs '
                         'measured at N=%d instances, scaled linearly to N=%d (x32 / x%d steps); estimated '
@@ -459,6 +470,15 @@ def main():
         if dist.get_world_size() != a.gpus or int((seen > 0).sum()) != a.gpus or len(set(seen.tolist())) != a.gpus:
             raise SystemExit('RCCL sees %d ranks / devices %s, expected %d distinct' % (dist.get_world_size(), seen.tolist(), a.gpus))
 
+    pinned = pin_host_threads(local, world)
+    rank_diag = None
+    if world > 1:
+        # what RCCL actually sees: every rank's (rank, device index, device name, pinned cores) -- the first SCALE run is self-diagnosing
+        info = dict(rank=rank, local_rank=local, device=torch.cuda.current_device(), name=torch.cuda.get_device_name(local),
+                    pinned_cores=len(pinned) if pinned else None)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, info)
+        rank_diag = gathered
     if a.workload != 'spotting':
         res = (run_mgp_str if a.workload == 'mgp_str' else run_kie)(a, device, world, rank)
         if rank == 0:
@@ -502,11 +522,14 @@ def main():
         else:
             gi = torch.cat([batches[(first_step + i) % POOL] for i in range(g_)], 0)
             gm = mask1.expand(g_, B, a.size, a.size).reshape(g_ * B, a.size, a.size)
-        res = model.infer(gi, gm, seqs, forced_instances=forced, has_padding=False, lane=lane)
-        out = gather_results(res, B * g_, N, args.rec_length, 1, device)
+        # packed: the padded all-gather payload comes out of ONE device kernel (ops.pack_spotting), no per-image host work
+        ids_, probs_, _ = model.infer(gi, gm, seqs, forced_instances=forced, has_padding=False, lane=lane, packed=N)
+        out = (ids_, probs_)
         ev1.record()
         calls.append((ev0, ev1, B * g_))
         return out
+
+    gather_ev = []   # (start, end) events around every all-gather pair of the timed region
 
     def exchange(ids, probs, g_):
         if world == 1:
@@ -516,8 +539,12 @@ def main():
         probs.record_stream(torch.cuda.current_stream())
         all_ids = torch.empty(world * B * g_, N, ids.shape[2], dtype=torch.int32, device=device)
         all_pr = torch.empty(world * B * g_, N, args.rec_length, dtype=torch.float32, device=device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         dist.all_gather_into_tensor(all_ids, ids)
         dist.all_gather_into_tensor(all_pr, probs)
+        e1.record()
+        gather_ev.append((e0, e1))
         return all_ids, all_pr
 
     def run_steps(k, group=None, forced=N):
@@ -555,12 +582,14 @@ def main():
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
+        local_s.append(el)
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, out
 
+    local_s = []   # this rank's own time of every repetition (before the max over ranks)
     with torch.cuda.stream(stream):
         # untimed set-up: every lane (or the model itself) allocates its buffers and captures its graphs for
         # both group sizes the timed region will use (full groups and the remainder group)
@@ -570,6 +599,8 @@ def main():
         run_steps(a.warmup)
         torch.cuda.synchronize()
         del calls[:]
+        del gather_ev[:]
+        del local_s[:]
         reps = []
         budget_reps = 64
         while True:
@@ -587,6 +618,13 @@ def main():
         call_ms = [e0.elapsed_time(e1) for e0, e1, _ in calls]
         call_imgs = calls[0][2] if calls else B * G
     elapsed = pct(reps, 0.5)
+    per_rank_ms = gather_ms = None
+    if world > 1:
+        mine = torch.tensor([pct(local_s, 0.5) / a.steps * 1e3], dtype=torch.float64, device=device)
+        allr = torch.empty(world, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank_ms = [float(v) for v in allr.tolist()]
+        gather_ms = [e0.elapsed_time(e1) for e0, e1 in gather_ev]
     total_images = world * B * a.steps
     ips = total_images / elapsed
     # sanity: the forced workload really produced N instances x rec_length chars per image
@@ -669,8 +707,51 @@ def main():
                          'tests/test_gpu_e2e.py::test_parity_engine_bf16x3): fp32 storage, large products as 3 bf16 matrix-core products '
                          'of split operands; same workload, one lane')
 
+    def side_args(**kw):
+        b_ = argparse.Namespace(**vars(a))
+        b_.steps, b_.warmup, b_.min_seconds, b_.no_roofline, b_.no_cpu_baseline, b_.batch = 3, 1, 1.5, True, True, None
+        for k_, v_ in kw.items():
+            setattr(b_, k_, v_)
+        return b_
+
+    def kie_leg():      # BASELINE config 3 (per GPU: batch 32 @ 960x1280, --infer_vie); full line: bench.py --workload kie
+        r_ = run_kie(side_args(), device, 1, 0)
+        return dict(images_per_sec=r_['value'], ms_per_step=r_['ms_per_step'], workload=r_['config']['workload'],
+                    words_per_image=r_['config']['words_per_image'], entities_per_image=r_['config']['entities_per_image'])
+
+    def mgp_leg():      # BASELINE config 5 (MGP-STR ViT-B, batch 512 words); full line: bench.py --workload mgp_str
+        r_ = run_mgp_str(side_args(steps=6, warmup=2), device, 1, 0)
+        return dict(words_per_sec=r_['value'], ms_per_step=r_['ms_per_step'], workload=r_['config']['workload'],
+                    model_tflops=r_['config']['tflops_model'])
+
+    def long_pt_leg():
+        # BASELINE config 4 as far as the reference allows: the released code has no table-recognition head and its
+        # position tables hold 1024 entries (transformer.py:475), so the long structured-sequence decode is the point decoder at
+        # its maximum: N = 508 forced instances -> 1016 + 6 point steps, then 508 polygon / recognition rows per image
+        Bl, Nl = 2, 508
+        imgs = batches[0][:Bl]
+        with torch.cuda.stream(stream):
+            model.infer(imgs, mask1[:Bl], seqs, forced_instances=Nl, has_padding=False, packed=Nl)
+            torch.cuda.synchronize()
+            rl = []
+            while sum(rl) < 2.0 and len(rl) < 4:
+                t0 = time.perf_counter()
+                ids_l, _, n_l = model.infer(imgs, mask1[:Bl], seqs, forced_instances=Nl, has_padding=False, packed=Nl)
+                torch.cuda.synchronize()
+                rl.append(time.perf_counter() - t0)
+        el_ = pct(rl, 0.5)
+        assert int(n_l.min()) == Nl, 'long decode produced %d instances' % int(n_l.min())
+        toks = Bl * (2 * Nl + Nl * (32 + args.rec_length))
+        return dict(images_per_sec=Bl / el_, tokens_per_sec=toks / el_, ms_per_call=el_ * 1e3, images_per_call=Bl, point_sequence_tokens=2 * Nl,
+                    instances_per_image=Nl, note='table-recognition stand-in: point sequence at the 1024-entry position-table limit '
+                                                 '(2 x 508 tokens + 6 prompt), then 508 polygon + recognition rows per image; %s engine' % a.dtype)
+
     if rank == 0 and world == 1 and not a.no_parity_leg and a.dtype == 'bf16':
         leg('parity_engine', parity_leg)
+    if rank == 0 and world == 1 and not a.no_config_legs:
+        leg('kie', kie_leg)
+        leg('mgp_str', mgp_leg)
+        leg('long_pt', long_pt_leg)
     if rank == 0 and world == 1 and not a.no_batch8:
         leg('batch8', batch8_leg)
     if rank == 0 and world == 1 and not a.no_eos_run:
@@ -678,8 +759,7 @@ def main():
 
     if a.phase_times and rank == 0:
         def one_step():
-            res = model.infer(batches[0], mask1, seqs, forced_instances=N, has_padding=False)
-            return gather_results(res, B, N, args.rec_length, 1, device)
+            return model.infer(batches[0], mask1, seqs, forced_instances=N, has_padding=False, packed=N)
         print('phase ms: %s' % json.dumps(phase_breakdown(model, one_step, stream)), file=sys.stderr, flush=True)
 
         def one_call():
@@ -778,11 +858,20 @@ def main():
                                note='each repetition = exactly %d steps between barrier+synchronize pairs, max over ranks; value from the median' % a.steps),
                    engine_call_ms=dict(images_per_call=call_imgs, calls=len(call_ms), median=pct(call_ms, 0.5), p10=pct(call_ms, 0.1),
                                        p90=pct(call_ms, 0.9), note='HIP events on the lane stream around every engine call of the timed region (latency, lanes overlap)'),
-                   config=dict(workload='OmniParser text-spotting, Swin-B, batch %d/GPU @ %dx%d, forced %d instances/image '
-                                        '(%d pt + 34 poly + 27 rec decoder steps), %s' % (B, a.size, a.size, N, 2 * N + 6, a.dtype),
+                   config=dict(workload='OmniParser text-spotting, Swin-B, batch %d/GPU per step @ %dx%d, %d steps coalesced per engine call = %d '
+                                        'images per engine call, forced %d instances/image (%d pt + 34 poly + 27 rec decoder steps), %s'
+                                        % (B, a.size, a.size, G, B * G, N, 2 * N + 6, a.dtype),
                                global_batch=world * B, image_size=a.size, instances_per_image=N, parallelism='image-sharded dp%d' % world,
                                hip_graph=bool(a.graph), lanes=lanes, coalesce=G, images_per_engine_call=B * G, distinct_batches=POOL))
         rec.update(extra)
+        # the literal BASELINE config-2 batch (one engine call per 8 images) next to the coalesced headline, at top level
+        rec['images_per_sec_coalesced'] = ips
+        rec['images_per_sec_batch8'] = extra.get('batch8', {}).get('images_per_sec') if isinstance(extra.get('batch8'), dict) else None
+        if world > 1:
+            rec['ranks'] = rank_diag
+            rec['per_rank_ms_per_step'] = per_rank_ms
+            rec['all_gather_ms'] = dict(calls=len(gather_ms), median=pct(gather_ms, 0.5), p90=pct(gather_ms, 0.9),
+                                        note='two all_gather_into_tensor (ids, probs) per engine call, HIP events on rank 0')
         if roof is not None:
             rec['roofline'] = roof
             rec['roofline_other'] = roof_other

@@ -240,6 +240,15 @@ int omp_head_softmax_mask_argmax(const float* logits, int ld, int R, const omp_s
                                  int32_t* seq, float* probs, int seq_ld, int32_t* finished,
                                  int32_t* lengths, int32_t* d_pos, int advance, omp_stream_t s);
 
+/* ---- Results of an engine call -> padded tensors (payload of the per-call all-gather) --------------------------
+ * Replaces the per-image result assembly of engine/val.py:39-60 for a batch: instance n of image b is row row0[b] + n of
+ * points [R,2], poly [R, poly_ld >= 32], rec [R, rec_ld >= rec_len], rec_probs [R, prob_ld] (device int32 / fp32, the
+ * decoders' own buffers); ids [B, N, 2 + 32 + rec_len] int32 = point | polygon | recognition tokens, probs [B, N, rec_len];
+ * instances beyond counts[b] (or N) are zero. */
+int omp_pack_spotting(const int32_t* points, const int32_t* poly, int poly_ld, const int32_t* rec, int rec_ld,
+                      const float* rec_probs, int prob_ld, const int32_t* row0, const int32_t* counts, int B, int N,
+                      int rec_len, int32_t* ids, float* probs, omp_stream_t s);
+
 /* ---- One decoder, many steps (the launch-bound inner loop runs from C++, optionally as a
  *      hipGraph replay).  Replaces Transformer.decode driven by decode_pt_seq / the poly and rec
  *      loops, transformer.py:74-141,252-284. */

@@ -307,7 +307,27 @@ def test_omp_ctx_is_per_thread_and_default_is_protected():
     assert seen['other'] == default                                # a new thread starts on the default context
     assert ops.current_context_handle() == default
     assert h.omp_ctx_destroy(ctypes.c_void_p(default)) != 0        # refused
+    # a context destroyed on THIS thread while ANOTHER thread still has it current: that thread must fall back to the default
+    # context on its next call instead of dereferencing freed memory, and the stale handle must be refused
+    go, done = threading.Event(), threading.Event()
+
+    def worker():
+        ops.make_context_current(ctx.handle)
+        seen['worker_before'] = ops.current_context_handle()
+        done.set()
+        go.wait(10)
+        seen['worker_after'] = ops.current_context_handle()
+    t = threading.Thread(target=worker)
+    t.start()
+    assert done.wait(10)
+    stale = ctx.handle
     ctx.destroy()
+    go.set()
+    t.join()
+    assert seen['worker_before'] == stale and seen['worker_after'] == default
+    assert h.omp_ctx_make_current(ctypes.c_void_p(stale)) != 0     # a destroyed handle cannot become current
+    assert h.omp_ctx_destroy(ctypes.c_void_p(stale)) != 0          # nor be destroyed twice
+    assert ops.current_context_handle() == default
 
 
 def test_cu_mask_words_are_balanced_over_xcds():

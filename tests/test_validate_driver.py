@@ -155,3 +155,32 @@ def test_validate_world2_gloo_shards_gathers_and_rank0_writes(tmp_path):
     assert (n0, n1) == (len(exp), 0)                       # only rank 0 returns / writes
     assert (imgs0, imgs1) == (shard0, shard1) and shard0 + shard1 == 7   # every rank decoded exactly its shard
     _same(json.load(open(os.path.join(str(tmp_path), 'results', 'ep001', 'unit_val.json'))), exp)
+
+
+def test_rank_items_reads_only_the_ranks_own_shard():
+    """a sharded validate must not decode the other ranks' images.  A torch DataLoader over a map-style dataset is
+    re-pointed at Subset(dataset, [lo, hi)): __getitem__ runs for this rank's indices only; sequences are sliced; unsized
+    iterables are refused for world > 1 instead of being materialised with list()."""
+    import pytest
+
+    class Counting(torch.utils.data.Dataset):
+        def __init__(self, n):
+            self.n, self.touched = n, []
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            self.touched.append(i)
+            return torch.full((3, 8, 8), float(i)), {'file_name': 'f%d' % i, 'orig_size': (8, 8)}
+
+    ds = Counting(10)
+    dl = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, num_workers=0, collate_fn=lambda b: b[0])
+    items, lo, hi = inf._rank_items(dl, 1, 3, False)
+    got = [int(img[0, 0, 0]) for img, _ in items]
+    assert (lo, hi) == udist.shard_range(10, 1, 3) and got == list(range(lo, hi)) and sorted(ds.touched) == list(range(lo, hi))
+    seq = list(range(7))
+    assert list(inf._rank_items(seq, 0, 2, False)[0]) == [0, 1, 2, 3] and list(inf._rank_items(seq, 1, 2, False)[0]) == [4, 5, 6]
+    assert inf._rank_items(seq, 1, 2, True)[0] is seq and inf._rank_items(seq, 0, 1, False)[0] is seq   # already sharded / single rank
+    with pytest.raises(TypeError):
+        inf._rank_items(iter(seq), 0, 2, False)
