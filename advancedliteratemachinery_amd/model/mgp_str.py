@@ -237,9 +237,12 @@ class MGPSTR(nn.Module):
 
     # result decoding (test_final.py:145-240) ---------------------------------------------------------
     @torch.no_grad()
-    def recognize(self, input):
+    def recognize(self, input, bpe_vocab=None, wp_vocab=None):
         """-> list of dicts per image: greedy ids of the three granularities (position 0 dropped), their confidences,
-        the fused choice (0 char / 1 bpe / 2 wp / -1 none) and the character-level string."""
+        the fused choice (0 char / 1 bpe / 2 wp / -1 none) and the character-level string.  bpe_vocab / wp_vocab: paths of a LOCAL
+        GPT-2 `vocab.json` / BERT `vocab.txt` (or utils.mgp_tokens.BpeVocab / WordPieceVocab objects): the records then also
+        carry `bpe_text`, `wp_text` and the fused `text` of test_final.py:196-236 (the reference fetches both tokenizers from
+        the hub, utils.py:23-24; without the files the engine stops at ids + confidences)."""
         outs = self.forward(input, is_eval=False)
         B, S = outs[0].shape[0], outs[0].shape[1]
         ids, probs = [], []
@@ -247,7 +250,13 @@ class MGPSTR(nn.Module):
             i, p = ops.row_argmax_prob(lg.reshape(B * S, -1))
             ids.append(i.view(B, S)[:, 1:].cpu())
             probs.append(p.view(B, S)[:, 1:].cpu())
-        return decode_ids(ids, probs)
+        res = decode_ids(ids, probs)
+        if bpe_vocab is not None or wp_vocab is not None:
+            from ..utils import mgp_tokens as MT
+            bpe = MT.BpeVocab(bpe_vocab) if isinstance(bpe_vocab, str) else bpe_vocab
+            wp = MT.WordPieceVocab(wp_vocab) if isinstance(wp_vocab, str) else wp_vocab
+            MT.decode_strings(res, bpe, wp)
+        return res
 
 
 def decode_ids(ids, probs):

@@ -649,11 +649,21 @@ def check_e2e(name, dtype_name='fp32', graph=False):
 #   * teacher-forced logits within BF16_LOGIT_REL of max|logit|;
 #   * at every teacher-forced position whose reference top-1/top-2 margin exceeds MARGIN_K x the measured logit error of
 #     that sequence, the engine's argmax equals the reference's (a decision can only flip inside the noise band);
-#   * free-running tokens: agreement fraction and first divergence are REPORTED (one flipped near-tie changes the rest
-#     of a greedy sequence), and gated exactly when the teacher-forced check saw no position inside the noise band.
-BF16_REL = dict(stage=0.04, fpn=0.04, memory=0.04, pos=0.01)
+#   * free-running tokens: UNCONDITIONAL floors per fixture on the fraction of tokens equal to the reference's (round 3; the
+#     round-2 gate was conditional on "no teacher-forced position inside the noise band" and never fired).  One flipped
+#     near-tie changes the rest of a greedy sequence, so the fraction moves by +-0.1 between kernel versions of equal accuracy
+#     (profiles/r03b_parity_report_fp32_residual.json vs r03d: rec 0.82 <-> 0.92 on spot_odd); the floors sit ~0.12 below the
+#     lowest value measured this round.  Point tokens are identical to the reference's on every fixture but spot_640, whose
+#     FIRST generated token is a reference near-tie inside the bf16 noise band (everything after it differs: 0.375).
+#     The engine that is token-exact is bf16x3 (test_parity_engine_bf16x3), not this one.
+#   * KIE (a free-running greedy walk): the result list is compared entity by entity and REPORTED; gated on being non-empty.
+BF16_REL = dict(stage=0.02, fpn=0.025, memory=0.025, pos=0.01)   # round 3 (fp32 residual stream): measured <= 0.0085 / 0.0096 / 0.0097
 BF16_LOGIT_REL = 0.03
 MARGIN_K = 2.0
+BF16_TOKEN_FLOOR = {   # fixture -> (pt, poly, rec) minimum fraction of tokens identical to the reference's
+    'spot_odd': (1.0, 0.70, 0.68), 'spot_224': (1.0, 0.82, 0.78), 'spot_1024': (1.0, 0.75, 0.78), 'spot_640': (0.30, 0.24, 0.16),
+    'spot_padded,img0': (1.0, 0.70, 0.68), 'spot_padded,img1': (1.0, 0.82, 0.78),
+}
 REPORT = []   # records of the measured errors (tools/parity_report.py dumps them for profiles/)
 
 
@@ -743,7 +753,10 @@ def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
         if f32:
             out.append(rec('e2e[%s,%s] kie result' % (name, dtype_name), 0 if same else 1, 0, str(res)[:120]))
         else:   # reported: the KIE walk is a free-running greedy decode (see the gate description above)
-            REPORT.append(dict(name='e2e[%s,bf16] kie result identical' % name, value=bool(same)))
+            n_same = sum(1 for a, b_ in zip(res or [], go or []) if a[0] == b_[0] and a[1] == b_[1])
+            REPORT.append(dict(name='e2e[%s,bf16] kie result identical' % name, value=bool(same), entities=len(res or []),
+                               reference_entities=len(go or []), entities_with_identical_text_and_class=n_same))
+            out.append(rec('e2e[%s,bf16] kie result non-empty like the reference' % name, 0 if bool(res) == bool(go) else 1, 0))
         return out
     # teacher-forced logits (decision-level parity without greedy cascades)
     tf = gold['tf']
@@ -777,14 +790,17 @@ def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
         out.append(rec('e2e[%s,%s] empty result' % (name, dtype_name), 0 if (res is None) == (go is None) else 1, 0))
         return out
     ids = [t.cpu() for t in res[0]]
-    exact = f32 or (tf and noisy_positions == 0)
-    for key, t in zip(('pt', 'poly', 'rec'), ids):
+    floors = BF16_TOKEN_FLOOR.get(name.replace(',graph', ''))
+    for ki, (key, t) in enumerate(zip(('pt', 'poly', 'rec'), ids)):
         same = t.shape == go[key].shape and bool((t == go[key]).all())
         frac = float((t.reshape(-1) == go[key].reshape(-1)).float().mean()) if t.shape == go[key].shape else 0.0
         REPORT.append(dict(name='e2e[%s,%s] %s tokens' % (name, dtype_name, key), identical=bool(same), match=frac,
                            first_divergence=_first_div(t, go[key]), n=int(go[key].numel())))
-        if exact:
+        if f32:
             out.append(rec('e2e[%s,%s] %s tokens' % (name, dtype_name, key), 0 if same else 1, 0, 'match=%.3f' % frac))
+        elif floors is not None:   # bf16: unconditional measured floor
+            out.append(rec('e2e[%s,%s] %s tokens >= %.2f of the reference\'s' % (name, dtype_name, key, floors[ki]), max(0.0, floors[ki] - frac), 0.0,
+                           'match=%.3f first divergence at %d' % (frac, _first_div(t, go[key]))))
     if res[1][0].shape == go['rec_probs'].shape and (f32 or all(bool((t == go[k]).all()) for k, t in zip(('pt', 'poly', 'rec'), ids) if t.shape == go[k].shape)):
         out.append(rec('e2e[%s,%s] rec probs' % (name, dtype_name), maxerr(res[1][0], go['rec_probs']), 1e-3 if f32 else 5e-2))
     return out
