@@ -1169,14 +1169,14 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   const bool f = dtype == OMP_F32;
   // PD key blocks in flight per wave: with one query tile a wave's whole slice is usually 4 blocks -> all of it
   if (q4) {
-    const bool nt = cx.cross_nt && n_groups >= 32;
+    const bool nt = cx.cross_nt == 2 || (cx.cross_nt && n_groups >= 32);
     switch (cx.cross_q4) {
       case 2: rc = launch_cross_q4<8, 1, false>(cp, n_groups, S, st); break;    // one block per step (round-2 start)
       case 4: rc = launch_cross_q4<8, 2, false>(cp, n_groups, S, st); break;    // A/B: chunks with temporal loads (an 80 KB ring, 4 chunks ahead, measured equal: r02y)
       default: rc = nt ? launch_cross_q4<8, 2, true>(cp, n_groups, S, st) : launch_cross_q4<8, 2, false>(cp, n_groups, S, st);
     }
   }
-  else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : ((cx.cross_nt && n_groups >= 32) ? launch_cross_t<bf16_t, 1, 4, true>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st));
+  else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : ((cx.cross_nt == 2 || (cx.cross_nt && n_groups >= 32)) ? launch_cross_t<bf16_t, 1, 4, true>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st));
   else if (qt == 2) rc = f ? launch_cross_t<float, 2, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 2, 2>(cp, n_groups, S, st);
   else rc = f ? launch_cross_t<float, 4, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 4, 2>(cp, n_groups, S, st);
   if (rc != OMP_OK) return rc;
@@ -1431,7 +1431,7 @@ extern "C" int omp_debug_self_attn_impl(int which) {
 }
 
 extern "C" int omp_debug_cross_nt(int on) {
-  omp_cur().cross_nt = on ? 1 : 0;
+  omp_cur().cross_nt = on == 2 ? 2 : (on ? 1 : 0);   // 2 = non-temporal at every size (A/B), 1 = from 32 groups per launch (default)
   return OMP_OK;
 }
 

@@ -117,6 +117,13 @@ def check_gemm():
                     if slabs[9][1] is not None:
                         out.append(rec('gemm[%s,k9 vs k5,V^T slab,B%d tok%d]' % (dn, Bn, tok), maxerr(slabs[9][1], slabs[5][1].float().cpu()), 0.0))
                 ops.force_gemm_kernel(9)
+                # per-position bias table (decoder q / k projections at thousands of rows) through the 256x256 kernel
+                Mb, Nb, Kb = 1500, 1536, 512
+                Ab, Wb = q(rnd(Mb, Kb, seed=21), dt), q(rnd(Nb, Kb, seed=22) / math.sqrt(Kb), dt)
+                tabb = rnd(9, Nb, seed=23)
+                rowb = torch.tensor([6], dtype=torch.int32, device=DEV)
+                yb = ops.gemm(Ab.to(DEV, dt), Wb.to(DEV, dt), tabb.to(DEV), bias_row=rowb, bias_row_stride=Nb)
+                out.append(rec('gemm[%s,k9,bias_row]' % dn, maxerr(yb, Ab @ Wb.t() + tabb[6]), tol))
                 continue
             # fp32 output + in-place fp32 residual (decoder), bias_row table, transposed store
             M, N, K = 24, 512, 512
