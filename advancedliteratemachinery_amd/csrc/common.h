@@ -66,7 +66,8 @@ struct omp_ctx {
   // kernel selectors (omp_debug_*): 0 = the measured default everywhere
   int force_gemm = 0;        // 0 auto, 3 rows, 4 small split-K, 5 dma 128x128, 6 dma 64x64 ring, 9 = 256x256 phase-interleaved, 15 = 5 + timestamps
   int cross_q4 = 1;          // 1 = LDS-ring kernel for 33..64 rows per image, 64-key chunks, non-temporal DMA; 2 = one block per step; 4 = chunks, temporal; 0 = register streaming
-  int cross_nt = 1;          // non-temporal K / V^T loads once >= 32 images share a launch
+  int cross_nt = 1;          // non-temporal K / V^T loads: 1 = always (the slabs are read once per launch and would evict the decoder weights from the
+                             // MALL: 8-image point phase 39.8 -> 37.2 ms, profiles/r03f_ab_*), 2 = only from 32 groups per launch (round 2), 0 = never
   int self_attn_impl = 0;    // 0 auto, 1 one wave per (row, head), 2 one wave per row
   int dec_fused = 0;         // 0 = fused few-row decoder kernels where they apply (csrc/decoder.hip: fused_step_ok), 1 = the launch-per-op path everywhere
   int swin_impl = 0;         // 0 matrix cores, 1 scalar cross-check kernel, 2 matrix cores with per-score table lookups

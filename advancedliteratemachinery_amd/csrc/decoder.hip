@@ -750,12 +750,22 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
 // done with c-1) -> refill the stages of c-1 with chunk c+D -> compute c with ONE running-max update, one
 // accumulator rescale and one cross-lane maximum (v_permlane swaps, no LDS round trip) per chunk.
 // ---------------------------------------------------------------------------------------------
-template <int NS, int CH, bool NT>
+// T = bf16 (32-key blocks) or float (16-key blocks: the fp32 slabs of the fp32 and bf16x3 engines; the register-streaming
+// kernel reached 1.6 TB/s there -- 1.66 ms per 160-image launch, 31 % of the parity engine's time, profiles/r03e_*).  A ring
+// stage is 8 KB either way (K then V^T); what differs is the LDS image of a block and its conflict-free swizzle:
+//   bf16: K = 32 rows (keys) x 128 B, V^T = 32 rows (two dims x 32 key slots) x 128 B, slot = chunk ^ (row & 7);
+//   f32 : K = 16 rows (keys) x 256 B, slot = chunk ^ row (16 chunks of 16 B); V^T = 64 rows (dims) x 64 B, slot = chunk ^ t(row >> 2
+//         & 3) with t = {0, 2, 3, 1}: the four rows a ds_read_b128 lane group touches in one 256-byte bank row get four
+//         different slots.
+template <typename T, int NS, int CH, bool NT>
 __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
-  typedef bf16_t T;
   typedef Mma<T> MM;
-  typedef MM::frag frag;
-  constexpr int KB = 32, BLKB = 8192;   // keys per block; bytes per ring stage (K then V^T)
+  typedef CrossTraits<T> CT;
+  typedef typename MM::frag frag;
+  constexpr bool F32 = sizeof(T) == 4;
+  constexpr int KB = CT::KB, BLKB = 8192;   // keys per block; bytes per ring stage (K then V^T)
+  constexpr int SPB = KB / 4;               // scores per lane per block
+  constexpr int QS = CT::DSTEPS;            // k-steps over the 64 head dims
   constexpr int SLOTS = NS / CH, D = SLOTS - 1;   // a chunk = CH blocks; D chunks in flight ahead of the one in use
   static_assert(NS % CH == 0 && D >= 1 && 2 * CH * (D - 1) <= 28, "ring geometry");
   extern __shared__ __attribute__((aligned(16))) char ring[];
@@ -768,12 +778,23 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
   if (kend > p.M) kend = p.M;
   const int nblk = kbeg < kend ? (kend - kbeg + KB - 1) / KB : 0;
   const int nchunk = (nblk + CH - 1) / CH;
+  auto tsw = [](int q) -> int { return (0x1320 >> (q * 4)) & 3; };   // t = {0, 2, 3, 1}
 
   const int64_t slab = (int64_t)img * p.img_stride + (int64_t)h * p.Mpad * 64;
-  // DMA: lane l of this wave's instruction fills slot (l & 7) of row 8*wave + (l >> 3) of the block image
-  const int dr = lane >> 3, dc = (lane & 7) ^ dr;
-  const T* ksrc = reinterpret_cast<const T*>(p.K) + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
-  const T* vsrc = reinterpret_cast<const T*>(p.V) + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
+  // DMA: this wave's instruction fills bytes [1024 * wave, + 1024) of the K image and of the V^T image of a block, lane-linearly;
+  // the swizzle is applied to the per-lane SOURCE address
+  const T* ksrc;
+  const T* vsrc;
+  if constexpr (F32) {
+    const int kr = wave * 4 + (lane >> 4), kc = (lane & 15) ^ kr;                 // K row (key) and the chunk that lands in this lane's slot
+    const int vr = wave * 16 + (lane >> 2), vc_ = (lane & 3) ^ tsw((lane >> 4) & 3);   // V^T row (dim): (vr >> 2) & 3 == (lane >> 4) & 3
+    ksrc = reinterpret_cast<const T*>(p.K) + slab + kr * 64 + kc * 4;
+    vsrc = reinterpret_cast<const T*>(p.V) + slab + vr * 16 + vc_ * 4;
+  } else {
+    const int dr = lane >> 3, dc = (lane & 7) ^ dr;
+    ksrc = reinterpret_cast<const T*>(p.K) + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
+    vsrc = reinterpret_cast<const T*>(p.V) + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
+  }
   // chunk c -> ring stages slot * CH .. slot * CH + CH - 1.  A ragged last chunk re-requests the last valid block for
   // its missing ones: their keys are masked below, but their V^T image must hold finite numbers (0 x NaN = NaN)
   auto issue_chunk = [&](int c, int slot) {
@@ -795,29 +816,36 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
     if (t < nchunk) issue_chunk(t, t);
 
   // fragment byte offsets inside a stage
-  int koff[2][2], voff[4];
+  int koff[CT::NSB][QS], voff[4];
+  if constexpr (F32) {
 #pragma unroll
-  for (int sb = 0; sb < 2; ++sb)
+    for (int st = 0; st < QS; ++st) koff[0][st] = li * 256 + (((st * 4 + g) ^ li) << 4);
 #pragma unroll
-    for (int st = 0; st < 2; ++st) koff[sb][st] = (sb * 16 + li) * 128 + (((st * 4 + g) ^ (li & 7)) << 4);
+    for (int dt = 0; dt < 4; ++dt) voff[dt] = 4096 + (dt * 16 + li) * 64 + ((g ^ tsw(li >> 2)) << 4);
+  } else {
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    const int rw = dt * 8 + (li >> 1), c = (li & 1) * 4 + g;
-    voff[dt] = 4096 + rw * 128 + ((c ^ (rw & 7)) << 4);
+    for (int sb = 0; sb < CT::NSB; ++sb)
+#pragma unroll
+      for (int st = 0; st < QS; ++st) koff[sb][st] = (sb * 16 + li) * 128 + (((st * 4 + g) ^ (li & 7)) << 4);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int rw = dt * 8 + (li >> 1), c = (li & 1) * 4 + g;
+      voff[dt] = 4096 + rw * 128 + ((c ^ (rw & 7)) << 4);
+    }
   }
 
   // Q fragments (B operand) of this wave's tile, 1/sqrt(64) folded in
-  frag qf[2];
+  frag qf[QS];
   {
     int qi = wave * 16 + li;
     if (qi > nrows - 1) qi = nrows - 1;
-    const T* qp = reinterpret_cast<const T*>(p.q) + (int64_t)(row0 + qi) * p.ldq + h * DH + g * 8;
+    const T* qp = reinterpret_cast<const T*>(p.q) + (int64_t)(row0 + qi) * p.ldq + h * DH + g * MM::KPL;
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      float tmp[8];
-      unpack16(ld16<T>(qp + st * 32), tmp);
+    for (int st = 0; st < QS; ++st) {
+      float tmp[MM::KPL];
+      unpack16(ld16<T>(qp + st * MM::KSTEP), tmp);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) tmp[i] *= 0.125f;
+      for (int i = 0; i < MM::KPL; ++i) tmp[i] *= 0.125f;
       pack16(tmp, qf[st]);
     }
   }
@@ -828,6 +856,9 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // key of score i of a chunk: block i / SPB, inside it (bf16: second 16-key half, then) 4 g + r
+  auto key_of = [&](int k0, int i) -> int { return k0 + (i / SPB) * KB + (((i % SPB) >> 2) & 1) * 16 + g * 4 + (i & 3); };
+
   int sl_c = 0, sl_i = D;   // slot in use, slot to refill (the one used by the previous chunk)
   for (int c = 0; c < nchunk; ++c) {
     const int after = nchunk - 1 - c;
@@ -835,54 +866,58 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
     __builtin_amdgcn_s_barrier();
     if (c + D < nchunk) issue_chunk(c + D, sl_i);
     if (active) {
-      float sc[CH * 8];
+      float sc[CH * SPB];
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         const char* base = ring + (sl_c * CH + j) * BLKB;
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-          const frag k0f = *reinterpret_cast<const frag*>(base + koff[sb][0]);
-          const frag k1f = *reinterpret_cast<const frag*>(base + koff[sb][1]);
+        for (int sb = 0; sb < CT::NSB; ++sb) {
           f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
-          MM::mma(sacc, k0f, qf[0]);
-          MM::mma(sacc, k1f, qf[1]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sc[j * 8 + sb * 4 + r] = sacc[r];
+          for (int st = 0; st < QS; ++st) MM::mma(sacc, *reinterpret_cast<const frag*>(base + koff[sb][st]), qf[st]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[j * SPB + sb * 4 + r] = sacc[r];
         }
       }
       // masking, branch-free per element (both conditions are wave-uniform): key padding mask bytes are all
       // loaded before any is used; the ragged tail of the split needs only the index compare
       const int k0 = kbeg + c * CH * KB;
       if (km != nullptr) {
-        uint8_t mk[CH * 8];
+        uint8_t mk[CH * SPB];
 #pragma unroll
-        for (int i = 0; i < CH * 8; ++i) {
-          const int kk = k0 + (i >> 3) * KB + ((i >> 2) & 1) * 16 + g * 4 + (i & 3);
+        for (int i = 0; i < CH * SPB; ++i) {
+          const int kk = key_of(k0, i);
           mk[i] = km[kk < p.M ? kk : p.M - 1];
         }
 #pragma unroll
-        for (int i = 0; i < CH * 8; ++i) {
-          const int kk = k0 + (i >> 3) * KB + ((i >> 2) & 1) * 16 + g * 4 + (i & 3);
+        for (int i = 0; i < CH * SPB; ++i) {
+          const int kk = key_of(k0, i);
           const bool dead = (kk >= kend) | (mk[i] != 0);
           sc[i] = dead ? -INFINITY : sc[i];
         }
       } else if (k0 + CH * KB > kend) {
 #pragma unroll
-        for (int i = 0; i < CH * 8; ++i) {
-          const int kk = k0 + (i >> 3) * KB + ((i >> 2) & 1) * 16 + g * 4 + (i & 3);
+        for (int i = 0; i < CH * SPB; ++i) {
+          const int kk = key_of(k0, i);
           sc[i] = (kk >= kend) ? -INFINITY : sc[i];
         }
       }
       float bmax = sc[0];
 #pragma unroll
-      for (int i = 1; i < CH * 8; ++i) bmax = fmaxf(bmax, sc[i]);
+      for (int i = 1; i < CH * SPB; ++i) bmax = fmaxf(bmax, sc[i]);
       bmax = quad_group_max(bmax);        // the 4 lane groups hold different keys of the same query
       const float mn = fmaxf(m, bmax);
       const float mref = (mn == -INFINITY) ? 0.f : mn;   // all keys so far masked: exp(-inf - 0) = 0, not NaN
-      const float alpha = __expf(m - mref);
-      float ps = 0.f;
+      float alpha, ps = 0.f;
+      if constexpr (F32) {     // the fp32 engines keep the accurate exponential (their parity gate is 1e-3 on logits)
+        alpha = expf(m - mref);
 #pragma unroll
-      for (int i = 0; i < CH * 8; ++i) { sc[i] = __expf(sc[i] - mref); ps += sc[i]; }
+        for (int i = 0; i < CH * SPB; ++i) { sc[i] = expf(sc[i] - mref); ps += sc[i]; }
+      } else {
+        alpha = __expf(m - mref);
+#pragma unroll
+        for (int i = 0; i < CH * SPB; ++i) { sc[i] = __expf(sc[i] - mref); ps += sc[i]; }
+      }
       lpart = lpart * alpha + ps;
       m = mn;
 #pragma unroll
@@ -892,7 +927,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         const char* base = ring + (sl_c * CH + j) * BLKB;
-        const frag pf = CrossTraits<T>::pfrag(sc + j * 8);
+        const frag pf = CT::pfrag(sc + j * SPB);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const frag vc = *reinterpret_cast<const frag*>(base + voff[dt]);
@@ -912,9 +947,11 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
     T* dst = reinterpret_cast<T*>(p.out) + (int64_t)(row0 + qi) * p.ldo + h * DH + g * 4;
     const float inv = 1.0f / l;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<bf16x4*>(dst + dt * 16) = bf16x4{(bf16_t)(ot[dt][0] * inv), (bf16_t)(ot[dt][1] * inv),
-                                                          (bf16_t)(ot[dt][2] * inv), (bf16_t)(ot[dt][3] * inv)};
+    for (int dt = 0; dt < 4; ++dt) {
+      if constexpr (F32) *reinterpret_cast<f32x4*>(dst + dt * 16) = f32x4{ot[dt][0] * inv, ot[dt][1] * inv, ot[dt][2] * inv, ot[dt][3] * inv};
+      else *reinterpret_cast<bf16x4*>(dst + dt * 16) = bf16x4{(bf16_t)(ot[dt][0] * inv), (bf16_t)(ot[dt][1] * inv),
+                                                               (bf16_t)(ot[dt][2] * inv), (bf16_t)(ot[dt][3] * inv)};
+    }
   } else {
     float* dst = p.partial + (((int64_t)(row0 + qi) * p.nH + h) * S + sp) * CROSS_PSTR;
     if (g == 0) { dst[0] = m; dst[1] = l; }
@@ -1132,10 +1169,10 @@ int launch_merge(const CrossP& cp, int S, hipStream_t st) {
 }
 
 
-template <int NS, int CH, bool NT>
+template <typename T, int NS, int CH, bool NT>
 int launch_cross_q4(const CrossP& cp, int n_groups, int S, hipStream_t st) {
   const size_t smem = (size_t)NS * 8192;
-  auto kern = dec_cross_attn_q4_kernel<NS, CH, NT>;
+  auto kern = dec_cross_attn_q4_kernel<T, NS, CH, NT>;
   static bool done = false;   // per template instantiation
   if (!done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -1157,7 +1194,7 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   const int KB = dtype == OMP_F32 ? 16 : 32;
   if (cp.Mpad % KB != 0 || cp.Mpad < cp.M) { omp_set_error("omp_dec_cross_attn_step: Mpad %d must be a multiple of %d and >= M", cp.Mpad, KB); return OMP_ERR_INVALID; }
   const omp_ctx& cx = omp_cur();
-  const bool q4 = cx.cross_q4 != 0 && dtype == OMP_BF16 && qt == 4;   // waves own query tiles, not key slices
+  const bool q4 = cx.cross_q4 != 0 && qt == 4;   // waves own query tiles, not key slices (bf16 and fp32 slabs alike)
   const int slices = q4 ? S : S * 4;
   cp.kpw = (((cp.M + slices - 1) / slices + KB - 1) / KB) * KB;
   const bool prof = omp_prof_active(OMP_PROF_CROSS) && !g_capturing;
@@ -1169,14 +1206,16 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   const bool f = dtype == OMP_F32;
   // PD key blocks in flight per wave: with one query tile a wave's whole slice is usually 4 blocks -> all of it
   if (q4) {
-    const bool nt = cx.cross_nt == 2 || (cx.cross_nt && n_groups >= 32);
+    const bool nt = cx.cross_nt == 1 || (cx.cross_nt == 2 && n_groups >= 32);
     switch (cx.cross_q4) {
-      case 2: rc = launch_cross_q4<8, 1, false>(cp, n_groups, S, st); break;    // one block per step (round-2 start)
-      case 4: rc = launch_cross_q4<8, 2, false>(cp, n_groups, S, st); break;    // A/B: chunks with temporal loads (an 80 KB ring, 4 chunks ahead, measured equal: r02y)
-      default: rc = nt ? launch_cross_q4<8, 2, true>(cp, n_groups, S, st) : launch_cross_q4<8, 2, false>(cp, n_groups, S, st);
+      case 2: rc = f ? launch_cross_q4<float, 8, 1, false>(cp, n_groups, S, st) : launch_cross_q4<bf16_t, 8, 1, false>(cp, n_groups, S, st); break;    // one block per step (round-2 start)
+      case 4: rc = f ? launch_cross_q4<float, 8, 2, false>(cp, n_groups, S, st) : launch_cross_q4<bf16_t, 8, 2, false>(cp, n_groups, S, st); break;    // A/B: chunks with temporal loads (an 80 KB ring, 4 chunks ahead, measured equal: r02y)
+      default:
+        if (f) rc = nt ? launch_cross_q4<float, 8, 2, true>(cp, n_groups, S, st) : launch_cross_q4<float, 8, 2, false>(cp, n_groups, S, st);
+        else rc = nt ? launch_cross_q4<bf16_t, 8, 2, true>(cp, n_groups, S, st) : launch_cross_q4<bf16_t, 8, 2, false>(cp, n_groups, S, st);
     }
   }
-  else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : ((cx.cross_nt == 2 || (cx.cross_nt && n_groups >= 32)) ? launch_cross_t<bf16_t, 1, 4, true>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st));
+  else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : ((cx.cross_nt == 1 || (cx.cross_nt == 2 && n_groups >= 32)) ? launch_cross_t<bf16_t, 1, 4, true>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st));
   else if (qt == 2) rc = f ? launch_cross_t<float, 2, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 2, 2>(cp, n_groups, S, st);
   else rc = f ? launch_cross_t<float, 4, 2>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 4, 2>(cp, n_groups, S, st);
   if (rc != OMP_OK) return rc;
@@ -1431,7 +1470,7 @@ extern "C" int omp_debug_self_attn_impl(int which) {
 }
 
 extern "C" int omp_debug_cross_nt(int on) {
-  omp_cur().cross_nt = on == 2 ? 2 : (on ? 1 : 0);   // 2 = non-temporal at every size (A/B), 1 = from 32 groups per launch (default)
+  omp_cur().cross_nt = on == 2 ? 2 : (on ? 1 : 0);   // 1 = non-temporal at every size (default), 2 = only from 32 groups per launch (round 2), 0 = never
   return OMP_OK;
 }
 

@@ -342,7 +342,7 @@ class Decoder(object):
         kb = 16 if self.dtype == torch.float32 else 32
         if self.n_split_override:
             return self.n_split_override
-        if qt == 4 and self.dtype == torch.bfloat16:
+        if qt == 4:   # bf16 and fp32 slabs alike (csrc/decoder.hip: dec_cross_attn_q4_kernel)
             # LDS-ring kernel (waves own query tiles, the workgroup streams one key range): enough workgroups
             # to put two on every CU, but at least 4 key blocks each
             S = 1

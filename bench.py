@@ -77,7 +77,7 @@ def parse():
     p.add_argument('--phase-times', action='store_true', help='also print a per-phase time breakdown (stderr)')
     p.add_argument('--overlap', type=int, default=1, help='polygon || recognition decoders on two streams')
     p.add_argument('--q4-mode', type=int, default=1, help='A/B: omp_debug_cross_q4 selector (1 default, 2 = one 32-key block per step, 4 = chunks with temporal loads)')
-    p.add_argument('--cross-nt', type=int, default=1, help='A/B: omp_debug_cross_nt selector (1 = non-temporal K / V^T loads from 32 images per launch, 2 = always, 0 = never)')
+    p.add_argument('--cross-nt', type=int, default=1, help='A/B: omp_debug_cross_nt selector (1 = non-temporal K / V^T loads always (default), 2 = only from 32 images per launch, 0 = never)')
     p.add_argument('--lanes', type=int, default=int(os.environ.get('OMP355_LANES', '1')),
                    help='step groups in flight per GPU (engine/pipeline.py): they overlap on separate HIP streams')
     p.add_argument('--coalesce', type=int, default=int(os.environ.get('OMP355_COALESCE', '64')),
