@@ -1342,6 +1342,55 @@ int gemm(const omp_decoder_plan* P, const void* A, int64_t lda, const void* W, i
   return omp_gemm_bias_act(&a, st);
 }
 
+// bf16x3 product of a decoder step (plan->gemm_x3): A = split-bf16 pair rows [R, 2 K0], W = [N, 3 K0] image of the fp32 weight,
+// fp32 or split-pair destination (out_dtype OMP_F32 / OMP_BF16X2), fp32 residual
+int gemm_x3(const omp_decoder_plan* P, const void* A, const void* W, int K0, int N, const float* bias, const int32_t* bias_row,
+            int64_t bias_stride, const void* res, void* C, int out_dtype, int act, hipStream_t st) {
+  omp_gemm_args a{};
+  a.A = A; a.lda = 2 * (int64_t)K0; a.W = W; a.ldw = 3 * (int64_t)K0; a.bias = bias; a.bias_row = bias_row; a.bias_row_stride = bias_stride;
+  a.residual = res; a.ldr = N; a.C = C; a.ldc = out_dtype == OMP_BF16X2 ? 2 * (int64_t)N : N; a.M = P->R; a.N = N; a.K = 3 * K0;
+  a.dtype = OMP_BF16; a.out_dtype = out_dtype; a.act = act; a.a_wrap = 2 * K0;
+  return omp_gemm_bias_act(&a, st);
+}
+
+// one pre-norm layer stack + head of the bf16x3 engine's many-row phases: fp32 residual stream / caches / slabs / attention
+// kernels, every product on the bf16 matrix cores as three bf16 products of split operands
+int step_launch_x3(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
+  const int d = P->d_model, R = P->R;
+  const int S2 = OMP_BF16X2, F = OMP_F32;
+  CrossP cp;
+  cp.q = P->q; cp.ldq = d; cp.img_stride = P->kv_img_stride; cp.Mpad = P->Mpad;
+  cp.kmask = P->key_mask; cp.groups = P->tiles; cp.out = P->att; cp.ldo = d;
+  cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R; cp.kpw = 0;
+  RUN(omp_dec_embed_ln(P->seq, P->seq_ld, P->d_pos, P->word_emb, P->pos_tab, P->emb_g, P->emb_b, P->x, nullptr, F, R, d, P->eps, st));
+  void* ys = P->y;       // [R, 2d] bf16 split pairs (the bytes of the fp32 [R, d] buffer)
+  void* as = P->ffh;     // attention outputs as split pairs (the FFN hidden buffer is free until ff1)
+  for (int li = 0; li < P->n_layers; ++li) {
+    const omp_dec_layer& L = P->layers[li];
+    cp.K = L.crossK; cp.V = L.crossVt;
+    RUN(omp_layernorm(P->x, F, L.n1_g, L.n1_b, ys, S2, nullptr, R, d, P->eps, st));
+    RUN(gemm_x3(P, ys, L.sa_in_w, d, 3 * d, L.sa_bias_tab, P->d_pos, 3 * d, nullptr, P->qkv, F, OMP_ACT_NONE, st));
+    RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, F, R, P->n_heads, d, P->Lmax, st));
+    RUN(omp_split_bf16(reinterpret_cast<const float*>(P->att), d, as, 2 * d, R, d, 0, st));
+    RUN(gemm_x3(P, as, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x, F, OMP_ACT_NONE, st));
+    RUN(omp_layernorm(P->x, F, L.n2_g, L.n2_b, ys, S2, nullptr, R, d, P->eps, st));
+    RUN(gemm_x3(P, ys, L.ca_q_w, d, d, L.ca_qbias_tab, P->d_pos, d, nullptr, P->q, F, OMP_ACT_NONE, st));
+    RUN(launch_cross(cp, P->n_tiles, F, P->n_split, P->q_tiles, st));
+    RUN(omp_split_bf16(reinterpret_cast<const float*>(P->att), d, as, 2 * d, R, d, 0, st));
+    RUN(gemm_x3(P, as, L.ca_out_w, d, d, L.ca_out_b, nullptr, 0, P->x, P->x, F, OMP_ACT_NONE, st));
+    RUN(omp_layernorm(P->x, F, L.n3_g, L.n3_b, ys, S2, nullptr, R, d, P->eps, st));
+    RUN(gemm_x3(P, ys, L.ff1_w, d, P->d_ff, L.ff1_b, nullptr, 0, nullptr, P->ffh, S2, OMP_ACT_RELU, st));
+    RUN(gemm_x3(P, P->ffh, L.ff2_w, P->d_ff, d, L.ff2_b, nullptr, 0, P->x, P->x, F, OMP_ACT_NONE, st));
+  }
+  if (do_head) {
+    RUN(omp_layernorm(P->x, F, P->fn_g, P->fn_b, ys, S2, nullptr, R, d, P->eps, st));
+    RUN(gemm_x3(P, ys, P->h0_w, d, d, P->h0_b, nullptr, 0, nullptr, P->hh0, S2, OMP_ACT_RELU, st));
+    RUN(gemm_x3(P, P->hh0, P->h1_w, d, d, P->h1_b, nullptr, 0, nullptr, P->hh1, S2, OMP_ACT_RELU, st));
+    RUN(gemm_x3(P, P->hh1, P->h2_w, d, P->vocab, P->h2_b, nullptr, 0, nullptr, P->logits, F, OMP_ACT_NONE, st));
+  }
+  return OMP_OK;
+}
+
 // y = LN(x) @ W^T (+bias...): fused LayerNorm prologue when the phase has <= 64 rows (split-K small-M
 // kernel), otherwise a LayerNorm launch followed by the tiled GEMM.
 int ln_gemm(const omp_decoder_plan* P, const float* g, const float* b, const void* W, int N, const float* bias,
@@ -1384,6 +1433,11 @@ int launch_fused_self_attn(const omp_decoder_plan* P, const omp_dec_layer& L, bo
 
 int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
   const int d = P->d_model, R = P->R, T = P->dtype;
+  if (P->gemm_x3) {
+    OMP_CHECK_ARG(T == OMP_F32 && P->pre_norm && R > 64 && d % 64 == 0 && P->d_ff % 64 == 0,
+                  "omp_decoder_run: gemm_x3 plans are fp32, pre-norm, more than 64 rows, widths multiples of 64");
+    return step_launch_x3(P, do_head, st);
+  }
   const bool fused = fused_step_ok(P);
   // embedding: pre-norm needs only the fp32 stream; post-norm also the T copy (fused: layer 0's first kernel embeds)
   if (!fused)

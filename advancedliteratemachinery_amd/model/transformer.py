@@ -188,6 +188,19 @@ class Decoder(object):
             self.Wk_all, self.bk_all = mat(torch.cat(wk, 0)), torch.cat(bk, 0).contiguous()
             self.Wv_all, self.bv_all = mat(torch.cat(wv, 0)), torch.cat(bv, 0).contiguous()
         self.NL = len(KINDS) * self.L
+        self._x3_cache = {}   # kind -> (layers, head) with every matrix as its [w_hi | w_hi | w_lo] image (bf16x3 engine, R > 64)
+
+    X3_MIN_ROWS = 65    # phases with more rows run their products as split-bf16 products (csrc/decoder.hip: step_launch_x3)
+
+    def _x3_weights(self, kind):
+        """[out, 3 in] bf16 images of decoder `kind`'s matrices, built on first use (the fp32 masters stay bound for the
+        few-row phases, whose weight-streaming kernels are fp32)."""
+        if kind not in self._x3_cache:
+            mats = ('sa_in_w', 'sa_out_w', 'ca_q_w', 'ca_out_w', 'ff1_w', 'ff2_w')
+            layers = [{n: ops.split_weight3(w[n]) for n in mats} for w in self.layers[kind]]
+            head = [ops.split_weight3(w) for w, _ in self.head[kind]]
+            self._x3_cache[kind] = (layers, head)
+        return self._x3_cache[kind]
 
     # -- memory K/V: once per batch ---------------------------------------------------------------
     def project_memory(self, memory, mem_pos, B, M, key_mask):
@@ -255,6 +268,9 @@ class Decoder(object):
         esz = 4 if self.dtype == torch.float32 else 2
         P.dtype, P.n_layers, P.d_model, P.n_heads, P.d_ff, P.vocab = ops.dt(self.dtype), self.L, d, self.nH, self.ff, self.V
         P.pre_norm = 1 if a.tfm_pre_norm else 0
+        use_x3 = bool(self.x3 and a.tfm_pre_norm and ph.R >= self.X3_MIN_ROWS and d % 64 == 0 and self.ff % 64 == 0)
+        P.gemm_x3 = 1 if use_x3 else 0
+        x3_layers, x3_head = self._x3_weights(ph.kind) if use_x3 else (None, None)
         P.R, P.Lmax, P.M, P.Mpad, P.n_tiles, P.q_tiles, P.n_split, P.n_prompt = (ph.R, ph.Lmax, kv['M'], kv['Mpad'], len(tiles), qt,
                                                                                  ph.n_split, n_prompt)
         P.eps = LN_EPS
@@ -268,7 +284,7 @@ class Decoder(object):
             Lc = P.layers[l]
             for name in ('sa_in_w', 'sa_bias_tab', 'sa_out_w', 'sa_out_b', 'ca_q_w', 'ca_qbias_tab', 'ca_out_w',
                          'ca_out_b', 'ff1_w', 'ff1_b', 'ff2_w', 'ff2_b', 'n1_g', 'n1_b', 'n2_g', 'n2_b', 'n3_g', 'n3_b'):
-                setattr(Lc, name, w[name].data_ptr())
+                setattr(Lc, name, (x3_layers[l][name] if use_x3 and name in x3_layers[l] else w[name]).data_ptr())
             Lc.kcache, Lc.vcache = ph.kc[l].data_ptr(), ph.vc[l].data_ptr()
             off = (kidx * self.L + l) * slab * esz
             Lc.crossK = kv['K'].data_ptr() + off
@@ -276,7 +292,8 @@ class Decoder(object):
         P.word_emb, P.pos_tab = self.word.data_ptr(), self.pos_tab[ph.kind].data_ptr()
         P.emb_g, P.emb_b = self.emb_g.data_ptr(), self.emb_b.data_ptr()
         P.fn_g, P.fn_b = self.fn[ph.kind][0].data_ptr(), self.fn[ph.kind][1].data_ptr()
-        (P.h0_w, P.h0_b), (P.h1_w, P.h1_b), (P.h2_w, P.h2_b) = [(w.data_ptr(), b.data_ptr()) for w, b in self.head[ph.kind]]
+        (P.h0_w, P.h0_b), (P.h1_w, P.h1_b), (P.h2_w, P.h2_b) = [((x3_head[i] if use_x3 else w).data_ptr(), b.data_ptr())
+                                                                 for i, (w, b) in enumerate(self.head[ph.kind])]
         P.kv_img_stride = img_stride
         P.key_mask = kv['key_mask'].data_ptr() if kv['key_mask'] is not None else None
         P.tiles = ph.tiles.data_ptr()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 13
+#define OMP_ABI_VERSION 14
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -275,6 +275,10 @@ typedef struct {
 typedef struct {
   int32_t dtype, n_layers, d_model, n_heads, d_ff, vocab, pre_norm;
   int32_t R, Lmax, M, Mpad, n_tiles, q_tiles, n_split, n_prompt; /* n_tiles = row groups, see omp_dec_cross_attn_step */
+  /* gemm_x3 = 1 (dtype OMP_F32, pre_norm, R > 64: the many-row phases of the bf16x3 engine): every matrix pointer below
+   * (sa_in_w ... ff2_w, h0_w ... h2_w) is the [out, 3 * in] bf16 image [w_hi | w_hi | w_lo] of the fp32 weight and the step's
+   * products run as split-bf16 products (omp_gemm_args.a_wrap); activations, caches, slabs and every other kernel stay fp32. */
+  int32_t gemm_x3;
   float eps;
   omp_dec_layer layers[OMP_MAX_DEC_LAYERS];
   const float *word_emb, *pos_tab, *emb_g, *emb_b, *fn_g, *fn_b;

@@ -602,6 +602,45 @@ def check_sampling_block():
     return [rec('sampling: workgroup-per-row kernel with fused advance == wave-per-row kernel + advance launch [fp32 tokens, probs]', bad, 0)]
 
 
+def check_decoder_x3(with_mask=True):
+    """Many-row phases of the bf16x3 engine (omp_decoder_plan.gemm_x3: every product of the step as three bf16 products of split
+    operands, everything else fp32): teacher-forced logits of the three decoders for 103 rows against the oracle, at the fp32
+    engine's tolerance, and against the fp32 engine itself."""
+    out = []
+    args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True)
+    sd = weights.make_state_dict(args, seed=2, depths=(2, 2, 2, 2))
+    B, M, d = 2, 90, 512
+    mem, pos = rnd(B * M, d, seed=1), rnd(B * M, d, seed=2)
+    kmask = torch.zeros(B, M, dtype=torch.bool)
+    if with_mask:
+        kmask[1, 70:] = True
+    mem_pos = mem + pos
+    counts = [70, 33]
+    R = sum(counts)
+    g = torch.Generator().manual_seed(5)
+    seqs = {kind: torch.randint(0, args.num_classes - 1, (R, L), generator=g) for kind, L in (('pt', 6), ('poly', 7), ('rec', 5))}
+    lgs = {}
+    for eng in ('bf16x3', 'fp32'):
+        model = build_model(args, sd, (2, 2, 2, 2), ENGINES[eng])
+        enc, dec = model.engine()
+        kv = dec.project_memory(mem.to(DEV), mem_pos.to(DEV), B, M, kmask.to(torch.uint8).to(DEV) if with_mask else None)
+        lgs[eng] = {kind: dec.teacher_forced_logits(kind, kv, sq, counts, 3).cpu() for kind, sq in seqs.items()}
+        if eng == 'bf16x3':
+            ph = [p_ for p_ in dec._phases.values() if p_.R == R]
+            out.append(rec('decoder_x3: the %d-row phases run gemm_x3 plans' % R, 0 if ph and all(p_.plan.gemm_x3 == 1 for p_ in ph) else 1, 0))
+    for kind, sq in seqs.items():
+        worst, r0, scale = 0.0, 0, 0.0
+        for b in range(B):
+            n = counts[b]
+            ref = O.decode(sd, args, sq[r0:r0 + n], mem.reshape(B, M, d)[b].unsqueeze(1), kmask[b:b + 1], pos.reshape(B, M, d)[b].unsqueeze(1), kind)
+            worst = max(worst, (lgs['bf16x3'][kind][r0:r0 + n] - ref).abs().max().item())
+            scale = max(scale, ref.abs().max().item())
+            r0 += n
+        out.append(rec('decoder_x3_logits[%s,mask=%s] vs oracle' % (kind, with_mask), worst, 2e-3, 'max|logit|=%.2f' % scale))
+        out.append(rec('decoder_x3_logits[%s,mask=%s] vs fp32 engine' % (kind, with_mask), (lgs['bf16x3'][kind] - lgs['fp32'][kind]).abs().max().item(), 2e-3))
+    return out
+
+
 def check_decoder_long(dtype_name='fp32'):
     """BASELINE config 4 as far as the reference allows it: the decoders' position tables hold 1024 entries
     (transformer.py:475), so the longest sequence is 1023 input positions.  Teacher-forced logits of the point

@@ -36,6 +36,11 @@ def test_decoder_fused_few_row_kernels(C, with_mask):
     _assert_all(C.check_decoder_fused(with_mask))
 
 
+@pytest.mark.parametrize('with_mask', [True, False])
+def test_decoder_x3_many_row_phases(C, with_mask):
+    _assert_all(C.check_decoder_x3(with_mask))
+
+
 def test_sampling_block_kernel(C):
     _assert_all(C.check_sampling_block())
 
