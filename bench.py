@@ -749,16 +749,19 @@ def main():
                     instances_per_image=Nl, note='table-recognition stand-in: point sequence at the 1024-entry position-table limit '
                                                  '(2 x 508 tokens + 6 prompt), then 508 polygon + recognition rows per image; %s engine' % a.dtype)
 
+    # the two legs on the main model first (same thermal / cache state as the headline they are compared with), then the legs
+    # that build other models (r03e / r03i: batch8 measured after the config legs read 118-121 img/s, 152-155 straight after
+    # the headline on the same code)
+    if rank == 0 and world == 1 and not a.no_batch8:
+        leg('batch8', batch8_leg)
+    if rank == 0 and world == 1 and not a.no_eos_run:
+        leg('eos_run', eos_leg)
     if rank == 0 and world == 1 and not a.no_parity_leg and a.dtype == 'bf16':
         leg('parity_engine', parity_leg)
     if rank == 0 and world == 1 and not a.no_config_legs:
         leg('kie', kie_leg)
         leg('mgp_str', mgp_leg)
         leg('long_pt', long_pt_leg)
-    if rank == 0 and world == 1 and not a.no_batch8:
-        leg('batch8', batch8_leg)
-    if rank == 0 and world == 1 and not a.no_eos_run:
-        leg('eos_run', eos_leg)
 
     if a.phase_times and rank == 0:
         def one_step():

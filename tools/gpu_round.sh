@@ -2,7 +2,7 @@
 # One GPU-box session: parity tests, PMC passes (HBM bytes of the cross-attention kernels), bench line,
 # rocprofv3 kernel stats.   usage: tools/gpu_round.sh <tag> [legs]
 #   legs: subset of "tests pmc bench prof kbench sweep" (default: tests pmc bench prof)
-TAG=${1:-r01x}; LEGS=${2:-"tests pmc bench prof"}
+TAG=${1:-r01x}; LEGS=${2:-"tests bench prof"}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 export TMPDIR=/tmp
@@ -16,7 +16,7 @@ pmc)   for c in FETCH_SIZE WRITE_SIZE; do
          f=$(find $OUT/pmc_$c -name "*counter_collection.csv" 2>/dev/null | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f $c > $OUT/pmc_$c.txt 2>> $OUT/pmc_$c.err; rm -rf $OUT/pmc_$c
        done
        python tools/pmc_cross_json.py $OUT/pmc_FETCH_SIZE.txt $OUT/pmc_WRITE_SIZE.txt ${PMC_IMAGES:-128} "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- $PMC_CMD" profiles/pmc_cross_attn.json > $OUT/pmc_cross_attn.json 2>> $OUT/rc.log;;
-bench) OMP355_PMC_JSON=$R/$OUT/pmc_cross_attn.json timeout 900 python bench.py ${BENCH_ARGS:---steps 20 --warmup 5} --phase-times > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/rc.log;;
+bench) [ -s $R/$OUT/pmc_cross_attn.json ] && export OMP355_PMC_JSON=$R/$OUT/pmc_cross_attn.json; timeout 900 python bench.py ${BENCH_ARGS:---steps 20 --warmup 5} --phase-times > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/rc.log;;
 prof)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o ks -- python $R/bench.py ${PROF_ARGS:---steps 20 --warmup 5} --no-cpu-baseline --no-config-legs > $R/$OUT/prof_bench.json 2> $R/$OUT/prof.err); prc=$?; echo "prof rc=$prc" >> $OUT/rc.log
        if [ $prc -ne 0 ]; then   # rocprofv3 has crashed inside hipGraphLaunch tracing once: same command with eager launches
          rm -rf $OUT/prof; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o ks -- python $R/bench.py ${PROF_ARGS:---steps 20 --warmup 5} --no-cpu-baseline --no-config-legs --graph 0 > $R/$OUT/prof_bench.json 2> $R/$OUT/prof_graph0.err); echo "prof(graph 0) rc=$?" >> $OUT/rc.log
