@@ -26,7 +26,7 @@ def test_committed_pmc_records_feed_the_roofline_traffic():
     """profiles/pmc_cross_attn.json (keyed by images per launch) and profiles/pmc_gemm.json: measured HBM bytes within a few
     per cent of (cross-attention) / a small factor above (GEMM class, re-reads through L2) the algorithmic bytes"""
     b = _bench()
-    for images in (256, 512):
+    for images in (160, 256, 512):      # 160 = the driver's `--steps 20` engine call (round 3)
         t = b.pmc_traffic(images)
         alg = images * 2 * 4096 * 512 * 2
         assert t is not None and 1.0 <= t / alg < 1.03, (images, t, alg)
@@ -49,3 +49,24 @@ def test_defaults_are_the_documented_ones(monkeypatch):
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '1', '--steps', '20', '--warmup', '5'])
     a = b.parse()
     assert max(1, min(a.coalesce, -(-a.steps // max(1, a.lanes)))) == 20   # one engine call of 160 images per repetition
+
+
+def test_round3_flags_and_host_pinning(monkeypatch):
+    """the legs the default line carries can be switched off one by one; pin_host_threads gives every rank its own slice of the
+    cores the process may use and leaves a single rank alone"""
+    b = _bench()
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--no-parity-leg', '--no-config-legs', '--dtype', 'bf16x3', '--cross-nt', '2'])
+    a = b.parse()
+    assert a.no_parity_leg and a.no_config_legs and a.dtype == 'bf16x3' and a.cross_nt == 2
+    monkeypatch.setattr(sys, 'argv', ['bench.py'])
+    a = b.parse()
+    assert not a.no_parity_leg and not a.no_config_legs and a.cross_nt == 1
+    before = os.sched_getaffinity(0)
+    try:
+        assert b.pin_host_threads(0, 1) is None and os.sched_getaffinity(0) == before
+        if len(before) >= 2:
+            mine = b.pin_host_threads(1, 2)
+            assert mine is not None and set(mine) == os.sched_getaffinity(0) and len(mine) == len(before) // 2
+            assert set(mine).isdisjoint(sorted(before)[:len(before) // 2])
+    finally:
+        os.sched_setaffinity(0, before)

@@ -384,3 +384,25 @@ def test_n_split_is_a_power_of_two_that_fills_the_chip_without_oversplitting():
             assert s4 == 1 or M >= 8 * 32 * (s4 // 2)
             if n_img * 8 >= 512:
                 assert s4 == 1
+
+
+def test_split_bf16_products_are_one_gemm_over_3k():
+    """The algebra of the bf16x3 engine (include/omp355.h omp_gemm_args.a_wrap), on the CPU: x = hi + lo keeps 16
+    mantissa bits; [a_hi | a_lo | a_hi] . [w_hi | w_hi | w_lo]^T is hi.hi + lo.hi + hi.lo -- ONE bf16 GEMM with K' = 3K whose
+    A side is the [hi | lo] pair row read with a wrap -- and is within 2^-15 of the fp64 product where plain bf16 is 2^-8."""
+    from advancedliteratemachinery_amd import ops
+    g = torch.Generator().manual_seed(0)
+    A, W = torch.randn(64, 256, generator=g), torch.randn(48, 256, generator=g) / 16.0
+    W3 = ops.split_weight3(W).float()                     # [N, 3K] = [hi | hi | lo]
+    W2 = ops.split_weight2(W).float()                     # [N, 2K] = [hi | lo]
+    a_hi = A.to(torch.bfloat16).float()
+    a_lo = (A - a_hi).to(torch.bfloat16).float()
+    assert float((A - a_hi - a_lo).abs().max() / A.abs().max()) < 2.0 ** -15          # 16 mantissa bits in 2 x 16 bits
+    assert torch.equal(W3[:, :256], W2[:, :256]) and torch.equal(W3[:, 256:512], W2[:, :256]) and torch.equal(W3[:, 512:], W2[:, 256:])
+    pair = torch.cat([a_hi, a_lo], 1)                     # what the producers store (OMP_BF16X2)
+    wrapped = torch.cat([pair, pair[:, :256]], 1)         # what the kernels read: columns >= a_wrap = 2K come from column k - a_wrap
+    y3 = wrapped.double() @ W3.double().t()
+    ref = A.double() @ W.double().t()
+    assert float((y3 - ref).abs().max() / ref.abs().max()) < 2.0 ** -15
+    y1 = a_hi.double() @ W2[:, :256].double().t()         # plain bf16 operands
+    assert float((y1 - ref).abs().max() / ref.abs().max()) > 2.0 ** -10
