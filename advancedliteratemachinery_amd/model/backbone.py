@@ -50,13 +50,18 @@ class Encoder(object):
         self.args = args
         self.window = swin_cfg['window']
         self.embed_dim = swin_cfg['embed_dim']
+        if dtype == torch.bfloat16 and self.embed_dim % 64 != 0:
+            # the bf16 matrix-core GEMMs step K in 64-element tiles (csrc/gemm.hip); Swin-T's stage-0 width (96) does not divide
+            raise ValueError('the bf16 engine needs channel widths that are multiples of 64 (embed_dim = %d): run this backbone with '
+                             "engine_dtype='fp32'" % self.embed_dim)
         f32 = lambda k: sd[k].detach().float().contiguous()          # noqa: E731
         if self.x3:   # [w_hi | w_hi | w_lo] images of the fp32 matrices (ops.split_weight3); K % 64 == 0 for the bf16 K tiles
             def mat(k):
                 w = sd[k].detach().float()
                 w = w.reshape(w.shape[0], -1)
                 if w.shape[1] % 64 != 0:
-                    raise ValueError('bf16x3 engine: %s has K = %d, not a multiple of 64' % (k, w.shape[1]))
+                    raise ValueError('the bf16x3 engine needs GEMM K extents that are multiples of 64 (%s has K = %d): run this backbone with '
+                                     "engine_dtype='fp32'" % (k, w.shape[1]))
                 return ops.split_weight3(w)
         else:
             mat = lambda k: sd[k].detach().to(dtype).contiguous()    # noqa: E731

@@ -86,3 +86,18 @@ def test_swin_t_extension_fp32(C):
     the parametrised backbone (embed 96, depths 2-2-6-2, heads 3-6-12-24) is pinned to the reference's classes with the one
     hard-coded width patched (oracle/ref_import.py).  fp32 engine only: the bf16 GEMMs need K % 64 == 0."""
     _assert_all(C.check_e2e('swint_nofpn', 'fp32'))
+
+
+def test_swin_t_widths_are_refused_loudly_in_bf16(C):
+    """the bf16 GEMMs step K in 64-element tiles, Swin-T's stage-0 width is 96 -- the engine says so when it is
+    built (ValueError naming the fp32 engine), it does not fail inside some GEMM call later."""
+    import torch as _t
+    from advancedliteratemachinery_amd.utils import synthetic as weights
+    gold = C.golden('swint_nofpn')
+    case = gold['case']
+    args, sd, _, _, _ = C.G.case_inputs(case)
+    for eng in ('bf16', 'bf16x3'):
+        model = C.build_model(args, sd, case['depths'], C.ENGINES[eng], False, case.get('swin'))
+        with pytest.raises(ValueError, match='multiple'):
+            model.engine()
+    del weights, _t
