@@ -21,10 +21,13 @@ import torch
 
 
 class Lane(object):
-    def __init__(self, device, index, dec_priority=False):
+    def __init__(self, device, index, dec_priority=False, side_streams=True):
         self.index = index
         self.device = device
         self.stream = torch.cuda.Stream(device=device)
+        if not side_streams:   # one HIP stream per lane: polygon then recognition on the lane stream (see LanePool)
+            self.side, self.dec_stream, self._dec, self._dec_src = None, None, None, None
+            return
         # decoder phases are chains of small latency-bound kernels: with dec_priority they run on high-priority
         # streams, so the hardware dispatcher places their workgroups ahead of the thousands queued by another
         # lane's encoder GEMMs whenever CUs free up
@@ -46,7 +49,11 @@ class LanePool(object):
     """submit(fn) runs fn(lane) on the next lane (round robin) inside that lane's stream context and
     returns a Future of (result, event); the event is recorded on the lane stream after fn's last launch."""
 
-    def __init__(self, device, n_lanes, dec_priority=None):
+    def __init__(self, device, n_lanes, dec_priority=None, side_streams=True):
+        """side_streams=False: every lane is ONE HIP stream.  The runtime multiplexes streams onto a few hardware queues
+        (GPU_MAX_HW_QUEUES, default 4) and streams that share a queue serialise: with three streams per lane which lanes collide
+        is decided by creation order, and the throughput of small-call pipelines swings 95-208 img/s between pools of the same
+        size (profiles/r03j_lane_sweep_*).  One stream per lane keeps up to four lanes on queues of their own."""
         self.device = torch.device(device)
         if self.device.index is None:   # torch.cuda.set_device() in the lane threads needs an explicit index
             self.device = torch.device(self.device.type, torch.cuda.current_device())
@@ -54,7 +61,7 @@ class LanePool(object):
             dec_priority = os.environ.get('OMP355_DEC_PRIORITY', '0') == '1'
         from .. import ops
         self._ctx = ops.current_context_handle()   # lane threads work on the omp_ctx of the thread that built the pool
-        self.lanes = [Lane(self.device, i, dec_priority) for i in range(max(1, n_lanes))]
+        self.lanes = [Lane(self.device, i, dec_priority, side_streams) for i in range(max(1, n_lanes))]
         self._queues = [queue.Queue() for _ in self.lanes]
         self._next = 0
         self._threads = []
@@ -104,7 +111,7 @@ class LanePool(object):
     def synchronize(self):
         for lane in self.lanes:
             lane.stream.synchronize()
-            for s in lane.side + ((lane.dec_stream,) if lane.dec_stream is not None else ()):
+            for s in (lane.side or ()) + ((lane.dec_stream,) if lane.dec_stream is not None else ()):
                 s.synchronize()
 
     def close(self):

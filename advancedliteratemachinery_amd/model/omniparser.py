@@ -124,7 +124,7 @@ class OmniParser(nn.Module):
         enc, dec = self.engine()
         side = None
         if lane is not None:
-            dec, side = lane.decoder(dec), lane.side
+            dec, side = lane.decoder(dec), (lane.side if lane.side is not None else False)   # False: no side streams at all
         a = self.args
         dev = img.device
         B = img.shape[0]
@@ -197,7 +197,7 @@ class OmniParser(nn.Module):
             return [None] * B
         points = torch.cat([ids.reshape(-1, 2) for ids, _ in pts], 0).to(dev, torch.int32)
         (poly, _), (rec, rprob) = dec.decode_poly_and_rec(kv, points, counts, poly_sos, rec_sos, a.rec_length,
-                                                          streams=side if side is not None else self._side_streams(dev))
+                                                          streams=(side or None) if side is not None else self._side_streams(dev))
         if packed is not None:   # one launch from the decoders' own buffers (views into the phase tensors)
             self._mark('poly_rec_decode')
             return ops.pack_spotting(points, poly, rec, rprob, counts, int(packed), a.rec_length)
@@ -242,7 +242,7 @@ class OmniParser(nn.Module):
             points = torch.tensor(words, dtype=torch.int32, device=kv['K'].device)
             (poly, _), (rec, _) = dec.decode_poly_and_rec(kv, points, counts, poly_sos, rec_sos, a.rec_length,
                                                           infer_vie=True,
-                                                          streams=side if side is not None else self._side_streams(kv['K'].device))
+                                                          streams=(side or None) if side is not None else self._side_streams(kv['K'].device))
             poly, rec = poly.cpu(), rec.cpu()
         i2c = index2class(a)
         sizes = _image_sizes(sizes, B)

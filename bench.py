@@ -80,6 +80,11 @@ def parse():
     p.add_argument('--cross-nt', type=int, default=1, help='A/B: omp_debug_cross_nt selector (1 = non-temporal K / V^T loads always (default), 2 = only from 32 images per launch, 0 = never)')
     p.add_argument('--lanes', type=int, default=int(os.environ.get('OMP355_LANES', '1')),
                    help='step groups in flight per GPU (engine/pipeline.py): they overlap on separate HIP streams')
+    p.add_argument('--lane-side', type=int, default=int(os.environ.get('OMP355_LANE_SIDE', '0')),
+                   help='1 = every pipeline lane gets two side streams (polygon || recognition); 0 = ONE HIP stream per lane: streams that '
+                        'share a hardware queue serialise and with three streams per lane the collisions make small-call pipelines swing '
+                        '95-208 img/s (profiles/r03j_lane_sweep_*)')
+    p.add_argument('--batch8-lanes', type=int, default=4, help='lanes of the batch8 leg (one 8-image engine call each)')
     p.add_argument('--coalesce', type=int, default=int(os.environ.get('OMP355_COALESCE', '64')),
                    help='consecutive steps (batches of --batch images) merged into one engine call: the decoders then '
                         'advance coalesce*batch images per launch (dynamic batching across steps); 1 = every step alone; '
@@ -503,7 +508,7 @@ def main():
 
     from advancedliteratemachinery_amd.engine.pipeline import LanePool
     lanes = max(1, a.lanes)
-    pool = LanePool(device, lanes) if lanes > 1 else None
+    pool = LanePool(device, lanes, side_streams=bool(a.lane_side)) if lanes > 1 else None
     pools = {'active': pool, 'b8': None}   # the batch-8 leg pipelines its small engine calls over two lanes of its own
 
     # steps per engine call: `coalesce`, but never so many that a lane would stay idle in a short run
@@ -644,14 +649,14 @@ def main():
 
     def batch8_leg():
         # BASELINE config 2 literally: every batch of 8 images its own engine call (no cross-step coalescing)
-        lanes8 = max(lanes, 2)
+        lanes8 = max(lanes, a.batch8_lanes)
         if pools['active'] is None:
-            pools['b8'] = LanePool(device, lanes8)
+            pools['b8'] = LanePool(device, lanes8, side_streams=bool(a.lane_side))
             pools['active'] = pools['b8']
         with torch.cuda.stream(stream):
-            for _ in range(lanes8):
-                run_steps(2, group=1)
-            k8 = min(a.steps, 32)
+            for _ in range(2):
+                run_steps(lanes8, group=1)    # every lane allocates its buffers and captures its graphs
+            k8 = max(min(a.steps, 32), 4 * lanes8)
             r8 = []
             # two lanes of 8-image calls interleave differently from run to run (96 .. 139 img/s over four 128-step runs,
             # profiles/r02zb): several short repetitions, median and spread reported
@@ -661,7 +666,7 @@ def main():
         pools['active'] = pool
         return dict(images_per_sec=B * k8 / e8, ms_per_step=e8 / k8 * 1e3, steps=k8, repeats=len(r8),
                     ms_per_step_p10=pct(r8, 0.1) / k8 * 1e3, ms_per_step_p90=pct(r8, 0.9) / k8 * 1e3,
-                    note='coalesce 1: one engine call per 8-image batch, %d lanes' % lanes8)
+                    note='coalesce 1: one engine call per 8-image batch, %d lanes, %s' % (lanes8, 'two side streams per lane' if a.lane_side else 'one HIP stream per lane'))
     def eos_leg():
         # EOS honoured (no forced instance count) on the sharpened synthetic checkpoint; the point sequence is
         # capped at --eos-pt-len tokens so that an image yields at most 64 instances, as in the forced workload

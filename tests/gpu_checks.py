@@ -919,7 +919,7 @@ def check_graph_matches_eager(dtype_name='fp32'):
     return [rec('graph==eager[%s]' % dtype_name, bad, 0)]
 
 
-def check_lanes(dtype_name='fp32', n_lanes=3, n_jobs=7):
+def check_lanes(dtype_name='fp32', n_lanes=3, n_jobs=7, side_streams=True):
     """engine/pipeline.py: batches pipelined over lanes (own streams, forked decoder state, graphs) return
     exactly what the synchronous path returns, whatever lane they ran on and however they overlapped."""
     from advancedliteratemachinery_amd.engine.pipeline import LanePool
@@ -938,7 +938,7 @@ def check_lanes(dtype_name='fp32', n_lanes=3, n_jobs=7):
     with torch.cuda.stream(st):
         ref = [model.infer(i, m, seqs, forced_instances=3) for i, m in jobs]
     st.synchronize()
-    pool = LanePool(DEV, n_lanes)
+    pool = LanePool(DEV, n_lanes, side_streams=side_streams)   # False: one HIP stream per lane (bench.py's batch8 leg)
     bad = 0
     try:
         for rep in range(2):   # second round replays every lane's captured graphs
@@ -952,7 +952,7 @@ def check_lanes(dtype_name='fp32', n_lanes=3, n_jobs=7):
                     bad += 0 if maxerr(gb[1][0], rb[1][0]) < 1e-6 else 1
     finally:
         pool.close()
-    return [rec('lanes==direct[%s,%d lanes,%d jobs]' % (dtype_name, n_lanes, n_jobs), bad, 0)]
+    return [rec('lanes==direct[%s,%d lanes,%d jobs,side streams %s]' % (dtype_name, n_lanes, n_jobs, side_streams), bad, 0)]
 
 
 def check_contexts(dtype_name='bf16'):

@@ -76,9 +76,11 @@ def test_graph_replay_matches_eager(C):
     _assert_all(C.check_graph_matches_eager('fp32'))
 
 
-def test_pipelined_lanes_match_direct(C):
-    """Batches in flight on several HIP streams (engine/pipeline.py) == the synchronous path."""
-    _assert_all(C.check_lanes('fp32'))
+@pytest.mark.parametrize('side_streams', [True, False])
+def test_pipelined_lanes_match_direct(C, side_streams):
+    """Batches in flight on several HIP streams (engine/pipeline.py) == the synchronous path; with two side streams per lane
+    (polygon || recognition) and with ONE stream per lane (bench.py's batch8 leg: four lanes on four hardware queues)."""
+    _assert_all(C.check_lanes('fp32', n_lanes=3 if side_streams else 4, side_streams=side_streams))
 
 
 def test_swin_t_extension_fp32(C):
@@ -91,8 +93,6 @@ def test_swin_t_extension_fp32(C):
 def test_swin_t_widths_are_refused_loudly_in_bf16(C):
     """the bf16 GEMMs step K in 64-element tiles, Swin-T's stage-0 width is 96 -- the engine says so when it is
     built (ValueError naming the fp32 engine), it does not fail inside some GEMM call later."""
-    import torch as _t
-    from advancedliteratemachinery_amd.utils import synthetic as weights
     gold = C.golden('swint_nofpn')
     case = gold['case']
     args, sd, _, _, _ = C.G.case_inputs(case)
@@ -100,4 +100,3 @@ def test_swin_t_widths_are_refused_loudly_in_bf16(C):
         model = C.build_model(args, sd, case['depths'], C.ENGINES[eng], False, case.get('swin'))
         with pytest.raises(ValueError, match='multiple'):
             model.engine()
-    del weights, _t

@@ -21,6 +21,7 @@ def main():
     p.add_argument('--batches', default='8')
     p.add_argument('--steps', type=int, default=8)
     p.add_argument('--prio', default='0', help='comma list of 0/1: decoder phases on high-priority streams')
+    p.add_argument('--side', type=int, default=1, help='0 = one HIP stream per lane (polygon then recognition on the lane stream)')
     a = p.parse_args()
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(0)
@@ -50,7 +51,7 @@ def main():
         ph = {ev[i][0]: ev[i - 1][1].elapsed_time(ev[i][1]) for i in range(1, len(ev))}
         print('B=%d sync batch: host return %.1f ms, gpu done %.1f ms, phases %s' % (B, (t1 - t0) * 1e3, (t2 - t0) * 1e3, {k: round(v, 1) for k, v in ph.items()}), flush=True)
         for L, prio in [(int(x), int(y)) for y in a.prio.split(',') for x in a.lanes.split(',')]:
-            pool = LanePool(dev, L, dec_priority=bool(prio))
+            pool = LanePool(dev, L, dec_priority=bool(prio), side_streams=bool(a.side))
             def run(k):
                 futs = [pool.submit(lambda lane: model.infer(img, mask, seqs, forced_instances=64, has_padding=False, lane=lane)) for _ in range(k)]
                 for f in futs:
@@ -65,7 +66,7 @@ def main():
                 run(nst)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
-            print('B=%d lanes=%d prio=%d : %.1f ms/step  %.1f img/s  (%d steps)' % (B, L, prio, dt / nst * 1e3, B * nst / dt, nst), flush=True)
+            print('B=%d lanes=%d prio=%d side=%d : %.1f ms/step  %.1f img/s  (%d steps)' % (B, L, prio, a.side, dt / nst * 1e3, B * nst / dt, nst), flush=True)
             pool.close()
             del pool
             torch.cuda.empty_cache()
