@@ -1,8 +1,8 @@
 """One encoder pass (Swin-B + FPN + input_proj on 32 images of 1024x1024, the chunk bench.py's engine calls encode) plus the
 K / V^T projection of those 32 images, launched eagerly for the rocprofv3 --pmc passes that measure the HBM traffic of the
 large GEMMs (FETCH_SIZE, WRITE_SIZE; separate passes).  Prints the ALGORITHMIC bytes of every GEMM / fused-MLP launch it
-made -- (M K + N K + M N (+ M N residual / second destination)) x 2 bytes, x in + y out + packed weights for the fused
-MLP -- so that tools/pmc_gemm_json.py can put measured next to algorithmic traffic.
+made -- M K + N K + M N (+ M N residual / second destination), each at the element size it is launched with (bf16 operands,
+fp32 residual stream), x in + y out + packed weights for the fused MLP -- so that tools/pmc_gemm_json.py can put measured next to algorithmic traffic.
     python tools/encode_pmc.py [images] > gpurun_out/.../encode_alg.json"""
 import json
 import os
@@ -34,15 +34,24 @@ def main():
         K = kw.get('K') or A.shape[-1]
         N = kw.get('N') or W.shape[0]
         M = kw.get('M') or A.numel() // A.shape[-1]
-        n_out = 1 + (1 if residual is not None else 0) + (1 if kw.get('out_noresidual') is not None else 0)
+        # element sizes as launched: bf16 operands, the residual stream (residual in, out) in fp32
+        ea, ew = A.element_size(), W.element_size()
+        out = kw.get('out')
+        od = kw.get('out_dtype') or W.dtype
+        eo = out.element_size() if out is not None else (4 if (od == ops.SPLIT or od == torch.float32) else 2)
+        mn = M * N * eo
+        if residual is not None:
+            mn += M * N * residual.element_size()
+        if kw.get('out_noresidual') is not None:
+            mn += M * N * kw['out_noresidual'].element_size()
         log['gemm_launches'] += 1
-        log['gemm_alg_bytes'] += (M * K + N * K + n_out * M * N) * 2.0
+        log['gemm_alg_bytes'] += float(M * K * ea + N * K * ew + mn)
         log['gemm_flops'] += 2.0 * M * N * K
         return real_gemm(A, W, bias, residual=residual, **kw)
 
     def mlp(x, g, b, wpack, b2, out=None, eps=1e-5):
         log['mlp_launches'] += 1
-        log['mlp_alg_bytes'] += 2.0 * x.numel() * 2 + wpack.numel()
+        log['mlp_alg_bytes'] += 2.0 * x.numel() * x.element_size() + wpack.numel() * wpack.element_size()
         return real_mlp(x, g, b, wpack, b2, out=out, eps=eps)
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):

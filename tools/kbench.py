@@ -108,21 +108,29 @@ def bench_gemm(dtype=torch.bfloat16):
               (8192, 3072, 1024, 0, 0), (8192, 1024, 1024, 0, 1), (8192, 4096, 1024, 1, 0), (8192, 1024, 4096, 0, 1),
               (32768, 6144, 512, 0, 0)]
     ms = int(os.environ.get('KBENCH_GEMM_MSCALE', '1'))   # 4 = the encoder's 32-image chunks
+    f32res = os.environ.get('KBENCH_GEMM_F32RES', '1') == '1'   # the engines keep the residual stream in fp32
+    lib = os.environ.get('KBENCH_GEMM_LIB', '0') == '1'         # calibration: torch's library GEMM (hipBLASLt) on the same product
     for (M, N, K, act, res) in shapes:
         M = M * ms
         A = torch.randn(M, K, device=DEV).to(dtype)
         W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(dtype)
         bias = torch.randn(N, device=DEV)
-        out = torch.empty(M, N, device=DEV, dtype=dtype)
-        r = torch.randn(M, N, device=DEV).to(dtype) if res else None
+        odt = torch.float32 if (res and f32res) else dtype
+        out = torch.empty(M, N, device=DEV, dtype=odt)
+        r = torch.randn(M, N, device=DEV).to(odt) if res else None
         fl = 2.0 * M * N * K
-        by = (M * K + N * K + M * N * (2 if res else 1)) * 2
+        by = (M * K + N * K) * 2 + M * N * (2 if res else 1) * out.element_size()
         for which in GEMM_VARIANTS:
             ops.force_gemm_kernel(which)
             us = timeit(lambda: ops.gemm(A, W, bias, residual=r, act=act, out=out), iters=20, warm=3)
-            print('gemm[%s,k%d] %7dx%5dx%5d act=%d res=%d : %8.1f us  %6.1f TF/s  %6.0f GB/s' % (str(dtype)[6:], which, M, N, K, act, res, us, fl / us / 1e6, by / us / 1e3),
+            print('gemm[%s,k%d] %7dx%5dx%5d act=%d res=%d out=%s : %8.1f us  %6.1f TF/s  %6.0f GB/s' % (str(dtype)[6:], which, M, N, K, act, res, str(odt)[6:], us, fl / us / 1e6, by / us / 1e3),
                   flush=True)
         ops.force_gemm_kernel(0)
+        if lib:
+            o2 = torch.empty(M, N, device=DEV, dtype=dtype)
+            Wt = W.t()
+            us = timeit(lambda: torch.mm(A, Wt, out=o2), iters=20, warm=3)
+            print('gemm[lib     ] %7dx%5dx%5d plain bf16 product (no bias / act / residual) : %8.1f us  %6.1f TF/s' % (M, N, K, us, fl / us / 1e6), flush=True)
 
 
 def bench_kvproj(dtype=torch.bfloat16):
