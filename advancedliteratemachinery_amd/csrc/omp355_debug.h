@@ -13,7 +13,7 @@ extern "C" {
 #endif
 
 int omp_debug_swin_mlp_variant(int v); /* alternative (rows per wave, waves, ring depth) instantiations of the fused MLP; 100 = traced default */
-int omp_debug_swin_mlp_trace(void* buffer); /* uint64 [workgroups][8] cycle sums written by variant 100 (csrc/mlp.hip) */
+int omp_debug_swin_mlp_trace(void* buffer); /* uint64 [workgroups][8] cycle sums written by variant 100 (csrc/mlp.hip); while set, omp_swin_attn_block launches its traced instantiation into the same buffer (csrc/swin_block.hip) */
 
 /* ---- streams on a subset of the compute units (engine/pipeline.py: HBM-bound decoder phases of one engine call
  * next to the matrix-core-bound encoder of another) ---------------------------------------------------------------

@@ -31,7 +31,7 @@ FUSED_MLP_WIDTHS = (128, 256)
 
 class _Block(object):
     __slots__ = ('n1g', 'n1b', 'qkv_w', 'qkv_b', 'table', 'proj_w', 'proj_b', 'n2g', 'n2b', 'fc1_w',
-                 'fc1_b', 'fc2_w', 'fc2_b', 'shift', 'mlp_pack', 'bias_exp')
+                 'fc1_b', 'fc2_w', 'fc2_b', 'shift', 'mlp_pack', 'bias_exp', 'attn_fused')
 
 
 class _Stage(object):
@@ -92,6 +92,9 @@ class Encoder(object):
                 fuse = (dtype == torch.bfloat16 and st.C in FUSED_MLP_WIDTHS and blk.fc1_w.shape[0] % 32 == 0
                         and getattr(args, 'fused_mlp', True))
                 blk.mlp_pack = pack_mlp(blk.fc1_w, blk.fc1_b, blk.fc2_w) if fuse else None
+                # norm1 + qkv + (S)W-MSA + proj + residual in one launch where the kernel is built (C = 128 with 4 heads: Swin-B stage 0)
+                blk.attn_fused = (dtype == torch.bfloat16 and not self.x3 and st.C == 128 and nh == 4 and self.window == 7
+                                  and getattr(args, 'fused_attn', True))
                 st.blocks.append(blk)
             if s + 1 < len(depths):
                 p = '%slayers.%d.downsample.' % (bb, s)
@@ -154,11 +157,15 @@ class Encoder(object):
         for si, st in enumerate(self.stages):
             C = st.C
             for blk in st.blocks:
-                y = ops.layernorm(x, blk.n1g, blk.n1b, out_dtype=T, eps=LN_EPS)
-                qkv = ops.gemm(y, blk.qkv_w, blk.qkv_b)
-                att = ops.swin_window_attn(qkv, blk.qkv_b, blk.table, B, H, W, C, st.nH, blk.shift, out=y,
-                                           window=self.window, bias_expanded=blk.bias_exp)
-                ops.gemm(att, blk.proj_w, blk.proj_b, residual=x, out=x)
+                if blk.attn_fused:
+                    ops.swin_attn_block(x, blk.n1g, blk.n1b, blk.qkv_w, blk.qkv_b, blk.bias_exp, blk.proj_w, blk.proj_b, B, H, W, C, st.nH,
+                                        blk.shift, window=self.window, eps=LN_EPS)
+                else:
+                    y = ops.layernorm(x, blk.n1g, blk.n1b, out_dtype=T, eps=LN_EPS)
+                    qkv = ops.gemm(y, blk.qkv_w, blk.qkv_b)
+                    att = ops.swin_window_attn(qkv, blk.qkv_b, blk.table, B, H, W, C, st.nH, blk.shift, out=y,
+                                               window=self.window, bias_expanded=blk.bias_exp)
+                    ops.gemm(att, blk.proj_w, blk.proj_b, residual=x, out=x)
                 if blk.mlp_pack is not None:   # norm2 + fc1 + GELU + fc2 + residual in one launch, in place
                     ops.swin_mlp_fused(x, blk.n2g, blk.n2b, blk.mlp_pack, blk.fc2_b, out=x, eps=LN_EPS)
                 else:

@@ -143,6 +143,19 @@ def swin_window_attn(qkv, qkv_bias, table, B, H, W, C, nH, shift, out=None, wind
     return out
 
 
+def swin_attn_block(x, ln_g, ln_b, qkv_w, qkv_b, bias_expanded, proj_w, proj_b, B, H, W, C, nH, shift, out=None, window=7, eps=1e-5):
+    """x (fp32 [B*H*W, C]) -> x + proj(window attention(qkv(LayerNorm(x)))) in one launch (omp_swin_attn_block: C = 128, 4 heads);
+    out defaults to x (in place)."""
+    _c(x, 'x')
+    if x.dtype != torch.float32 or qkv_w.dtype != torch.bfloat16 or proj_w.dtype != torch.bfloat16:
+        raise TypeError('swin_attn_block: fp32 residual stream with bf16 weights')
+    out = x if out is None else out
+    rc = _lib.lib().omp_swin_attn_block(ptr(x), ptr(out), ptr(ln_g), ptr(ln_b), float(eps), ptr(qkv_w), ptr(qkv_b), ptr(bias_expanded),
+                                        ptr(proj_w), ptr(proj_b), B, H, W, C, nH, window, shift, stream())
+    _lib.check(rc, 'omp_swin_attn_block')
+    return out
+
+
 def patch_merge_gather_ln(x, gamma, beta, B, H, W, C, eps=1e-5, out_dtype=None):
     """out_dtype: x.dtype (default), torch.bfloat16 for an fp32 x, or SPLIT (split pairs [rows, 8C])."""
     _c(x, 'x')

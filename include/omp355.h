@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 14
+#define OMP_ABI_VERSION 15
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -158,6 +158,19 @@ int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, const float* r
                           void* out, int dtype, int out_dtype, int B, int H, int W, int C, int nH, int window, int shift,
                           omp_stream_t s);
 int omp_swin_expand_bias(const float* rel_bias_table, int nH, float* out, omp_stream_t s);
+
+/* ---- Attention half of a Swin block in one launch (bf16 engine, C = 128 with 4 heads: Swin-B stage 0) ------------
+ * Replaces `shortcut = x; x = norm1(x); pad; roll; window_partition; attn(qkv -> softmax -> proj); window_reverse;
+ * roll back; crop; x = shortcut + drop_path(x)`, swin_transformer.py:196-247 (SwinTransformerBlock.forward up to the
+ * first residual) with WindowAttention.forward (:119-151) inlined: q / k / v, the attention weights and the
+ * attention output never reach HBM.  x, out: fp32 residual stream [B*H*W, C] (out may be x: a window reads and writes
+ * its own tokens only); ln_gamma / ln_beta: norm1; qkv_w bf16 [3C, C], qkv_b fp32 [3C]; bias_expanded from
+ * omp_swin_expand_bias; proj_w bf16 [C, C], proj_b fp32 [C].  The products take bf16 operands exactly where the
+ * unfused chain of the bf16 engine rounds (LayerNorm output, q / k / v, P, attention output).
+ * OMP_ERR_INVALID for any other C / nH / window. */
+int omp_swin_attn_block(const void* x, void* out, const float* ln_gamma, const float* ln_beta, float eps, const void* qkv_w,
+                        const float* qkv_b, const float* bias_expanded, const void* proj_w, const float* proj_b, int B, int H,
+                        int W, int C, int nH, int window, int shift, omp_stream_t s);
 
 /* ---- PatchMerging gather + LayerNorm(4C) ------------------------------------------------------------
  * Replaces swin_transformer.py:281-293 (pad to even, 2x2 gather in order (0,0),(1,0),(0,1),(1,1),

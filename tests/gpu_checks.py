@@ -1112,5 +1112,40 @@ def check_window_attn_split():
     return out
 
 
+def check_swin_block():
+    """omp_swin_attn_block (LN1 + qkv + W-MSA / SW-MSA + proj + residual in one launch, C = 128) vs the reference block's attention
+    half evaluated by the oracle path with the bf16 engine's rounding points, and vs the unfused kernel chain it replaces."""
+    out = []
+    C, nH, bf = 128, 4, torch.bfloat16
+    for (B, H, W) in ((2, 10, 13), (1, 21, 28), (3, 7, 7), (1, 40, 37), (5, 15, 9)):
+        for shift in (0, 3):
+            x = rnd(B * H * W, C, seed=H + shift) * 1.5 + 0.2
+            x[:, 5] *= 6.0          # the residual stream has outlier channels
+            g, b = rnd(C, seed=1) * 0.1 + 1, rnd(C, seed=2) * 0.1
+            Wqkv, bqkv = q(rnd(3 * C, C, seed=3) / math.sqrt(C) * 2, bf), rnd(3 * C, seed=4) * 0.3
+            table = rnd(169, nH, seed=5) * 0.5
+            Wp, bp = q(rnd(C, C, seed=6) / math.sqrt(C), bf), rnd(C, seed=7) * 0.1
+            y = q(F.layer_norm(x, (C,), g, b, 1e-5), bf)
+            qkv = q(y @ Wqkv.t() + bqkv, bf)
+            att = _ref_window_attention_from_qkv(qkv.reshape(B, H, W, 3 * C), bqkv, table, nH, shift)
+            ref = x + q(att.reshape(-1, C), bf) @ Wp.t() + bp
+            dev = lambda t, dt=None: t.to(DEV, dt) if dt is not None else t.to(DEV)   # noqa: E731
+            bexp = ops.swin_expand_bias(dev(table))
+            xg = dev(x)
+            args = (dev(g), dev(b), dev(Wqkv, bf), dev(bqkv), bexp, dev(Wp, bf), dev(bp), B, H, W, C, nH, shift)
+            got = ops.swin_attn_block(xg, *args, out=torch.empty_like(xg))
+            inplace = ops.swin_attn_block(xg.clone(), *args)
+            yg = ops.layernorm(xg, dev(g), dev(b), out_dtype=bf, eps=1e-5)
+            qg = ops.gemm(yg, dev(Wqkv, bf), dev(bqkv))
+            ag = ops.swin_window_attn(qg, dev(bqkv), dev(table), B, H, W, C, nH, shift, bias_expanded=bexp)
+            chain = ops.gemm(ag, dev(Wp, bf), dev(bp), residual=xg, out=torch.empty_like(xg))
+            tag = 'B%d %dx%d shift%d' % (B, H, W, shift)
+            out.append(rec('swin_attn_block[%s] vs reference chain' % tag, maxerr(got, ref), 6e-2,
+                           'max|ref - x|=%.1f (bf16 operands: LN output, q / k / v, P, attention output)' % (ref - x).abs().max().item()))
+            out.append(rec('swin_attn_block[%s] vs unfused kernels' % tag, maxerr(got, chain), 4e-2))
+            out.append(rec('swin_attn_block[%s] in place == out of place' % tag, maxerr(inplace, got), 0.0))
+    return out
+
+
 ALL_OP_CHECKS = [check_layernorm, check_gemm, check_mlp_fused, check_self_attn, check_gemm_small, check_patch_embed, check_window_attn, check_patch_merge, check_fpn,
-                 check_posembed, check_sampling, check_cross_attn, check_split_ops, check_gemm_x3, check_window_attn_split]
+                 check_posembed, check_sampling, check_cross_attn, check_split_ops, check_gemm_x3, check_window_attn_split, check_swin_block]

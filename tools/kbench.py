@@ -182,6 +182,47 @@ def bench_mlp(dtype=torch.bfloat16):
         ops.swin_mlp_variant(0)
 
 
+def bench_swin_block(dtype=torch.bfloat16):
+    """attention half of a stage-0 block (C = 128): one launch (omp_swin_attn_block) vs LayerNorm + qkv GEMM + window attention + proj GEMM."""
+    C, nH = 128, 4
+    B = int(os.environ.get('KBENCH_SWIN_B', '32'))
+    for (H, W) in ((256, 256),):
+        M = B * H * W
+        x = torch.randn(M, C, device=DEV)
+        g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        Wqkv = (torch.randn(3 * C, C, device=DEV) / C ** 0.5).to(dtype)
+        bqkv = torch.randn(3 * C, device=DEV) * 0.1
+        table = torch.randn(169, nH, device=DEV) * 0.2
+        bexp = ops.swin_expand_bias(table)
+        Wp, bp = (torch.randn(C, C, device=DEV) / C ** 0.5).to(dtype), torch.randn(C, device=DEV) * 0.1
+        y = torch.empty(M, C, device=DEV, dtype=dtype)
+        out = torch.empty_like(x)
+        by = 2.0 * M * C * 4
+        for shift in (0, 3):
+            def chain():
+                ops.layernorm(x, g, b, out=y, out_dtype=dtype)
+                qkv = ops.gemm(y, Wqkv, bqkv)
+                ops.swin_window_attn(qkv, bqkv, table, B, H, W, C, nH, shift, out=y, bias_expanded=bexp)
+                ops.gemm(y, Wp, bp, residual=x, out=out)
+            us_c = timeit(chain, iters=10, warm=2)
+            us_f = timeit(lambda: ops.swin_attn_block(x, g, b, Wqkv, bqkv, bexp, Wp, bp, B, H, W, C, nH, shift, out=out), iters=10, warm=2)
+            print('swin_attn_block B%d %dx%d shift%d : unfused chain %8.1f us   fused %8.1f us  (%5.0f GB/s of x in + out)'
+                  % (B, H, W, shift, us_c, us_f, by / us_f / 1e3), flush=True)
+            if os.environ.get('KBENCH_SWIN_TRACE', '0') == '1':   # wave 0's phase cycles, median over the persistent workgroups
+                h = _lib.lib()
+                trace = torch.zeros(1024, 8, dtype=torch.int64, device=DEV)
+                h.omp_debug_swin_mlp_trace(ops.ptr(trace))
+                ops.swin_attn_block(x, g, b, Wqkv, bqkv, bexp, Wp, bp, B, H, W, C, nH, shift, out=out)
+                torch.cuda.synchronize()
+                h.omp_debug_swin_mlp_trace(None)
+                t = trace.cpu().double()
+                t = t[t[:, 0] > 0]
+                med = t.median(dim=0).values
+                names = ['whole workgroup', 'LayerNorm + prefetch issue', 'wait B1', 'fragments + q k v', 'attention', 'B2, O, loads, B3, fragments, B4', 'proj + stores']
+                for i, n in enumerate(names):
+                    print('    %-34s %9.0f cycles (%5.1f%%)' % (n, med[i].item(), 100 * med[i].item() / med[0].item()), flush=True)
+
+
 def bench_dec_gemm(dtype=torch.bfloat16):
     """decoder-step GEMMs: weight streaming at R = 8 rows (point decoder) and R = 512 (polygon / recognition)."""
     for R, which in ((8, 0), (64, 0), (128, 0), (256, 0), (512, 6), (2048, 6), (8192, 6), (8192, 5), (16384, 0)):
@@ -253,6 +294,8 @@ if __name__ == '__main__':
     what = sys.argv[1:] or ['all']
     print(torch.cuda.get_device_name(0), flush=True)
     _lib.lib()
+    if 'swin_block' in what or 'all' in what:
+        bench_swin_block()
     if 'cross' in what or 'all' in what:
         bench_cross()
     if 'dec_gemm' in what or 'all' in what:
