@@ -406,3 +406,77 @@ def test_split_bf16_products_are_one_gemm_over_3k():
     assert float((y3 - ref).abs().max() / ref.abs().max()) < 2.0 ** -15
     y1 = a_hi.double() @ W2[:, :256].double().t()         # plain bf16 operands
     assert float((y1 - ref).abs().max() / ref.abs().max()) > 2.0 ** -10
+
+
+def test_swin_block_tile_layout_identities():
+    """csrc/swin_block.hip addresses its bf16 tiles ([rows][128] at 256 B per row, 16-byte chunk c of row r at slot c ^ (r & 15))
+    through three shortcuts; each is an identity over the index ranges the kernel uses."""
+    def sw_off(row, chunk):
+        return row * 256 + ((chunk ^ (row & 15)) << 4)
+
+    # (1) fragment reads: rows R + li with R a multiple of 16 -> R * 256 + cx[ks], cx[ks] = li * 256 + (((ks * 4 + g) ^ li) << 4);
+    #     the 16 lanes of one k-group hit 16 different chunk slots (conflict-free ds_read_b128)
+    for R in (0, 16, 48, 128, 256 + 96):
+        for ks in range(4):
+            for g in range(4):
+                slots = set()
+                for li in range(16):
+                    cx = li * 256 + (((ks * 4 + g) ^ li) << 4)
+                    assert R * 256 + cx == sw_off(R + li, ks * 4 + g)
+                    slots.add((cx >> 4) & 15)
+                assert len(slots) == 16
+    # (2) LayerNorm writes: wave `head`, lane (tk, lj), pass `it`, piece k -> token row it * 32 + head * 8 + tk, fp32 piece c = k * 8 + lj,
+    #     i.e. bf16 chunk c >> 1 = k * 4 + (lj >> 1), half (lj & 1); the kernel keeps ONE offset and folds k in as ^ (k << 6)
+    for head in range(4):
+        for tk in range(8):
+            for lj in range(8):
+                ln_row = head * 8 + tk
+                ln_off = ln_row * 256 + (((lj >> 1) ^ (ln_row & 15)) << 4) + (lj & 1) * 8
+                for it in range(2):
+                    for k in range(4):
+                        row, c = it * 32 + ln_row, k * 8 + lj
+                        assert it * 32 * 256 + (ln_off ^ (k << 6)) == sw_off(row, c >> 1) + (c & 1) * 8
+    # every (row, 8-byte half chunk) of the 64 x 128 tile is written exactly once per window
+    seen = set()
+    for head in range(4):
+        for lane in range(64):
+            tk, lj = lane >> 3, lane & 7
+            for it in range(2):
+                for k in range(4):
+                    seen.add((it * 32 + head * 8 + tk, k * 8 + lj))
+    assert len(seen) == 64 * 32
+    # (3) O^T accumulator pieces: head h, dim tile dt, lane (li, g) holds dims dt * 16 + 4 g .. + 4 of query t4 * 16 + li
+    for h in range(4):
+        for li in range(16):
+            for g in range(4):
+                off = [li * 256 + (((h * 4 + dt * 2 + (g >> 1)) ^ li) << 4) + (g & 1) * 8 for dt in range(2)]
+                for t4 in range(4):
+                    for dt in range(2):
+                        q, ch = t4 * 16 + li, h * 32 + dt * 16 + 4 * g      # channel of the first of the 4 values
+                        assert t4 * 4096 + off[dt] == sw_off(q, ch >> 3) + ((ch >> 2) & 1) * 8
+    # (4) window-local token t -> (t // 7, t % 7) as (t * 37) >> 8 for every t the kernel decodes
+    for t in range(64):
+        assert (t * 37) >> 8 == t // 7
+
+
+def test_swin_block_accumulators_are_operands():
+    """The fused block feeds MFMA accumulators straight back as operands.  A 16x16x32 operand lane (li, g) holds k = 8 g + e, e < 8;
+    an accumulator lane (li, g) holds rows 4 g + r, r < 4, of column li.  Packing {acc[tile 0][0..3], acc[tile 1][0..3]} therefore
+    presents row (e >> 2) * 16 + 4 g + (e & 3) at hardware index 8 g + e: a product over k is unchanged as long as BOTH operands
+    use the same map and the map is a bijection of the 32 indices."""
+    import numpy as np
+    perm = np.array([[(e >> 2) * 16 + 4 * g + (e & 3) for e in range(8)] for g in range(4)]).reshape(-1)   # hardware k -> head dim
+    assert sorted(perm.tolist()) == list(range(32))
+    rng = np.random.default_rng(0)
+    q, k = rng.standard_normal((64, 32)), rng.standard_normal((64, 32))
+    # S^T = K Q^T with both operands permuted along k == the unpermuted product
+    assert np.allclose(k[:, perm] @ q[:, perm].T, k @ q.T)
+    # O^T = V^T P per 32-key step ps: P comes from the S^T accumulators (keys kt * 16 + 4 g + r of tile kt), V from the v accumulators
+    # (tokens tt * 16 + 4 g + r of tile tt): the same map, offset by the step
+    v, p = rng.standard_normal((64, 32)), rng.random((64, 64))
+    o = np.zeros((32, 64))
+    for ps in range(2):
+        keys = 32 * ps + perm
+        assert sorted(keys.tolist()) == list(range(32 * ps, 32 * ps + 32))
+        o += v[keys].T @ p[:, keys].T          # [dim][query]
+    assert np.allclose(o, (p @ v).T)
