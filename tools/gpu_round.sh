@@ -9,6 +9,11 @@ export TMPDIR=/tmp
 PMC_STEPS=${PMC_STEPS:-16}   # images per launch = 8 x PMC_STEPS (PMC_IMAGES must say the same): 20 = the driver's --steps 20 -> 160
 PMC_ARGS="--steps $PMC_STEPS --warmup 0 --lanes 1 --graph 0 --no-cpu-baseline --no-roofline --no-parity-leg --no-config-legs --no-batch8 --no-eos-run --min-seconds 0.5"
 PMC_CMD="python bench.py $PMC_ARGS"
+# canary: a box whose GPU faults at the first device touch (round 3's last call: profiles/r03q_last_call_box_fault.txt) must not be
+# allowed to burn the budget in every leg's timeout
+if ! timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); torch.cuda.synchronize(); assert float(x.sum()) == float(1 << 20)" > $OUT/canary.log 2>&1; then
+  echo "canary failed: this box's GPU does not work, nothing was run" | tee -a $OUT/rc.log; tail -3 $OUT/canary.log; exit 3
+fi
 for leg in $LEGS; do case $leg in
 tests) timeout 900 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; echo "tests rc=$?" >> $OUT/rc.log; tail -3 $OUT/tests.log;;
 pmc)   for c in FETCH_SIZE WRITE_SIZE; do
@@ -17,9 +22,9 @@ pmc)   for c in FETCH_SIZE WRITE_SIZE; do
        done
        python tools/pmc_cross_json.py $OUT/pmc_FETCH_SIZE.txt $OUT/pmc_WRITE_SIZE.txt ${PMC_IMAGES:-128} "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- $PMC_CMD" profiles/pmc_cross_attn.json > $OUT/pmc_cross_attn.json 2>> $OUT/rc.log;;
 bench) [ -s $R/$OUT/pmc_cross_attn.json ] && export OMP355_PMC_JSON=$R/$OUT/pmc_cross_attn.json; timeout 900 python bench.py ${BENCH_ARGS:---steps 20 --warmup 5} --phase-times > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/rc.log;;
-prof)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o ks -- python $R/bench.py ${PROF_ARGS:---steps 20 --warmup 5} --no-cpu-baseline --no-config-legs > $R/$OUT/prof_bench.json 2> $R/$OUT/prof.err); prc=$?; echo "prof rc=$prc" >> $OUT/rc.log
+prof)  (cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o ks -- python $R/bench.py ${PROF_ARGS:---steps 20 --warmup 5} --no-cpu-baseline --no-config-legs > $R/$OUT/prof_bench.json 2> $R/$OUT/prof.err); prc=$?; echo "prof rc=$prc" >> $OUT/rc.log
        if [ $prc -ne 0 ]; then   # rocprofv3 has crashed inside hipGraphLaunch tracing once: same command with eager launches
-         rm -rf $OUT/prof; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o ks -- python $R/bench.py ${PROF_ARGS:---steps 20 --warmup 5} --no-cpu-baseline --no-config-legs --graph 0 > $R/$OUT/prof_bench.json 2> $R/$OUT/prof_graph0.err); echo "prof(graph 0) rc=$?" >> $OUT/rc.log
+         rm -rf $OUT/prof; (cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o ks -- python $R/bench.py ${PROF_ARGS:---steps 20 --warmup 5} --no-cpu-baseline --no-config-legs --graph 0 > $R/$OUT/prof_bench.json 2> $R/$OUT/prof_graph0.err); echo "prof(graph 0) rc=$?" >> $OUT/rc.log
        fi
        db=$(find $OUT/prof -name "*.db" 2>/dev/null | head -1); [ -n "$db" ] && python tools/rocpd_stats.py $db > $OUT/kernel_stats.txt 2>> $OUT/prof.err
        find $OUT/prof -name "*.db" -size +20M -delete 2>/dev/null;;
