@@ -147,9 +147,15 @@ def swin_attn_block(x, ln_g, ln_b, qkv_w, qkv_b, bias_expanded, proj_w, proj_b, 
     """x (fp32 [B*H*W, C]) -> x + proj(window attention(qkv(LayerNorm(x)))) in one launch (omp_swin_attn_block: C = 128, 4 heads);
     out defaults to x (in place)."""
     _c(x, 'x')
+    _c(qkv_w, 'qkv_w')
+    _c(proj_w, 'proj_w')
     if x.dtype != torch.float32 or qkv_w.dtype != torch.bfloat16 or proj_w.dtype != torch.bfloat16:
         raise TypeError('swin_attn_block: fp32 residual stream with bf16 weights')
-    out = x if out is None else out
+    if x.numel() != B * H * W * C or tuple(qkv_w.shape) != (3 * C, C) or tuple(proj_w.shape) != (C, C) or bias_expanded.numel() != nH * 4096:
+        raise ValueError('swin_attn_block: x [B*H*W, C], qkv_w [3C, C], proj_w [C, C], bias_expanded [nH, 64, 64] expected')
+    out = x if out is None else _c(out, 'out')
+    if out.dtype != torch.float32 or out.numel() != x.numel():
+        raise ValueError('swin_attn_block: out must be fp32 with the shape of x')
     rc = _lib.lib().omp_swin_attn_block(ptr(x), ptr(out), ptr(ln_g), ptr(ln_b), float(eps), ptr(qkv_w), ptr(qkv_b), ptr(bias_expanded),
                                         ptr(proj_w), ptr(proj_b), B, H, W, C, nH, window, shift, stream())
     _lib.check(rc, 'omp_swin_attn_block')

@@ -480,3 +480,24 @@ def test_swin_block_accumulators_are_operands():
         assert sorted(keys.tolist()) == list(range(32 * ps, 32 * ps + 32))
         o += v[keys].T @ p[:, keys].T          # [dim][query]
     assert np.allclose(o, (p @ v).T)
+
+
+def test_swin_attn_block_wrapper_refuses_bad_operands():
+    """ops.swin_attn_block validates layouts before the C ABI sees a pointer (no device needed: nothing reaches the library)."""
+    import pytest
+    import torch
+    from advancedliteratemachinery_amd import ops
+    x = torch.zeros(2 * 7 * 7, 128)
+    w, pw, be = torch.zeros(384, 128, dtype=torch.bfloat16), torch.zeros(128, 128, dtype=torch.bfloat16), torch.zeros(4, 64, 64)
+    call = lambda **kw: ops.swin_attn_block(kw.get('x', x), None, None, kw.get('w', w), None, kw.get('be', be), kw.get('pw', pw), None,  # noqa: E731
+                                            2, 7, 7, 128, 4, 0, out=kw.get('out'))
+    with pytest.raises(ValueError):
+        call(w=w[:, :64])                       # a strided view
+    with pytest.raises(ValueError):
+        call(x=torch.zeros(10, 128))            # not B*H*W rows
+    with pytest.raises(ValueError):
+        call(be=torch.zeros(8, 64, 64))         # bias expanded for another head count
+    with pytest.raises(ValueError):
+        call(out=torch.zeros(3, 128))
+    with pytest.raises(TypeError):
+        call(w=w.float())                       # the kernel takes bf16 weights
