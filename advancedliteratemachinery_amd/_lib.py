@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16, OMP_BF16X2 = 0, 1, 2   # BF16X2: split-bf16 pair rows [hi | lo] (include/omp355.h)
-ABI_VERSION = 15
+ABI_VERSION = 16
 STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
@@ -76,6 +76,7 @@ _SIGS = {
     'omp_swin_window_attn2': (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p]),
     'omp_swin_expand_bias': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     'omp_swin_attn_block': (c_int, [c_void_p] * 4 + [c_float] + [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
+    'omp_swin_attn_block_packed': (c_int, [c_void_p] * 4 + [c_float] + [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     'omp_patch_merge_gather_ln': (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_void_p]),
     'omp_patch_merge_gather_ln2': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_float, c_void_p]),
     'omp_split_bf16': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),

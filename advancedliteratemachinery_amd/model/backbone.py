@@ -21,7 +21,7 @@ Engine precisions (model/omniparser.py `engine_dtype`):
 import torch
 
 from .. import ops
-from .packing import pack_mlp
+from .packing import pack_attn_block, pack_mlp
 
 LN_EPS = 1e-5
 # stages whose MLP runs as ONE fused launch in the bf16 engine (csrc/mlp.hip); at C >= 512 the row-stationary kernel is
@@ -31,7 +31,7 @@ FUSED_MLP_WIDTHS = (128, 256)
 
 class _Block(object):
     __slots__ = ('n1g', 'n1b', 'qkv_w', 'qkv_b', 'table', 'proj_w', 'proj_b', 'n2g', 'n2b', 'fc1_w',
-                 'fc1_b', 'fc2_w', 'fc2_b', 'shift', 'mlp_pack', 'bias_exp', 'attn_fused')
+                 'fc1_b', 'fc2_w', 'fc2_b', 'shift', 'mlp_pack', 'bias_exp', 'attn_fused', 'attn_pack')
 
 
 class _Stage(object):
@@ -95,6 +95,9 @@ class Encoder(object):
                 # norm1 + qkv + (S)W-MSA + proj + residual in one launch where the kernel is built (C = 128 with 4 heads: Swin-B stage 0)
                 blk.attn_fused = (dtype == torch.bfloat16 and not self.x3 and st.C == 128 and nh == 4 and self.window == 7
                                   and getattr(args, 'fused_attn', True))
+                # C = 256 with 8 heads (stage 1): the same block streaming a fragment-major weight image (model/packing.py::pack_attn_block)
+                blk.attn_pack = (pack_attn_block(blk.qkv_w, blk.proj_w, nh) if (dtype == torch.bfloat16 and not self.x3 and st.C == 256 and nh == 8
+                                                                                and self.window == 7 and getattr(args, 'fused_attn', True)) else None)
                 st.blocks.append(blk)
             if s + 1 < len(depths):
                 p = '%slayers.%d.downsample.' % (bb, s)
@@ -156,10 +159,14 @@ class Encoder(object):
         outs = []
         for si, st in enumerate(self.stages):
             C = st.C
+            y = None   # LayerNorm operand buffer of the unfused halves (a block whose attention half is fused never made one)
             for blk in st.blocks:
                 if blk.attn_fused:
                     ops.swin_attn_block(x, blk.n1g, blk.n1b, blk.qkv_w, blk.qkv_b, blk.bias_exp, blk.proj_w, blk.proj_b, B, H, W, C, st.nH,
                                         blk.shift, window=self.window, eps=LN_EPS)
+                elif blk.attn_pack is not None:
+                    ops.swin_attn_block_packed(x, blk.n1g, blk.n1b, blk.attn_pack, blk.qkv_b, blk.bias_exp, blk.proj_b, B, H, W, C, st.nH,
+                                               blk.shift, window=self.window, eps=LN_EPS)
                 else:
                     y = ops.layernorm(x, blk.n1g, blk.n1b, out_dtype=T, eps=LN_EPS)
                     qkv = ops.gemm(y, blk.qkv_w, blk.qkv_b)

@@ -61,3 +61,27 @@ def pack_mlp(fc1_w, fc1_b, fc2_w):
     b1 = fc1_b.detach().float().reshape(nsub, 32).contiguous()
     out[:, C * 128:C * 128 + 128] = b1.view(torch.uint8).reshape(nsub, 128)
     return out
+
+
+def pack_attn_block(qkv_w, proj_w, n_heads):
+    """Fragment-major weight image for the fused attention half of a Swin block whose weights do not fit in LDS
+    (csrc/swin_block.hip::swin_block256_kernel, C = 256 with 8 heads).  qkv_w [3C, C], proj_w [C, C] in bf16 ->
+    bf16 [3C*C + C*C], two regions:
+
+      qkv : fragment ((h * KS + ks) * 6 + sel * 2 + dt) of 64 lanes x 8 elements; lane = 16 g + li holds
+            qkv_w[sel*C + 32 h + 16 dt + li][32 ks + 8 g .. + 8]          (h = head, sel = q / k / v, dt = 16-row tile of the head)
+      proj: fragment ((w * 2 + nt) * KS + ks); lane 16 g + li holds proj_w[32 w + 16 nt + li][32 ks + 8 g .. + 8]
+
+    i.e. every matrix-core operand fragment is ONE contiguous 1 KB read (a wave reads its head's fragments straight into registers),
+    and the six fragments of a k-step sit next to each other.  Pure index permutation."""
+    C3, C = qkv_w.shape
+    if C3 != 3 * C or proj_w.shape != (C, C) or C != 32 * n_heads or C % 32:
+        raise ValueError('pack_attn_block: unsupported shapes %s / %s for %d heads' % (tuple(qkv_w.shape), tuple(proj_w.shape), n_heads))
+    if qkv_w.dtype != torch.bfloat16 or proj_w.dtype != torch.bfloat16:
+        raise TypeError('pack_attn_block packs bf16 matrices')
+    KS = C // 32
+    # qkv_w[sel][h][dt][li][ks][g][e] -> [h][ks][sel][dt][g][li][e]
+    q = qkv_w.reshape(3, n_heads, 2, 16, KS, 4, 8).permute(1, 4, 0, 2, 5, 3, 6).contiguous()
+    # proj_w[w][nt][li][ks][g][e] -> [w][nt][ks][g][li][e]
+    p = proj_w.reshape(n_heads, 2, 16, KS, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
+    return torch.cat([q.reshape(-1), p.reshape(-1)])

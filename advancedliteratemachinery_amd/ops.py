@@ -162,6 +162,18 @@ def swin_attn_block(x, ln_g, ln_b, qkv_w, qkv_b, bias_expanded, proj_w, proj_b, 
     return out
 
 
+def swin_attn_block_packed(x, ln_g, ln_b, wpack, qkv_b, bias_expanded, proj_b, B, H, W, C, nH, shift, out=None, window=7, eps=1e-5):
+    """swin_attn_block for C = 256 with 8 heads: wpack = model.packing.pack_attn_block(qkv.weight, proj.weight, nH) (omp_swin_attn_block_packed)."""
+    _c(x, 'x')
+    if x.dtype != torch.float32 or wpack.dtype != torch.bfloat16:
+        raise TypeError('swin_attn_block_packed: fp32 residual stream with a bf16 weight image')
+    out = x if out is None else out
+    rc = _lib.lib().omp_swin_attn_block_packed(ptr(x), ptr(out), ptr(ln_g), ptr(ln_b), float(eps), ptr(wpack), ptr(qkv_b), ptr(bias_expanded),
+                                               ptr(proj_b), B, H, W, C, nH, window, shift, stream())
+    _lib.check(rc, 'omp_swin_attn_block_packed')
+    return out
+
+
 def patch_merge_gather_ln(x, gamma, beta, B, H, W, C, eps=1e-5, out_dtype=None):
     """out_dtype: x.dtype (default), torch.bfloat16 for an fp32 x, or SPLIT (split pairs [rows, 8C])."""
     _c(x, 'x')

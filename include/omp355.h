@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 15
+#define OMP_ABI_VERSION 16
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -171,6 +171,12 @@ int omp_swin_expand_bias(const float* rel_bias_table, int nH, float* out, omp_st
 int omp_swin_attn_block(const void* x, void* out, const float* ln_gamma, const float* ln_beta, float eps, const void* qkv_w,
                         const float* qkv_b, const float* bias_expanded, const void* proj_w, const float* proj_b, int B, int H,
                         int W, int C, int nH, int window, int shift, omp_stream_t s);
+/* The same block for C = 256 with 8 heads (Swin-B stage 1), whose weights fit neither LDS nor registers: wpack is the
+ * fragment-major image of qkv.weight and proj.weight written once per checkpoint by model/packing.py::pack_attn_block
+ * (bf16 [4 C C]); every wave streams its head's operand fragments from it. */
+int omp_swin_attn_block_packed(const void* x, void* out, const float* ln_gamma, const float* ln_beta, float eps, const void* wpack,
+                               const float* qkv_b, const float* bias_expanded, const float* proj_b, int B, int H, int W, int C,
+                               int nH, int window, int shift, omp_stream_t s);
 
 /* ---- PatchMerging gather + LayerNorm(4C) ------------------------------------------------------------
  * Replaces swin_transformer.py:281-293 (pad to even, 2x2 gather in order (0,0),(1,0),(0,1),(1,1),

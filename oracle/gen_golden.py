@@ -54,6 +54,12 @@ BIG_CASES = {
     # hard-wired to Swin-B widths; input_proj is rebuilt at 768 inputs by oracle/ref_import.py -- patched widths)
     'swint_nofpn': dict(args=dict(tfm_pre_norm=True, use_fpn=False, use_char_window_prompt=True, pt_seq_length=6),
                         hw=(200, 264), depths=(2, 2, 6, 2), swin=dict(embed_dim=96, num_heads=(3, 6, 12, 24))),
+    # round 4: the BENCH's decode shapes end to end -- 40 instances over an M = 4096 memory and 64 instances (the value bench.py
+    # forces) over M = 1600: the 33..64-row cross-attention kernel and the 64-row self-attention path inside a whole engine call
+    'spot_1024_n40': dict(args=dict(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=80),
+                          hw=(1024, 1024), depths=(2, 2, 18, 2), mem_stride=(7, 3), feat_stride=(8, 7, 7), src_stride=(32, 3, 3)),
+    'spot_640_n64': dict(args=dict(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=128),
+                         hw=(640, 640), depths=(2, 2, 18, 2), mem_stride=(3, 3), feat_stride=(8, 5, 5), src_stride=(32, 3, 3)),
     'spot_padded': dict(args=dict(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True, pt_seq_length=8),
                         hws=[(150, 203), (120, 170)], depths=(2, 2, 18, 2)),
 }

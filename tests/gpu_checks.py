@@ -1116,8 +1116,10 @@ def check_swin_block():
     """omp_swin_attn_block (LN1 + qkv + W-MSA / SW-MSA + proj + residual in one launch, C = 128) vs the reference block's attention
     half evaluated by the oracle path with the bf16 engine's rounding points, and vs the unfused kernel chain it replaces."""
     out = []
-    C, nH, bf = 128, 4, torch.bfloat16
-    for (B, H, W) in ((2, 10, 13), (1, 21, 28), (3, 7, 7), (1, 40, 37), (5, 15, 9)):
+    bf = torch.bfloat16
+    from advancedliteratemachinery_amd.model.packing import pack_attn_block
+    for (C, nH, B, H, W) in ((128, 4, 2, 10, 13), (128, 4, 1, 21, 28), (128, 4, 3, 7, 7), (128, 4, 1, 40, 37), (128, 4, 5, 15, 9),
+                             (256, 8, 2, 10, 13), (256, 8, 1, 21, 28), (256, 8, 3, 7, 7), (256, 8, 1, 40, 37), (256, 8, 300, 7, 7)):
         for shift in (0, 3):
             x = rnd(B * H * W, C, seed=H + shift) * 1.5 + 0.2
             x[:, 5] *= 6.0          # the residual stream has outlier channels
@@ -1132,14 +1134,19 @@ def check_swin_block():
             dev = lambda t, dt=None: t.to(DEV, dt) if dt is not None else t.to(DEV)   # noqa: E731
             bexp = ops.swin_expand_bias(dev(table))
             xg = dev(x)
-            args = (dev(g), dev(b), dev(Wqkv, bf), dev(bqkv), bexp, dev(Wp, bf), dev(bp), B, H, W, C, nH, shift)
-            got = ops.swin_attn_block(xg, *args, out=torch.empty_like(xg))
-            inplace = ops.swin_attn_block(xg.clone(), *args)
+            if C == 128:
+                args = (dev(g), dev(b), dev(Wqkv, bf), dev(bqkv), bexp, dev(Wp, bf), dev(bp), B, H, W, C, nH, shift)
+                got = ops.swin_attn_block(xg, *args, out=torch.empty_like(xg))
+                inplace = ops.swin_attn_block(xg.clone(), *args)
+            else:   # weights streamed from the fragment-major image
+                args = (dev(g), dev(b), pack_attn_block(dev(Wqkv, bf), dev(Wp, bf), nH), dev(bqkv), bexp, dev(bp), B, H, W, C, nH, shift)
+                got = ops.swin_attn_block_packed(xg, *args, out=torch.empty_like(xg))
+                inplace = ops.swin_attn_block_packed(xg.clone(), *args)
             yg = ops.layernorm(xg, dev(g), dev(b), out_dtype=bf, eps=1e-5)
             qg = ops.gemm(yg, dev(Wqkv, bf), dev(bqkv))
             ag = ops.swin_window_attn(qg, dev(bqkv), dev(table), B, H, W, C, nH, shift, bias_expanded=bexp)
             chain = ops.gemm(ag, dev(Wp, bf), dev(bp), residual=xg, out=torch.empty_like(xg))
-            tag = 'B%d %dx%d shift%d' % (B, H, W, shift)
+            tag = 'C%d B%d %dx%d shift%d' % (C, B, H, W, shift)
             out.append(rec('swin_attn_block[%s] vs reference chain' % tag, maxerr(got, ref), 6e-2,
                            'max|ref - x|=%.1f (bf16 operands: LN output, q / k / v, P, attention output)' % (ref - x).abs().max().item()))
             out.append(rec('swin_attn_block[%s] vs unfused kernels' % tag, maxerr(got, chain), 4e-2))

@@ -501,3 +501,59 @@ def test_swin_attn_block_wrapper_refuses_bad_operands():
         call(out=torch.zeros(3, 128))
     with pytest.raises(TypeError):
         call(w=w.float())                       # the kernel takes bf16 weights
+
+def test_pack_attn_block_fragment_order():
+    """model/packing.py::pack_attn_block: every 64-lane x 8-element fragment is the slice of the weight the kernel's indexing names."""
+    import torch
+    from advancedliteratemachinery_amd.model.packing import pack_attn_block
+    C, nH = 256, 8
+    KS = C // 32
+    qkv = torch.arange(3 * C * C, dtype=torch.float32).reshape(3 * C, C).to(torch.bfloat16)
+    qkv = (torch.randn(3 * C, C, generator=torch.Generator().manual_seed(0))).to(torch.bfloat16)
+    proj = (torch.randn(C, C, generator=torch.Generator().manual_seed(1))).to(torch.bfloat16)
+    img = pack_attn_block(qkv, proj, nH)
+    assert img.numel() == 4 * C * C
+    for (h, ks, sel, dt) in ((0, 0, 0, 0), (3, 5, 1, 1), (7, 7, 2, 0), (2, 1, 2, 1)):
+        frag = img[((h * KS + ks) * 6 + sel * 2 + dt) * 512:][:512].reshape(64, 8)
+        for lane in (0, 5, 17, 40, 63):
+            g, li = lane >> 4, lane & 15
+            assert torch.equal(frag[lane], qkv[sel * C + 32 * h + 16 * dt + li, 32 * ks + 8 * g:32 * ks + 8 * g + 8])
+    base = 3 * C * C
+    for (w, nt, ks) in ((0, 0, 0), (5, 1, 3), (7, 0, 7)):
+        frag = img[base + ((w * 2 + nt) * KS + ks) * 512:][:512].reshape(64, 8)
+        for lane in (0, 9, 33, 63):
+            g, li = lane >> 4, lane & 15
+            assert torch.equal(frag[lane], proj[32 * w + 16 * nt + li, 32 * ks + 8 * g:32 * ks + 8 * g + 8])
+
+
+def test_swin_block256_tile_layout_identities():
+    """The C = 256 variant (rows of 512 B = 32 chunks, slot = chunk ^ (row & 15)) folds the k-step / piece index into its offsets by XOR."""
+    def sw_off(row, chunk):
+        return row * 512 + ((chunk ^ (row & 15)) << 4)
+
+    for li in range(16):
+        for g in range(4):
+            cx0 = li * 512 + ((g ^ li) << 4)
+            for ks in range(8):
+                for R in (0, 16, 32, 48):
+                    assert R * 512 + (cx0 ^ (ks << 6)) == sw_off(R + li, ks * 4 + g)
+    seen = set()
+    for head in range(8):
+        for lane in range(64):
+            tk, lj = lane >> 4, lane & 15
+            ln_row = head * 4 + tk
+            ln_off = ln_row * 512 + (((lj >> 1) ^ (ln_row & 15)) << 4) + (lj & 1) * 8
+            for it in range(2):
+                for k in range(4):
+                    row, c = it * 32 + ln_row, k * 16 + lj            # fp32 piece c of the 1 KB row -> bf16 chunk c >> 1, half c & 1
+                    assert it * 32 * 512 + (ln_off ^ (k << 7)) == sw_off(row, c >> 1) + (c & 1) * 8
+                    seen.add((row, c))
+    assert len(seen) == 64 * 64
+    for h in range(8):
+        for li in range(16):
+            for g in range(4):
+                off = [li * 512 + (((h * 4 + dt * 2 + (g >> 1)) ^ li) << 4) + (g & 1) * 8 for dt in range(2)]
+                for t4 in range(4):
+                    for dt in range(2):
+                        q, ch = t4 * 16 + li, h * 32 + dt * 16 + 4 * g
+                        assert t4 * 8192 + off[dt] == sw_off(q, ch >> 3) + ((ch >> 2) & 1) * 8

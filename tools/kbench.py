@@ -184,9 +184,9 @@ def bench_mlp(dtype=torch.bfloat16):
 
 def bench_swin_block(dtype=torch.bfloat16):
     """attention half of a stage-0 block (C = 128): one launch (omp_swin_attn_block) vs LayerNorm + qkv GEMM + window attention + proj GEMM."""
-    C, nH = 128, 4
+    from advancedliteratemachinery_amd.model.packing import pack_attn_block
     B = int(os.environ.get('KBENCH_SWIN_B', '32'))
-    for (H, W) in ((256, 256),):
+    for (C, nH, H, W) in ((128, 4, 256, 256), (256, 8, 128, 128)):
         M = B * H * W
         x = torch.randn(M, C, device=DEV)
         g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
@@ -205,14 +205,21 @@ def bench_swin_block(dtype=torch.bfloat16):
                 ops.swin_window_attn(qkv, bqkv, table, B, H, W, C, nH, shift, out=y, bias_expanded=bexp)
                 ops.gemm(y, Wp, bp, residual=x, out=out)
             us_c = timeit(chain, iters=10, warm=2)
-            us_f = timeit(lambda: ops.swin_attn_block(x, g, b, Wqkv, bqkv, bexp, Wp, bp, B, H, W, C, nH, shift, out=out), iters=10, warm=2)
-            print('swin_attn_block B%d %dx%d shift%d : unfused chain %8.1f us   fused %8.1f us  (%5.0f GB/s of x in + out)'
-                  % (B, H, W, shift, us_c, us_f, by / us_f / 1e3), flush=True)
+            wpack = pack_attn_block(Wqkv, Wp, nH) if C == 256 else None
+
+            def fused():
+                if C == 128:
+                    ops.swin_attn_block(x, g, b, Wqkv, bqkv, bexp, Wp, bp, B, H, W, C, nH, shift, out=out)
+                else:
+                    ops.swin_attn_block_packed(x, g, b, wpack, bqkv, bexp, bp, B, H, W, C, nH, shift, out=out)
+            us_f = timeit(fused, iters=10, warm=2)
+            print('swin_attn_block C%d B%d %dx%d shift%d : unfused chain %8.1f us   fused %8.1f us  (%5.0f GB/s of x in + out)'
+                  % (C, B, H, W, shift, us_c, us_f, by / us_f / 1e3), flush=True)
             if os.environ.get('KBENCH_SWIN_TRACE', '0') == '1':   # wave 0's phase cycles, median over the persistent workgroups
                 h = _lib.lib()
                 trace = torch.zeros(1024, 8, dtype=torch.int64, device=DEV)
                 h.omp_debug_swin_mlp_trace(ops.ptr(trace))
-                ops.swin_attn_block(x, g, b, Wqkv, bqkv, bexp, Wp, bp, B, H, W, C, nH, shift, out=out)
+                fused()
                 torch.cuda.synchronize()
                 h.omp_debug_swin_mlp_trace(None)
                 t = trace.cpu().double()
