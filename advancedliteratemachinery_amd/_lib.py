@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16, OMP_BF16X2 = 0, 1, 2   # BF16X2: split-bf16 pair rows [hi | lo] (include/omp355.h)
-ABI_VERSION = 16
+ABI_VERSION = 17
 STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
@@ -48,7 +48,7 @@ class DecLayer(ctypes.Structure):
 
 class DecoderPlan(ctypes.Structure):
     _fields_ = ([(n, c_int32) for n in ('dtype', 'n_layers', 'd_model', 'n_heads', 'd_ff', 'vocab',
-                                        'pre_norm', 'R', 'Lmax', 'M', 'Mpad', 'n_tiles', 'q_tiles', 'n_split', 'n_prompt', 'gemm_x3')]
+                                        'pre_norm', 'R', 'Lmax', 'M', 'Mpad', 'n_tiles', 'q_tiles', 'n_split', 'n_prompt', 'gemm_x3', 'kv_split')]
                 + [('eps', c_float), ('layers', DecLayer * MAX_DEC_LAYERS)]
                 + [(n, c_void_p) for n in ('word_emb', 'pos_tab', 'emb_g', 'emb_b', 'fn_g', 'fn_b',
                                            'h0_w', 'h1_w', 'h2_w', 'h0_b', 'h1_b', 'h2_b')]

@@ -524,12 +524,22 @@ struct CrossP {
   void* out; int64_t ldo;
   float* partial;
   int M, Mpad, nH, R, kpw;        // kpw: keys per wave, multiple of the key block
+  int lo_off;                     // split-plane slabs only: > 0 = the output rows are split-bf16 pairs, lo plane lo_off columns after hi (ldo in bf16 elements)
 };
 
+// Slab element types: bf16, float, and bf16s_t = SPLIT-bf16 planes (round 4, the parity engine): every 32-key block of a K / V^T slab is
+// [hi plane | lo plane] of bf16 (the bytes of the fp32 block), value = hi + lo to 16 mantissa bits.  q arrives and the output leaves
+// in fp32; S and PV run as three bf16 matrix-core products each (K_hi q_hi + K_lo q_hi + K_hi q_lo; V_hi p_hi + V_lo p_hi + V_hi p_lo),
+// so the fp32-grade cross-attention is paced by HBM like the bf16 one instead of by the 16x16x4 fp32 matrix-core rate.  A CPU
+// simulation (tools/sim_cross_planes.py, profiles/r04_sim_cross_planes.txt) shows that NONE of K, V, q, P may stay a single bf16
+// plane under north_star's 1e-3 logit gate.
+struct bf16s_t {};
 template <typename T>
 struct CrossTraits;
 template <>
 struct CrossTraits<bf16_t> {
+  typedef bf16_t elem;
+  static constexpr int PL = 1;    // planes per block
   static constexpr int KB = 32;   // keys per block
   static constexpr int NSB = 2;   // 16-key score blocks per key block
   static constexpr int DSTEPS = 2;  // 64 dims / 32
@@ -541,7 +551,23 @@ struct CrossTraits<bf16_t> {
   }
 };
 template <>
+struct CrossTraits<bf16s_t> {
+  typedef bf16_t elem;
+  static constexpr int PL = 2;
+  static constexpr int KB = 32;
+  static constexpr int NSB = 2;
+  static constexpr int DSTEPS = 2;
+  __device__ static __forceinline__ bf16x8 pfrag(const float* p) {
+    bf16x8 f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (bf16_t)p[i];
+    return f;
+  }
+};
+template <>
 struct CrossTraits<float> {
+  typedef float elem;
+  static constexpr int PL = 1;
   static constexpr int KB = 16;
   static constexpr int NSB = 1;
   static constexpr int DSTEPS = 4;  // 64 dims / 16
@@ -549,6 +575,12 @@ struct CrossTraits<float> {
 };
 
 constexpr int CROSS_PSTR = 68;   // m, l, pad, pad, o[64]
+
+// 8 fp32 values -> the hi / lo bf16 fragments of their split representation (lo = bf16(x - hi): x = hi + lo to 2^-17 relative)
+__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { hi[i] = (bf16_t)v[i]; lo[i] = (bf16_t)(v[i] - (float)hi[i]); }
+}
 
 // wait until at most `blocks` of this wave's most recently issued key blocks (IPB DMA instructions each) are
 // still in flight (the count must be an immediate; the switch is wave-uniform)
@@ -568,10 +600,11 @@ __device__ __forceinline__ void wait_dma_blocks(int blocks) {
 
 template <typename T, int NW, int QT, int PD, bool NT = false>
 __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
-  typedef Mma<T> MM;
   typedef CrossTraits<T> CT;
+  typedef typename CT::elem E;      // slab element
+  typedef Mma<E> MM;
   typedef typename MM::frag frag;
-  constexpr int KB = CT::KB;
+  constexpr int KB = CT::KB, PL = CT::PL;
   constexpr int NKF = CT::NSB * CT::DSTEPS;
   constexpr int PSTR = CROSS_PSTR;
   extern __shared__ __attribute__((aligned(16))) float part[];   // [NW][QT*16 queries][PSTR]
@@ -586,26 +619,31 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
   const int nblk = kbeg < kend ? (kend - kbeg + KB - 1) / KB : 0;
 
   // K / V^T fragment addresses of this lane inside the (image, head) slabs
-  const int64_t slab = (int64_t)img * p.img_stride + (int64_t)h * p.Mpad * 64;
-  const T* Kb = reinterpret_cast<const T*>(p.K) + slab + li * 64 + g * MM::KPL;
-  const T* Vb = reinterpret_cast<const T*>(p.V) + slab + li * KB + g * MM::KPL;
+  // (image, head) slab: Mpad keys x 64 dims x PL planes; block k0 / KB starts at element k0 * 64 * PL, its plane pl KB * 64 further
+  const int64_t slab = (int64_t)img * p.img_stride + (int64_t)h * p.Mpad * 64 * PL;
+  const E* Kb = reinterpret_cast<const E*>(p.K) + slab + li * 64 + g * MM::KPL;
+  const E* Vb = reinterpret_cast<const E*>(p.V) + slab + li * KB + g * MM::KPL;
   const uint8_t* km = p.kmask ? p.kmask + (int64_t)img * p.M : nullptr;
 
-  frag kr[PD][NKF], vr[PD][4];
+  frag kr[PD][PL * NKF], vr[PD][PL * 4];
   // the K / V^T slabs are streamed exactly once per launch: NT = non-temporal loads (no L2 / MALL allocation)
-  auto ldkv = [](const T* ptr) -> frag {
+  auto ldkv = [](const E* ptr) -> frag {
     if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const frag*>(ptr));
-    else return ld16<T>(ptr);
+    else return ld16<E>(ptr);
   };
   auto load_block = [&](int k0, frag* kf, frag* vf) {
-    const T* kp = Kb + (int64_t)k0 * 64;
+    const E* kp = Kb + (int64_t)k0 * 64 * PL;
 #pragma unroll
-    for (int sb = 0; sb < CT::NSB; ++sb)
+    for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
-      for (int s = 0; s < CT::DSTEPS; ++s) kf[sb * CT::DSTEPS + s] = ldkv(kp + sb * 16 * 64 + s * MM::KSTEP);
-    const T* vp = Vb + (int64_t)k0 * 64;   // block k0/KB starts at element (k0/KB) * 64 * KB = k0 * 64
+      for (int sb = 0; sb < CT::NSB; ++sb)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) vf[dt] = ldkv(vp + dt * 16 * KB);
+        for (int s = 0; s < CT::DSTEPS; ++s) kf[pl * NKF + sb * CT::DSTEPS + s] = ldkv(kp + pl * KB * 64 + sb * 16 * 64 + s * MM::KSTEP);
+    const E* vp = Vb + (int64_t)k0 * 64 * PL;
+#pragma unroll
+    for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vf[pl * 4 + dt] = ldkv(vp + pl * KB * 64 + dt * 16 * KB);
   };
   // the K/V stream depends on nothing computed here: put PD key blocks in flight before touching Q
 #pragma unroll
@@ -613,19 +651,32 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
     if (u < nblk) load_block(kbeg + u * KB, kr[u], vr[u]);
 
   // Q fragments (B operand) of the QT query tiles: query li of the tile (clamped), dims s*KSTEP + g*KPL ..
-  frag qf[QT][CT::DSTEPS];
+  frag qf[QT][PL * CT::DSTEPS];   // split planes: [s] = hi, [DSTEPS + s] = lo of the fp32 query row
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     int qi = t * 16 + li;
     if (qi > nrows - 1) qi = nrows - 1;
-    const T* qp = reinterpret_cast<const T*>(p.q) + (int64_t)(row0 + qi) * p.ldq + h * DH + g * MM::KPL;
+    if constexpr (PL == 2) {
+      const float* qp = reinterpret_cast<const float*>(p.q) + (int64_t)(row0 + qi) * p.ldq + h * DH + g * 8;
 #pragma unroll
-    for (int s = 0; s < CT::DSTEPS; ++s) {
-      float tmp[MM::KPL];
-      unpack16(ld16<T>(qp + s * MM::KSTEP), tmp);
+      for (int s = 0; s < CT::DSTEPS; ++s) {
+        float tmp[8];
+        unpack16(ld16<float>(qp + s * 32), tmp);
+        unpack16(ld16<float>(qp + s * 32 + 4), tmp + 4);
 #pragma unroll
-      for (int i = 0; i < MM::KPL; ++i) tmp[i] *= 0.125f;   // 1/sqrt(64) on q, like nn.MultiheadAttention
-      pack16(tmp, qf[t][s]);
+        for (int i = 0; i < 8; ++i) tmp[i] *= 0.125f;   // a power of two: commutes with the split
+        split8(tmp, qf[t][s], qf[t][CT::DSTEPS + s]);
+      }
+    } else {
+      const E* qp = reinterpret_cast<const E*>(p.q) + (int64_t)(row0 + qi) * p.ldq + h * DH + g * MM::KPL;
+#pragma unroll
+      for (int s = 0; s < CT::DSTEPS; ++s) {
+        float tmp[MM::KPL];
+        unpack16(ld16<E>(qp + s * MM::KSTEP), tmp);
+#pragma unroll
+        for (int i = 0; i < MM::KPL; ++i) tmp[i] *= 0.125f;   // 1/sqrt(64) on q, like nn.MultiheadAttention
+        pack16(tmp, qf[t][s]);
+      }
     }
   }
 
@@ -658,6 +709,13 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
           f32x4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int s = 0; s < CT::DSTEPS; ++s) MM::mma(st, kc[sb * CT::DSTEPS + s], qf[t][s]);
+          if constexpr (PL == 2) {   // + K_lo q_hi + K_hi q_lo (K_lo q_lo is 2^-16 relative: dropped)
+#pragma unroll
+            for (int s = 0; s < CT::DSTEPS; ++s) {
+              MM::mma(st, kc[NKF + sb * CT::DSTEPS + s], qf[t][s]);
+              MM::mma(st, kc[sb * CT::DSTEPS + s], qf[t][CT::DSTEPS + s]);
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v = dead[sb * 4 + r] ? -INFINITY : st[r];
@@ -675,12 +733,25 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
         for (int i = 0; i < CT::NSB * 4; ++i) { sc[i] = expf(sc[i] - mref); ps += sc[i]; }
         lpart[t] = lpart[t] * alpha + ps;
         m[t] = mn;
-        const frag pf = CT::pfrag(sc);
+        if constexpr (PL == 2) {
+          frag ph, plo;
+          split8(sc, ph, plo);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+          for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ot[t][dt][r] *= alpha;
-          MM::mma(ot[t][dt], vc[dt], pf);
+            for (int r = 0; r < 4; ++r) ot[t][dt][r] *= alpha;
+            MM::mma(ot[t][dt], vc[dt], ph);
+            MM::mma(ot[t][dt], vc[4 + dt], ph);
+            MM::mma(ot[t][dt], vc[dt], plo);
+          }
+        } else {
+          const frag pf = CT::pfrag(sc);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[t][dt][r] *= alpha;
+            MM::mma(ot[t][dt], vc[dt], pf);
+          }
         }
       }
     }
@@ -709,7 +780,6 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
     }
   }
   __syncthreads();
-  T* out = reinterpret_cast<T*>(p.out);
   for (int qi = wave; qi < nrows; qi += NW) {
     float mall = -INFINITY;
 #pragma unroll
@@ -723,7 +793,20 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
       o += pw[4 + lane] * wt;
     }
     if (S == 1) {
-      out[(int64_t)(row0 + qi) * p.ldo + h * DH + lane] = from_f32<T>(o / L);
+      const float val = o / L;
+      const int64_t at = (int64_t)(row0 + qi) * p.ldo + h * DH + lane;
+      if constexpr (PL == 2) {
+        if (p.lo_off > 0) {   // split-pair rows for the out-projection's bf16x3 product
+          bf16_t* ob = reinterpret_cast<bf16_t*>(p.out) + at;
+          const bf16_t hi = (bf16_t)val;
+          ob[0] = hi;
+          ob[p.lo_off] = (bf16_t)(val - (float)hi);
+        } else {
+          reinterpret_cast<float*>(p.out)[at] = val;
+        }
+      } else {
+        reinterpret_cast<E*>(p.out)[at] = from_f32<E>(val);
+      }
     } else {
       float* dst = p.partial + (((int64_t)(row0 + qi) * p.nH + h) * S + sp) * PSTR;
       if (lane == 0) { dst[0] = mall; dst[1] = L; }
@@ -757,17 +840,22 @@ __global__ __launch_bounds__(NW * 64) void dec_cross_attn_kernel(CrossP p) {
 //   f32 : K = 16 rows (keys) x 256 B, slot = chunk ^ row (16 chunks of 16 B); V^T = 64 rows (dims) x 64 B, slot = chunk ^ t(row >> 2
 //         & 3) with t = {0, 2, 3, 1}: the four rows a ds_read_b128 lane group touches in one 256-byte bank row get four
 //         different slots.
+//   split planes (bf16s_t): a stage is 16 KB = K_hi | K_lo | V^T_hi | V^T_lo, each plane the bf16 image above (same swizzle); 4 DMA
+//         instructions per wave and block; the K_hi / V^T_hi fragments are read from LDS once and used in two products.
 template <typename T, int NS, int CH, bool NT>
 __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
-  typedef Mma<T> MM;
   typedef CrossTraits<T> CT;
+  typedef typename CT::elem E;
+  typedef Mma<E> MM;
   typedef typename MM::frag frag;
-  constexpr bool F32 = sizeof(T) == 4;
-  constexpr int KB = CT::KB, BLKB = 8192;   // keys per block; bytes per ring stage (K then V^T)
+  constexpr bool F32 = sizeof(E) == 4;
+  constexpr int PL = CT::PL;
+  constexpr int KB = CT::KB, BLKB = 8192 * PL;   // keys per block; bytes per ring stage (K planes then V^T planes)
+  constexpr int VOFF = 4096 * PL;                // V^T planes start here inside a stage
   constexpr int SPB = KB / 4;               // scores per lane per block
   constexpr int QS = CT::DSTEPS;            // k-steps over the 64 head dims
   constexpr int SLOTS = NS / CH, D = SLOTS - 1;   // a chunk = CH blocks; D chunks in flight ahead of the one in use
-  static_assert(NS % CH == 0 && D >= 1 && 2 * CH * (D - 1) <= 28, "ring geometry");
+  static_assert(NS % CH == 0 && D >= 1 && 2 * PL * CH * (D - 1) <= 56, "ring geometry");
   extern __shared__ __attribute__((aligned(16))) char ring[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int grp = blockIdx.x, h = blockIdx.y, sp = blockIdx.z, S = gridDim.z;
@@ -780,20 +868,20 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
   const int nchunk = (nblk + CH - 1) / CH;
   auto tsw = [](int q) -> int { return (0x1320 >> (q * 4)) & 3; };   // t = {0, 2, 3, 1}
 
-  const int64_t slab = (int64_t)img * p.img_stride + (int64_t)h * p.Mpad * 64;
-  // DMA: this wave's instruction fills bytes [1024 * wave, + 1024) of the K image and of the V^T image of a block, lane-linearly;
-  // the swizzle is applied to the per-lane SOURCE address
-  const T* ksrc;
-  const T* vsrc;
+  const int64_t slab = (int64_t)img * p.img_stride + (int64_t)h * p.Mpad * 64 * PL;
+  // DMA: this wave's instruction fills bytes [1024 * wave, + 1024) of the K image and of the V^T image of a block (of each plane),
+  // lane-linearly; the swizzle is applied to the per-lane SOURCE address
+  const E* ksrc;
+  const E* vsrc;
   if constexpr (F32) {
     const int kr = wave * 4 + (lane >> 4), kc = (lane & 15) ^ kr;                 // K row (key) and the chunk that lands in this lane's slot
     const int vr = wave * 16 + (lane >> 2), vc_ = (lane & 3) ^ tsw((lane >> 4) & 3);   // V^T row (dim): (vr >> 2) & 3 == (lane >> 4) & 3
-    ksrc = reinterpret_cast<const T*>(p.K) + slab + kr * 64 + kc * 4;
-    vsrc = reinterpret_cast<const T*>(p.V) + slab + vr * 16 + vc_ * 4;
+    ksrc = reinterpret_cast<const E*>(p.K) + slab + kr * 64 + kc * 4;
+    vsrc = reinterpret_cast<const E*>(p.V) + slab + vr * 16 + vc_ * 4;
   } else {
     const int dr = lane >> 3, dc = (lane & 7) ^ dr;
-    ksrc = reinterpret_cast<const T*>(p.K) + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
-    vsrc = reinterpret_cast<const T*>(p.V) + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
+    ksrc = reinterpret_cast<const E*>(p.K) + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
+    vsrc = reinterpret_cast<const E*>(p.V) + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
   }
   // chunk c -> ring stages slot * CH .. slot * CH + CH - 1.  A ragged last chunk re-requests the last valid block for
   // its missing ones: their keys are masked below, but their V^T image must hold finite numbers (0 x NaN = NaN)
@@ -802,13 +890,16 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
     for (int j = 0; j < CH; ++j) {
       int blk = c * CH + j;
       if (blk > nblk - 1) blk = nblk - 1;
-      const int64_t off = (int64_t)(kbeg + blk * KB) * 64;   // a block is KB*64 elements in both slabs
+      const int64_t off = (int64_t)(kbeg + blk * KB) * 64 * PL;   // a block is KB * 64 * PL elements in both slabs
       char* dst = ring + (slot * CH + j) * BLKB + wave * 1024;
       // NT: the slabs are read once per step and never fit a cache at 256 images per call -> non-temporal (aux = 2)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + off),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, NT ? 2 : 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + off),
-                                       (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, NT ? 2 : 0);
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + off + pl * KB * 64),
+                                         (__attribute__((address_space(3))) void*)(dst + pl * 4096), 16, 0, NT ? 2 : 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + off + pl * KB * 64),
+                                         (__attribute__((address_space(3))) void*)(dst + VOFF + pl * 4096), 16, 0, NT ? 2 : 0);
+      }
     }
   };
 #pragma unroll
@@ -821,7 +912,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
 #pragma unroll
     for (int st = 0; st < QS; ++st) koff[0][st] = li * 256 + (((st * 4 + g) ^ li) << 4);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) voff[dt] = 4096 + (dt * 16 + li) * 64 + ((g ^ tsw(li >> 2)) << 4);
+    for (int dt = 0; dt < 4; ++dt) voff[dt] = VOFF + (dt * 16 + li) * 64 + ((g ^ tsw(li >> 2)) << 4);
   } else {
 #pragma unroll
     for (int sb = 0; sb < CT::NSB; ++sb)
@@ -830,23 +921,36 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const int rw = dt * 8 + (li >> 1), c = (li & 1) * 4 + g;
-      voff[dt] = 4096 + rw * 128 + ((c ^ (rw & 7)) << 4);
+      voff[dt] = VOFF + rw * 128 + ((c ^ (rw & 7)) << 4);
     }
   }
 
-  // Q fragments (B operand) of this wave's tile, 1/sqrt(64) folded in
-  frag qf[QS];
+  // Q fragments (B operand) of this wave's tile, 1/sqrt(64) folded in (split planes: [st] = hi, [QS + st] = lo of the fp32 row)
+  frag qf[PL * QS];
   {
     int qi = wave * 16 + li;
     if (qi > nrows - 1) qi = nrows - 1;
-    const T* qp = reinterpret_cast<const T*>(p.q) + (int64_t)(row0 + qi) * p.ldq + h * DH + g * MM::KPL;
+    if constexpr (PL == 2) {
+      const float* qp = reinterpret_cast<const float*>(p.q) + (int64_t)(row0 + qi) * p.ldq + h * DH + g * 8;
 #pragma unroll
-    for (int st = 0; st < QS; ++st) {
-      float tmp[MM::KPL];
-      unpack16(ld16<T>(qp + st * MM::KSTEP), tmp);
+      for (int st = 0; st < QS; ++st) {
+        float tmp[8];
+        unpack16(ld16<float>(qp + st * 32), tmp);
+        unpack16(ld16<float>(qp + st * 32 + 4), tmp + 4);
 #pragma unroll
-      for (int i = 0; i < MM::KPL; ++i) tmp[i] *= 0.125f;
-      pack16(tmp, qf[st]);
+        for (int i = 0; i < 8; ++i) tmp[i] *= 0.125f;
+        split8(tmp, qf[st], qf[QS + st]);
+      }
+    } else {
+      const E* qp = reinterpret_cast<const E*>(p.q) + (int64_t)(row0 + qi) * p.ldq + h * DH + g * MM::KPL;
+#pragma unroll
+      for (int st = 0; st < QS; ++st) {
+        float tmp[MM::KPL];
+        unpack16(ld16<E>(qp + st * MM::KSTEP), tmp);
+#pragma unroll
+        for (int i = 0; i < MM::KPL; ++i) tmp[i] *= 0.125f;
+        pack16(tmp, qf[st]);
+      }
     }
   }
   const uint8_t* km = p.kmask ? p.kmask + (int64_t)img * p.M : nullptr;
@@ -862,7 +966,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
   int sl_c = 0, sl_i = D;   // slot in use, slot to refill (the one used by the previous chunk)
   for (int c = 0; c < nchunk; ++c) {
     const int after = nchunk - 1 - c;
-    wait_dma_blocks<2 * CH>(after < D - 1 ? after : D - 1);
+    wait_dma_blocks<2 * PL * CH>(after < D - 1 ? after : D - 1);
     __builtin_amdgcn_s_barrier();
     if (c + D < nchunk) issue_chunk(c + D, sl_i);
     if (active) {
@@ -874,7 +978,14 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
         for (int sb = 0; sb < CT::NSB; ++sb) {
           f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int st = 0; st < QS; ++st) MM::mma(sacc, *reinterpret_cast<const frag*>(base + koff[sb][st]), qf[st]);
+          for (int st = 0; st < QS; ++st) {
+            const frag kh = *reinterpret_cast<const frag*>(base + koff[sb][st]);
+            MM::mma(sacc, kh, qf[st]);
+            if constexpr (PL == 2) {   // + K_lo q_hi + K_hi q_lo
+              MM::mma(sacc, *reinterpret_cast<const frag*>(base + 4096 + koff[sb][st]), qf[st]);
+              MM::mma(sacc, kh, qf[QS + st]);
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) sc[j * SPB + sb * 4 + r] = sacc[r];
         }
@@ -909,7 +1020,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
       const float mn = fmaxf(m, bmax);
       const float mref = (mn == -INFINITY) ? 0.f : mn;   // all keys so far masked: exp(-inf - 0) = 0, not NaN
       float alpha, ps = 0.f;
-      if constexpr (F32) {     // the fp32 engines keep the accurate exponential (their parity gate is 1e-3 on logits)
+      if constexpr (F32 || PL == 2) {     // the fp32-grade engines keep the accurate exponential (their parity gate is 1e-3 on logits)
         alpha = expf(m - mref);
 #pragma unroll
         for (int i = 0; i < CH * SPB; ++i) { sc[i] = expf(sc[i] - mref); ps += sc[i]; }
@@ -927,11 +1038,23 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         const char* base = ring + (sl_c * CH + j) * BLKB;
-        const frag pf = CT::pfrag(sc + j * SPB);
+        if constexpr (PL == 2) {
+          frag ph, plo;
+          split8(sc + j * SPB, ph, plo);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const frag vc = *reinterpret_cast<const frag*>(base + voff[dt]);
-          MM::mma(ot[dt], vc, pf);
+          for (int dt = 0; dt < 4; ++dt) {
+            const frag vh = *reinterpret_cast<const frag*>(base + voff[dt]);
+            MM::mma(ot[dt], vh, ph);
+            MM::mma(ot[dt], *reinterpret_cast<const frag*>(base + 4096 + voff[dt]), ph);
+            MM::mma(ot[dt], vh, plo);
+          }
+        } else {
+          const frag pf = CT::pfrag(sc + j * SPB);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const frag vc = *reinterpret_cast<const frag*>(base + voff[dt]);
+            MM::mma(ot[dt], vc, pf);
+          }
         }
       }
     }
@@ -944,13 +1067,27 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
   const int qi = wave * 16 + li;
   if (qi >= nrows) return;
   if (S == 1) {
-    T* dst = reinterpret_cast<T*>(p.out) + (int64_t)(row0 + qi) * p.ldo + h * DH + g * 4;
+    const int64_t at = (int64_t)(row0 + qi) * p.ldo + h * DH + g * 4;
     const float inv = 1.0f / l;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      if constexpr (F32) *reinterpret_cast<f32x4*>(dst + dt * 16) = f32x4{ot[dt][0] * inv, ot[dt][1] * inv, ot[dt][2] * inv, ot[dt][3] * inv};
-      else *reinterpret_cast<bf16x4*>(dst + dt * 16) = bf16x4{(bf16_t)(ot[dt][0] * inv), (bf16_t)(ot[dt][1] * inv),
-                                                               (bf16_t)(ot[dt][2] * inv), (bf16_t)(ot[dt][3] * inv)};
+      const f32x4 v = {ot[dt][0] * inv, ot[dt][1] * inv, ot[dt][2] * inv, ot[dt][3] * inv};
+      if constexpr (PL == 2) {
+        if (p.lo_off > 0) {   // split-pair rows for the out-projection's bf16x3 product
+          bf16_t* ob = reinterpret_cast<bf16_t*>(p.out) + at + dt * 16;
+          bf16x4 hi, lo;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { hi[r] = (bf16_t)v[r]; lo[r] = (bf16_t)(v[r] - (float)hi[r]); }
+          *reinterpret_cast<bf16x4*>(ob) = hi;
+          *reinterpret_cast<bf16x4*>(ob + p.lo_off) = lo;
+        } else {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + at + dt * 16) = v;
+        }
+      } else if constexpr (F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + at + dt * 16) = v;
+      } else {
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out) + at + dt * 16) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      }
     }
   } else {
     float* dst = p.partial + (((int64_t)(row0 + qi) * p.nH + h) * S + sp) * CROSS_PSTR;
@@ -964,7 +1101,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q4_kernel(CrossP p) {
 // All loads are issued before any math (S <= 16) -- the merge is a latency-, not a bandwidth problem.
 template <typename T, int S>
 __global__ __launch_bounds__(256) void dec_cross_merge_kernel(const float* __restrict__ partial, T* __restrict__ out,
-                                                              int64_t ldo, int nH, int total) {
+                                                              int64_t ldo, int nH, int total, int lo_off) {
   const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= total) return;
   const int r = wid / nH, h = wid % nH;
@@ -981,6 +1118,16 @@ __global__ __launch_bounds__(256) void dec_cross_merge_kernel(const float* __res
     const float w = (mv[s] == -INFINITY) ? 0.f : expf(mv[s] - mall);
     L += lv[s] * w;
     o += ov[s] * w;
+  }
+  if constexpr (sizeof(T) == 4) {
+    if (lo_off > 0) {   // split-bf16 pair rows (ldo in bf16 elements)
+      bf16_t* ob = reinterpret_cast<bf16_t*>(out) + (int64_t)r * ldo + h * DH + lane;
+      const float val = o / L;
+      const bf16_t hi = (bf16_t)val;
+      ob[0] = hi;
+      ob[lo_off] = (bf16_t)(val - (float)hi);
+      return;
+    }
   }
   out[(int64_t)r * ldo + h * DH + lane] = from_f32<T>(o / L);
 }
@@ -1159,10 +1306,10 @@ int launch_merge(const CrossP& cp, int S, hipStream_t st) {
   dim3 grid((total + 3) / 4), block(256);
   T* out = reinterpret_cast<T*>(cp.out);
   switch (S) {
-    case 2: hipLaunchKernelGGL((dec_cross_merge_kernel<T, 2>), grid, block, 0, st, cp.partial, out, cp.ldo, cp.nH, total); break;
-    case 4: hipLaunchKernelGGL((dec_cross_merge_kernel<T, 4>), grid, block, 0, st, cp.partial, out, cp.ldo, cp.nH, total); break;
-    case 8: hipLaunchKernelGGL((dec_cross_merge_kernel<T, 8>), grid, block, 0, st, cp.partial, out, cp.ldo, cp.nH, total); break;
-    case 16: hipLaunchKernelGGL((dec_cross_merge_kernel<T, 16>), grid, block, 0, st, cp.partial, out, cp.ldo, cp.nH, total); break;
+    case 2: hipLaunchKernelGGL((dec_cross_merge_kernel<T, 2>), grid, block, 0, st, cp.partial, out, cp.ldo, cp.nH, total, cp.lo_off); break;
+    case 4: hipLaunchKernelGGL((dec_cross_merge_kernel<T, 4>), grid, block, 0, st, cp.partial, out, cp.ldo, cp.nH, total, cp.lo_off); break;
+    case 8: hipLaunchKernelGGL((dec_cross_merge_kernel<T, 8>), grid, block, 0, st, cp.partial, out, cp.ldo, cp.nH, total, cp.lo_off); break;
+    case 16: hipLaunchKernelGGL((dec_cross_merge_kernel<T, 16>), grid, block, 0, st, cp.partial, out, cp.ldo, cp.nH, total, cp.lo_off); break;
     default: omp_set_error("omp_dec_cross_attn_step: unsupported workgroup split %d", S); return OMP_ERR_INVALID;
   }
   return OMP_OK;
@@ -1171,7 +1318,7 @@ int launch_merge(const CrossP& cp, int S, hipStream_t st) {
 
 template <typename T, int NS, int CH, bool NT>
 int launch_cross_q4(const CrossP& cp, int n_groups, int S, hipStream_t st) {
-  const size_t smem = (size_t)NS * 8192;
+  const size_t smem = (size_t)NS * 8192 * CrossTraits<T>::PL;
   auto kern = dec_cross_attn_q4_kernel<T, NS, CH, NT>;
   static bool done = false;   // per template instantiation
   if (!done) {
@@ -1204,9 +1351,31 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   }
   int rc;
   const bool f = dtype == OMP_F32;
+  const bool nt_on = cx.cross_nt == 1 || (cx.cross_nt == 2 && n_groups >= 32);
+  if (dtype == OMP_BF16X2) {
+    // split-plane slabs (the parity engine): fp32 q / out, three bf16 products per score / value block.  A ring stage is 16 KB: four
+    // stages of one block each (64 KB, two workgroups per CU; selector 4: eight stages in 64-key chunks, one workgroup per CU);
+    // the register-streaming kernel keeps 2 blocks (32 KB) in flight per wave.
+    if (q4) {
+      if (cx.cross_q4 == 4) rc = nt_on ? launch_cross_q4<bf16s_t, 8, 2, true>(cp, n_groups, S, st) : launch_cross_q4<bf16s_t, 8, 2, false>(cp, n_groups, S, st);
+      else rc = nt_on ? launch_cross_q4<bf16s_t, 4, 1, true>(cp, n_groups, S, st) : launch_cross_q4<bf16s_t, 4, 1, false>(cp, n_groups, S, st);
+    }
+    else if (qt == 1) rc = nt_on ? launch_cross_t<bf16s_t, 1, 2, true>(cp, n_groups, S, st) : launch_cross_t<bf16s_t, 1, 2>(cp, n_groups, S, st);
+    else if (qt == 2) rc = launch_cross_t<bf16s_t, 2, 2>(cp, n_groups, S, st);
+    else rc = launch_cross_t<bf16s_t, 4, 1>(cp, n_groups, S, st);
+    if (rc != OMP_OK) return rc;
+    if (prof) omp_prof_end(OMP_PROF_CROSS, prof_slot, st);
+    OMP_CHECK_LAUNCH("omp_dec_cross_attn_step(split planes)");
+    if (S > 1) {
+      rc = launch_merge<float>(cp, S, st);
+      if (rc != OMP_OK) return rc;
+      OMP_CHECK_LAUNCH("omp_dec_cross_attn_step(merge)");
+    }
+    return OMP_OK;
+  }
   // PD key blocks in flight per wave: with one query tile a wave's whole slice is usually 4 blocks -> all of it
   if (q4) {
-    const bool nt = cx.cross_nt == 1 || (cx.cross_nt == 2 && n_groups >= 32);
+    const bool nt = nt_on;
     switch (cx.cross_q4) {
       case 2: rc = f ? launch_cross_q4<float, 8, 1, false>(cp, n_groups, S, st) : launch_cross_q4<bf16_t, 8, 1, false>(cp, n_groups, S, st); break;    // one block per step (round-2 start)
       case 4: rc = f ? launch_cross_q4<float, 8, 2, false>(cp, n_groups, S, st) : launch_cross_q4<bf16_t, 8, 2, false>(cp, n_groups, S, st); break;    // A/B: chunks with temporal loads (an 80 KB ring, 4 chunks ahead, measured equal: r02y)
@@ -1297,11 +1466,13 @@ extern "C" int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K
                                        int nH, int n_split, omp_stream_t s) {
   OMP_CHECK_ARG(q && K && Vt && groups && out, "omp_dec_cross_attn_step: null pointer");
   OMP_CHECK_ARG(R > 0, "omp_dec_cross_attn_step: bad R");
-  OMP_CHECK_ARG(dtype == OMP_F32 || dtype == OMP_BF16, "omp_dec_cross_attn_step: bad dtype");
+  OMP_CHECK_ARG(dtype == OMP_F32 || dtype == OMP_BF16 || dtype == OMP_BF16X2, "omp_dec_cross_attn_step: bad dtype");
   OMP_CHECK_ARG(n_groups > 0 && n_split > 0 && M > 0, "omp_dec_cross_attn_step: bad sizes");
+  OMP_CHECK_ARG(dtype != OMP_BF16X2 || (ldq % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)out % 16) == 0),
+                "omp_dec_cross_attn_step: split-plane slabs take 16-byte aligned fp32 q / out rows");
   CrossP cp;
   cp.q = q; cp.ldq = ldq; cp.K = K; cp.V = Vt; cp.img_stride = img_stride; cp.kmask = key_mask; cp.groups = groups;
-  cp.out = out; cp.ldo = ldo; cp.partial = partial; cp.M = M; cp.Mpad = Mpad; cp.nH = nH; cp.R = R; cp.kpw = 0;
+  cp.out = out; cp.ldo = ldo; cp.partial = partial; cp.M = M; cp.Mpad = Mpad; cp.nH = nH; cp.R = R; cp.kpw = 0; cp.lo_off = 0;
   return launch_cross(cp, n_groups, dtype, n_split, q_tiles, (hipStream_t)s);
 }
 
@@ -1361,10 +1532,13 @@ int step_launch_x3(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
   CrossP cp;
   cp.q = P->q; cp.ldq = d; cp.img_stride = P->kv_img_stride; cp.Mpad = P->Mpad;
   cp.kmask = P->key_mask; cp.groups = P->tiles; cp.out = P->att; cp.ldo = d;
-  cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R; cp.kpw = 0;
+  cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R; cp.kpw = 0; cp.lo_off = 0;
   RUN(omp_dec_embed_ln(P->seq, P->seq_ld, P->d_pos, P->word_emb, P->pos_tab, P->emb_g, P->emb_b, P->x, nullptr, F, R, d, P->eps, st));
   void* ys = P->y;       // [R, 2d] bf16 split pairs (the bytes of the fp32 [R, d] buffer)
   void* as = P->ffh;     // attention outputs as split pairs (the FFN hidden buffer is free until ff1)
+  if (P->kv_split) {     // split-plane slabs: the cross-attention kernels write the pair rows of the out-projection themselves
+    cp.out = as; cp.ldo = 2 * (int64_t)d; cp.lo_off = d;
+  }
   for (int li = 0; li < P->n_layers; ++li) {
     const omp_dec_layer& L = P->layers[li];
     cp.K = L.crossK; cp.V = L.crossVt;
@@ -1375,8 +1549,12 @@ int step_launch_x3(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
     RUN(gemm_x3(P, as, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x, F, OMP_ACT_NONE, st));
     RUN(omp_layernorm(P->x, F, L.n2_g, L.n2_b, ys, S2, nullptr, R, d, P->eps, st));
     RUN(gemm_x3(P, ys, L.ca_q_w, d, d, L.ca_qbias_tab, P->d_pos, d, nullptr, P->q, F, OMP_ACT_NONE, st));
-    RUN(launch_cross(cp, P->n_tiles, F, P->n_split, P->q_tiles, st));
-    RUN(omp_split_bf16(reinterpret_cast<const float*>(P->att), d, as, 2 * d, R, d, 0, st));
+    if (P->kv_split) {
+      RUN(launch_cross(cp, P->n_tiles, OMP_BF16X2, P->n_split, P->q_tiles, st));
+    } else {
+      RUN(launch_cross(cp, P->n_tiles, F, P->n_split, P->q_tiles, st));
+      RUN(omp_split_bf16(reinterpret_cast<const float*>(P->att), d, as, 2 * d, R, d, 0, st));
+    }
     RUN(gemm_x3(P, as, L.ca_out_w, d, d, L.ca_out_b, nullptr, 0, P->x, P->x, F, OMP_ACT_NONE, st));
     RUN(omp_layernorm(P->x, F, L.n3_g, L.n3_b, ys, S2, nullptr, R, d, P->eps, st));
     RUN(gemm_x3(P, ys, L.ff1_w, d, P->d_ff, L.ff1_b, nullptr, 0, nullptr, P->ffh, S2, OMP_ACT_RELU, st));
@@ -1446,7 +1624,8 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
   CrossP cp;
   cp.q = P->q; cp.ldq = d; cp.img_stride = P->kv_img_stride; cp.Mpad = P->Mpad;
   cp.kmask = P->key_mask; cp.groups = P->tiles; cp.out = P->att; cp.ldo = d;
-  cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R; cp.kpw = 0;
+  cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R; cp.kpw = 0; cp.lo_off = 0;
+  const int TC = P->kv_split ? OMP_BF16X2 : T;   // slab format the cross-attention kernels read (split planes: fp32 q / out)
   for (int li = 0; li < P->n_layers; ++li) {
     const omp_dec_layer& L = P->layers[li];
     cp.K = L.crossK; cp.V = L.crossVt;
@@ -1459,7 +1638,7 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
       }
       RUN(gemm(P, P->att, d, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
       RUN(ln_gemm(P, L.n2_g, L.n2_b, L.ca_q_w, d, L.ca_qbias_tab, P->d_pos, d, P->q, T, OMP_ACT_NONE, st));
-      RUN(launch_cross(cp, P->n_tiles, T, P->n_split, P->q_tiles, st));
+      RUN(launch_cross(cp, P->n_tiles, TC, P->n_split, P->q_tiles, st));
       RUN(gemm(P, P->att, d, L.ca_out_w, d, d, L.ca_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
       RUN(ln_gemm(P, L.n3_g, L.n3_b, L.ff1_w, P->d_ff, L.ff1_b, nullptr, 0, P->ffh, T, OMP_ACT_RELU, st));
       RUN(gemm(P, P->ffh, P->d_ff, L.ff2_w, P->d_ff, d, L.ff2_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
@@ -1469,7 +1648,7 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
       RUN(gemm(P, P->att, d, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x2, OMP_F32, OMP_ACT_NONE, st));
       RUN(omp_layernorm(P->x2, OMP_F32, L.n1_g, L.n1_b, P->y, T, P->x, R, d, P->eps, st));
       RUN(gemm(P, P->y, d, L.ca_q_w, d, d, L.ca_qbias_tab, P->d_pos, d, nullptr, P->q, T, OMP_ACT_NONE, st));
-      RUN(launch_cross(cp, P->n_tiles, T, P->n_split, P->q_tiles, st));
+      RUN(launch_cross(cp, P->n_tiles, TC, P->n_split, P->q_tiles, st));
       RUN(gemm(P, P->att, d, L.ca_out_w, d, d, L.ca_out_b, nullptr, 0, P->x, P->x2, OMP_F32, OMP_ACT_NONE, st));
       RUN(omp_layernorm(P->x2, OMP_F32, L.n2_g, L.n2_b, P->y, T, P->x, R, d, P->eps, st));
       RUN(gemm(P, P->y, d, L.ff1_w, d, P->d_ff, L.ff1_b, nullptr, 0, nullptr, P->ffh, T, OMP_ACT_RELU, st));
@@ -1496,6 +1675,7 @@ int check_plan(const omp_decoder_plan* P) {
                     P->hh1 && P->logits && P->tiles,
                 "omp_decoder_run: null buffer in plan");
   OMP_CHECK_ARG(P->pre_norm || P->x2, "omp_decoder_run: post-norm needs x2");
+  OMP_CHECK_ARG(!P->kv_split || (P->dtype == OMP_F32 && P->Mpad % 32 == 0), "omp_decoder_run: split-plane K / V^T slabs go with fp32 plans and 32-key blocks");
   return OMP_OK;
 }
 

@@ -66,6 +66,19 @@ __device__ __forceinline__ void store4(const GemmP& p, int64_t m, int n, const f
     const int d = p.kv_nH * 64;
     const int b = (int)(m / p.kv_tok), ml = (int)(m % p.kv_tok);
     const int nl = n / d, h = (n % d) >> 6, dd = n & 63;
+    if constexpr (sizeof(TOut) == 2) {
+      if (p.split_out) {   // split planes: block ml / 32 = [hi plane 32 x 64 | lo plane]
+        TOut* dst = C + (((((int64_t)nl * p.kv_B + b) * p.kv_nH + h) * (p.kv_mpad >> 5) + (ml >> 5)) * 2) * 2048 + (ml & 31) * 64 + dd;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) {
+            const bf16_t hi = (bf16_t)v[r];
+            dst[r] = hi;
+            dst[2048 + r] = (bf16_t)(v[r] - (float)hi);
+          }
+        return;
+      }
+    }
     TOut* dst = C + ((((int64_t)nl * p.kv_B + b) * p.kv_nH + h) * p.kv_mpad + ml) * 64 + dd;
     if (n + 3 < p.N) {
       if constexpr (sizeof(TOut) == 4) *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
@@ -83,14 +96,28 @@ __device__ __forceinline__ void store4(const GemmP& p, int64_t m, int n, const f
     // product consumes them (bf16: slot 8g + 4*half + r <-> key 16*half + 4g + r; f32: natural order).
     const int d = p.kv_nH * 64, KB = p.kv_kb;
     const int nl = (int)(m / d), h = (int)(m % d) >> 6, dd = (int)m & 63;
+    const int PLN = (sizeof(TOut) == 2 && p.split_out) ? 2 : 1;   // split planes: a block is [hi plane 64 x KB | lo plane]
     auto slot = [&](int tok, int& b) -> int64_t {
       b = tok / p.kv_tok;
       const int ml = tok - b * p.kv_tok;
       const int blk = ml / KB, kl = ml - blk * KB;
       const int pos = (KB == 32) ? (((kl & 15) >> 2) * 8 + (kl >> 4) * 4 + (kl & 3)) : kl;
-      return ((((int64_t)nl * p.kv_B + b) * p.kv_nH + h) * (p.kv_mpad / KB) + blk) * (64 * KB) + dd * KB + pos;
+      return ((((int64_t)nl * p.kv_B + b) * p.kv_nH + h) * (p.kv_mpad / KB) + blk) * (64 * KB * PLN) + dd * KB + pos;
     };
     int b0, b3;
+    if constexpr (sizeof(TOut) == 2) {
+      if (p.split_out) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) {
+            const int64_t i = slot(n + r, b3);
+            const bf16_t hi = (bf16_t)v[r];
+            C[i] = hi;
+            C[i + 64 * KB] = (bf16_t)(v[r] - (float)hi);
+          }
+        return;
+      }
+    }
     const int64_t i0 = slot(n, b0);
     if (n + 3 < p.N && (p.kv_tok & 3) == 0) {   // 4 tokens of one image, contiguous slots
       (void)b3;
@@ -730,14 +757,20 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
     return launch_small<T, TOut>(p, st);
   }
   if (which == 0) {
+    // round 4 (profiles/r04b_kbench_dec_rows*.txt, the 10240-row polygon / recognition phases of a 160-image engine call): 64x64
+    // tiles only below 256 tiles of 128x128 (they lose 10-25 % to the 128x128 kernel at 320 tiles, at K = 512 and at the bf16x3
+    // engine's K = 1536 / 6144 alike)
     if (p.M <= 64) which = 3;
-    else if (ceil_div64(p.M, 128) * ceil_div64(p.N, 128) < 512) which = 6;
+    else if (ceil_div64(p.M, 128) * ceil_div64(p.N, 128) < 256) which = 6;
     else which = 5;
-    // 256x256 phase-interleaved tiles once they fill the chip (>= one tile per CU) and the output is wide enough for a
-    // 256-column tile to pay (profiles/r02g_kbench_gemm_256.txt: wins on every Swin qkv / fc1 / fc2 / proj shape of
-    // stages 1-3 with >= 256 tiles, loses at N = 128 and on half-empty grids)
+    // 256x256 phase-interleaved tiles once they fill the chip and the output is wide enough for a 256-column tile to pay
+    // (profiles/r02g_kbench_gemm_256.txt: wins on every Swin qkv / fc1 / fc2 / proj shape of stages 1-3 with >= 256 tiles, loses
+    // at N = 128 and on half-empty grids).  "Fill the chip" = the last round of tiles over the 256 CUs is not mostly idle: 240
+    // tiles (one round, 94 %) win, 320 tiles (two rounds, 62 %) lose to the 128x128 kernel (r04b)
     if constexpr (std::is_same<T, bf16_t>::value) {
-      if (which == 5 && p.N >= 256 && ceil_div64(p.M, 256) * ceil_div64(p.N, 256) >= 256 && gemm256_ok(p, true, std::is_same<TOut, bf16_t>::value)) which = 9;
+      const int64_t t256 = ceil_div64(p.M, 256) * ceil_div64(p.N, 256);
+      const bool fills = t256 >= 192 && 4 * t256 >= 3 * 256 * ceil_div64(t256, 256);
+      if (which == 5 && p.N >= 256 && fills && gemm256_ok(p, true, std::is_same<TOut, bf16_t>::value)) which = 9;
     }
   }
   if (p.C2 != nullptr && which != 5 && which != 6 && which != 9 && which != 15) {
@@ -813,9 +846,10 @@ extern "C" int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s) {
   OMP_CHECK_ARG(a->out_dtype == a->dtype || a->out_dtype == OMP_F32 || (a->out_dtype == OMP_BF16X2 && a->dtype == OMP_BF16),
                 "omp_gemm_bias_act: out_dtype must equal dtype, be f32, or be split-bf16 pairs with bf16 operands");
   const bool split_out = a->out_dtype == OMP_BF16X2;
-  OMP_CHECK_ARG(!split_out || (a->residual == nullptr && a->C2 == nullptr && a->store_mode == OMP_STORE_PLAIN && !a->trans_out &&
-                               a->ldc >= 2 * (int64_t)a->N),
-                "omp_gemm_bias_act: split-bf16 destinations are plain [M, 2N] rows without residual / second destination");
+  OMP_CHECK_ARG(!split_out || (a->residual == nullptr && a->C2 == nullptr && !a->trans_out &&
+                               (a->store_mode == OMP_STORE_PLAIN ? (a->ldc >= 2 * (int64_t)a->N && a->N % 8 == 0) : a->kv_key_block == 32)),
+                "omp_gemm_bias_act: split-bf16 destinations are plain [M, 2N] rows (N %% 8 == 0) or split-plane K / V^T slabs of 32-key blocks, "
+                "without residual / second destination");
   OMP_CHECK_ARG(a->a_wrap >= 0 && (a->a_wrap == 0 || (a->dtype == OMP_BF16 && a->a_wrap % 64 == 0 && a->a_wrap < a->K && a->K <= 2 * a->a_wrap &&
                                                       a->ln_gamma == nullptr)),
                 "omp_gemm_bias_act: a_wrap needs bf16 operands, a_wrap %% 64 == 0 and a_wrap < K <= 2 * a_wrap");

@@ -132,6 +132,9 @@ class Decoder(object):
     def __init__(self, sd, args, dtype, device, x3=False):
         self.args, self.dtype, self.device = args, dtype, device
         self.x3 = bool(x3)   # bf16x3 engine: the K / V^T projection of the memory runs as split-bf16 products (decoder steps stay fp32)
+        # ... and (round 4) writes SPLIT-PLANE slabs: 32-key blocks of [hi plane | lo plane] bf16 -- the bytes of the fp32 slabs, streamed
+        # by cross-attention kernels that run three bf16 matrix-core products per block instead of fp32 ones (csrc/decoder.hip, bf16s_t)
+        self.kv_split = self.x3 and os.environ.get('OMP355_KV_SPLIT', '1') != '0'
         self.d, self.nH, self.L = args.tfm_hidden_dim, args.tfm_nheads, args.tfm_dec_layers
         self.ff, self.V = args.tfm_dim_feedforward, args.num_classes
         if self.d != self.nH * 64:
@@ -209,15 +212,19 @@ class Decoder(object):
           K   = (memory+pos) Wk^T + bk  ->  [NL][B][nH][Mpad][64]
           V^T = (memory Wv^T + bv)^T    ->  [NL][B][nH][Mpad/KB][64][KB]
         The padded tail (keys >= M) is zero from allocation and never written."""
-        KB = 16 if self.dtype == torch.float32 else 32
+        KB = 16 if (self.dtype == torch.float32 and not self.kv_split) else 32
         Mpad = _round_up(M, KB)
         key = (B, M)
         if key not in self._kv:
             while len(self._kv) >= MAX_KV_ENTRIES:
                 self._kv.popitem(last=False)   # plans bound to these slabs keep them alive until their phase goes too
-            self._kv[key] = (torch.zeros(self.NL, B, self.nH, Mpad, 64, dtype=self.dtype, device=self.device),
-                             torch.zeros(self.NL, B, self.nH, Mpad // KB, 64, KB, dtype=self.dtype, device=self.device),
-                             torch.zeros(B, M, dtype=torch.uint8, device=self.device))
+            if self.kv_split:   # [block][plane][32 keys x 64 dims] and [block][plane][64 dims x 32 key slots]
+                slabs = (torch.zeros(self.NL, B, self.nH, Mpad // 32, 2, 32, 64, dtype=torch.bfloat16, device=self.device),
+                         torch.zeros(self.NL, B, self.nH, Mpad // 32, 2, 64, 32, dtype=torch.bfloat16, device=self.device))
+            else:
+                slabs = (torch.zeros(self.NL, B, self.nH, Mpad, 64, dtype=self.dtype, device=self.device),
+                         torch.zeros(self.NL, B, self.nH, Mpad // KB, 64, KB, dtype=self.dtype, device=self.device))
+            self._kv[key] = slabs + (torch.zeros(B, M, dtype=torch.uint8, device=self.device),)
         self._kv.move_to_end(key)
         K_all, Vt_all, mask_buf = self._kv[key]
         if key_mask is not None:
@@ -227,9 +234,10 @@ class Decoder(object):
         geom = (B, M, Mpad, self.nH, KB)
         if self.x3:
             d = self.d
-            ops.gemm(ops.split_bf16(mem_pos), self.Wk_all, self.bk_all, out=K_all, store_mode=_lib.STORE_KBLK, kv=geom, a_wrap=2 * d,
+            od = ops.SPLIT if self.kv_split else None
+            ops.gemm(ops.split_bf16(mem_pos), self.Wk_all, self.bk_all, out=K_all, out_dtype=od, store_mode=_lib.STORE_KBLK, kv=geom, a_wrap=2 * d,
                      M=B * M, N=self.Wk_all.shape[0], K=3 * d)
-            ops.gemm(self.Wv_all, ops.split_bf16(memory, triple=True), self.bv_all, out=Vt_all, store_mode=_lib.STORE_VBLK, kv=geom,
+            ops.gemm(self.Wv_all, ops.split_bf16(memory, triple=True), self.bv_all, out=Vt_all, out_dtype=od, store_mode=_lib.STORE_VBLK, kv=geom,
                      bias_along_m=True, a_wrap=2 * d, M=self.Wv_all.shape[0], N=B * M, K=3 * d)
             return dict(K=K_all, Vt=Vt_all, B=B, M=M, Mpad=Mpad, KB=KB, key_mask=key_mask)
         ops.gemm(mem_pos, self.Wk_all, self.bk_all, out=K_all, store_mode=_lib.STORE_KBLK, kv=geom)
@@ -265,11 +273,12 @@ class Decoder(object):
     def _bind(self, ph, kv, tiles, n_prompt, suppress_eos, infer_vie):
         tiles, qt = tiles
         P, a, d = ph.plan, self.args, self.d
-        esz = 4 if self.dtype == torch.float32 else 2
+        esz = 4 if self.dtype == torch.float32 else 2   # bytes per (key, dim): a split-plane pair is 2 x 2
         P.dtype, P.n_layers, P.d_model, P.n_heads, P.d_ff, P.vocab = ops.dt(self.dtype), self.L, d, self.nH, self.ff, self.V
         P.pre_norm = 1 if a.tfm_pre_norm else 0
         use_x3 = bool(self.x3 and a.tfm_pre_norm and ph.R >= self.X3_MIN_ROWS and d % 64 == 0 and self.ff % 64 == 0)
         P.gemm_x3 = 1 if use_x3 else 0
+        P.kv_split = 1 if self.kv_split else 0
         x3_layers, x3_head = self._x3_weights(ph.kind) if use_x3 else (None, None)
         P.R, P.Lmax, P.M, P.Mpad, P.n_tiles, P.q_tiles, P.n_split, P.n_prompt = (ph.R, ph.Lmax, kv['M'], kv['Mpad'], len(tiles), qt,
                                                                                  ph.n_split, n_prompt)
@@ -278,7 +287,7 @@ class Decoder(object):
         ph.tiles[:t.shape[0]].copy_(t.to(self.device, non_blocking=False))
         ph.n_tiles = t.shape[0]
         kidx = KINDS.index(ph.kind)
-        img_stride = self.nH * kv['Mpad'] * 64
+        img_stride = self.nH * kv['Mpad'] * 64      # (key, dim) pairs per image
         slab = kv['B'] * img_stride   # one (decoder, layer) slab, K and V^T alike
         for l, w in enumerate(self.layers[ph.kind]):
             Lc = P.layers[l]
@@ -294,7 +303,7 @@ class Decoder(object):
         P.fn_g, P.fn_b = self.fn[ph.kind][0].data_ptr(), self.fn[ph.kind][1].data_ptr()
         (P.h0_w, P.h0_b), (P.h1_w, P.h1_b), (P.h2_w, P.h2_b) = [((x3_head[i] if use_x3 else w).data_ptr(), b.data_ptr())
                                                                  for i, (w, b) in enumerate(self.head[ph.kind])]
-        P.kv_img_stride = img_stride
+        P.kv_img_stride = img_stride * (2 if self.kv_split else 1)   # in slab elements: two bf16 planes per (key, dim)
         P.key_mask = kv['key_mask'].data_ptr() if kv['key_mask'] is not None else None
         P.tiles = ph.tiles.data_ptr()
         P.seq, P.seq_ld, P.d_pos, P.probs = ph.seq.data_ptr(), ph.seq_ld, ph.d_pos.data_ptr(), ph.probs.data_ptr()
@@ -356,7 +365,7 @@ class Decoder(object):
         Per-wave slice ~4 key blocks (one memory round trip with 4 blocks in flight) but never fewer than
         ~512 workgroups' worth of parallelism when the memory is large; power of two <= 16."""
         groups, qt = tiles
-        kb = 16 if self.dtype == torch.float32 else 32
+        kb = 16 if (self.dtype == torch.float32 and not self.kv_split) else 32
         if self.n_split_override:
             return self.n_split_override
         if qt == 4:   # bf16 and fp32 slabs alike (csrc/decoder.hip: dec_cross_attn_q4_kernel)

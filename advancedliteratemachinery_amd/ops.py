@@ -263,10 +263,17 @@ def dec_self_attn_step(qkv, kcache, vcache, out, d_pos, nH):
 
 
 def dec_cross_attn_step(q, K, Vt, img_stride, Mpad, key_mask, groups, n_groups, q_tiles, partial, out, M, nH, n_split):
+    """K / Vt in q's dtype: the bf16 / fp32 slabs; fp32 q with bf16 K / Vt: SPLIT-PLANE slabs (OMP_BF16X2: 32-key blocks of
+    [hi plane | lo plane], img_stride = nH * Mpad * 128 bf16 elements; fp32 out)."""
     R = q.shape[0]
+    split = q.dtype == torch.float32 and K.dtype == torch.bfloat16
+    if split and (Vt.dtype != torch.bfloat16 or out.dtype != torch.float32):
+        raise TypeError('split-plane slabs: bf16 K and V^T planes, fp32 q and out')
+    if not split and (K.dtype != q.dtype or Vt.dtype != q.dtype or out.dtype != q.dtype):
+        raise TypeError('dec_cross_attn_step: q, K, V^T and out share one dtype (or fp32 q / out over split-plane bf16 slabs)')
     rc = _lib.lib().omp_dec_cross_attn_step(ptr(q), q.stride(0), ptr(K), ptr(Vt), img_stride, Mpad, ptr(key_mask),
                                             ptr(groups), n_groups, q_tiles, R, ptr(partial), ptr(out), out.stride(0),
-                                            dt(q), M, nH, n_split, stream())
+                                            OMP_BF16X2 if split else dt(q), M, nH, n_split, stream())
     _lib.check(rc, 'omp_dec_cross_attn_step')
 
 

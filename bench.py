@@ -136,7 +136,7 @@ def pin_host_threads(local_rank, ranks_on_node):
         return None
 
 
-def pmc_traffic(images_per_launch):
+def pmc_traffic(images_per_launch, prefix=''):
     """HBM bytes per cross-attention launch from the rocprofv3 PMC passes (separate runs; tools/pmc_cross_json.py
     turns their summaries into profiles/pmc_cross_attn.json, one record per images-per-launch).  FETCH_SIZE is in KiB
     and counts 16-byte/lane streaming reads at half their size on gfx950 (MI355X_MICROARCH.md, HBM) -> x2;
@@ -147,7 +147,7 @@ def pmc_traffic(images_per_launch):
             rec = json.load(f)
         if 'images_per_launch' in rec:          # single record (round-1 format)
             rec = {str(rec['images_per_launch']): rec}
-        r = rec.get(str(int(images_per_launch)))
+        r = rec.get(prefix + str(int(images_per_launch)))   # prefix 'x3_': the split-plane kernels of the parity engine (tools/cross_pmc.py <images> split)
         if r is None:
             return None
         return float(r['fetch_kib_mean']) * 1024.0 * 2.0 + float(r['write_kib_mean']) * 1024.0
@@ -703,6 +703,85 @@ def main():
             args.pt_seq_length = keep
             pools['active'] = pool
 
+    def measure_rooflines(mdl, dtype_name, n_groups):
+        """Kernel classes of engine `mdl` timed with HIP events over `n_groups` eager engine calls -> (dominant class, other classes)."""
+        # Kernel classes timed with HIP events on their launch streams over the same engine calls as the timed region,
+        # launched eagerly on one stream (events cannot bracket kernels inside a graph replay; one lane so that a
+        # kernel's duration is its own): large-M GEMMs and the fused MLP (matrix-core bound, flops counted by the
+        # library per launch) and the decoder cross-attention (HBM bound: streams K and V^T of every image once per
+        # launch, shared by all query rows).
+        was = mdl.use_graph
+        mdl.use_graph = False
+        h = _lib.lib()
+        with torch.cuda.stream(stream):
+            run_group(0, G, model=mdl)
+            torch.cuda.synchronize()
+            h.omp_prof_enable(7)
+            for i in range(n_groups):
+                run_group(i * G, G, model=mdl)
+            torch.cuda.synchronize()
+
+        def read(cls):
+            tot, cnt, work = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+            h.omp_prof_read_class(cls, ctypes.byref(tot), ctypes.byref(cnt), ctypes.byref(work))
+            return tot.value, cnt.value, work.value
+        def read_roof(cls):
+            by, rs = ctypes.c_double(0), ctypes.c_double(0)
+            h.omp_prof_read_roofline(cls, ctypes.byref(by), ctypes.byref(rs))
+            return by.value, rs.value
+        t_cross, n_cross, _ = read(0)
+        t_gemm, n_gemm, f_gemm = read(1)
+        t_mlp, n_mlp, f_mlp = read(2)
+        (b_gemm, r_gemm), (b_mlp, r_mlp) = read_roof(1), read_roof(2)
+        h.omp_prof_enable(0)
+        mdl.use_graph = was
+        M = (a.size // 16) ** 2
+        esz = 2 if dtype_name == 'bf16' else 4   # bytes per (key, dim) of the K / V^T slabs: bf16; fp32, or split-bf16 planes [hi | lo] (bf16x3)
+        BI = B * G   # images per launch
+        recs = []
+        if n_gemm:
+            tf = f_gemm / (t_gemm / 1e3) / 1e12
+            gt = pmc_gemm_traffic(a.size, dtype_name)
+            grec = dict(bound='mfma', kernel='gemm_256 + gemm_dma<128,128,2> (Swin qkv / proj / fc1 / fc2 / merge, FPN, input_proj, K-V projection)',
+                        achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=gt[0] if gt else None,
+                        launches=int(n_gemm), avg_us=t_gemm / n_gemm * 1e3, flops_per_launch=f_gemm / n_gemm,
+                        gpu_ms_per_image=t_gemm / (n_groups * BI))
+            # the class mixes matrix-core-bound (stage 2 / 3) and HBM-bound products (K = 128 / 256, fp32 decoder outputs): the time
+            # its launches would take on their OWN rooflines, max(flops / 2.5 PF, algorithmic bytes / 8 TB/s) each, over the measured time
+            grec['alg_bytes_per_launch'] = b_gemm / n_gemm
+            grec['frac_of_launch_rooflines'] = r_gemm / (t_gemm / 1e3)
+            if gt:
+                grec['traffic_over_algorithmic'] = gt[1]
+                grec['traffic_scope'] = ('HBM bytes per GEMM launch of one 32-image encoder chunk + its K / V^T projection (profiles/pmc_gemm.json); '
+                                         'the decoder-phase GEMMs of this class are not in that pass')
+            recs.append((t_gemm, grec))
+        if n_mlp:
+            tf = f_mlp / (t_mlp / 1e3) / 1e12
+            recs.append((t_mlp, dict(bound='mfma', kernel='mlp_fused_kernel (Swin stages 0/1: LayerNorm + fc1 + GELU + fc2 + residual)',
+                                     achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None,
+                                     launches=int(n_mlp), avg_us=t_mlp / n_mlp * 1e3, flops_per_launch=f_mlp / n_mlp,
+                                     alg_bytes_per_launch=b_mlp / n_mlp, frac_of_launch_rooflines=r_mlp / (t_mlp / 1e3),
+                                     gpu_ms_per_image=t_mlp / (n_groups * BI))))
+        if n_cross:
+            # algorithmic bytes per launch (DESIGN.md 5): K + V^T of the images in the call (d = 512) + q in / o out of the
+            # rows (launch-weighted: 1 row/image in the point phase, N rows/image in polygon / recognition)
+            rows_avg = BI * (1 * (2 * N + 6) + N * (34 + 27)) / float((2 * N + 6) + 34 + 27)
+            alg = BI * 2 * M * 512 * esz + rows_avg * 2 * 512 * esz
+            avg_s = (t_cross / 1e3) / n_cross
+            ach = alg / avg_s / 1e9
+            recs.append((t_cross, dict(bound='hbm', kernel='dec_cross_attn_kernel / dec_cross_attn_q4_kernel' + (' <split-bf16 planes>' if dtype_name == 'bf16x3' else ''), achieved=ach, peak=HBM_PEAK_GBS,
+                                       unit='GB/s', frac=ach / HBM_PEAK_GBS, traffic=pmc_traffic(BI, 'x3_' if dtype_name == 'bf16x3' else ''), launches=int(n_cross),
+                                       avg_us=avg_s * 1e6, alg_bytes_per_launch=alg, images_per_launch=BI,
+                                       gpu_ms_per_image=t_cross / (n_groups * BI))))
+        recs.sort(key=lambda r: -r[0])
+        note = ('hipEvent-bracketed eager launches of %d engine calls of %d images on one stream (graph replay cannot be bracketed); '
+                'ordered by GPU time; traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch from the committed '
+                'PMC passes (profiles/pmc_cross_attn.json, profiles/pmc_gemm.json), null for classes / sizes without a pass' % (n_groups, BI))
+        if recs:
+            return dict(recs[0][1], note=note), [r for _, r in recs[1:]]
+        return None, []
+
+
     def parity_leg():
         # The engine that MEETS the parity contract (tests/test_gpu_e2e.py::test_parity_engine_bf16x3: logits within 1e-3 of the
         # reference, ids identical on every fixture) on the same workload and the same engine-call size, one lane
@@ -720,9 +799,10 @@ def main():
                 torch.cuda.synchronize()
                 rp.append(time.perf_counter() - t0)
         ep = pct(rp, 0.5)
+        proof, pother = (None, []) if (a.no_roofline or kp < G) else measure_rooflines(m2, 'bf16x3', 1)
         del m2
         torch.cuda.empty_cache()
-        return dict(engine='bf16x3', images_per_sec=B * kp / ep, chars_per_sec=B * kp / ep * N * args.rec_length, ms_per_step=ep / kp * 1e3,
+        return dict(engine='bf16x3', roofline=proof, roofline_other=pother, images_per_sec=B * kp / ep, chars_per_sec=B * kp / ep * N * args.rec_length, ms_per_step=ep / kp * 1e3,
                     images_per_engine_call=B * kp, repeats=len(rp),
                     note='cheapest engine precision that passes the fp32 parity gates (logits <= 1e-3, decoded ids identical, '
                          'tests/test_gpu_e2e.py::test_parity_engine_bf16x3): fp32 storage, large products as 3 bf16 matrix-core products '
@@ -795,82 +875,7 @@ def main():
 
     roof, roof_other = None, []
     if rank == 0 and not a.no_roofline:
-        # Kernel classes timed with HIP events on their launch streams over the same engine calls as the timed region,
-        # launched eagerly on one stream (events cannot bracket kernels inside a graph replay; one lane so that a
-        # kernel's duration is its own): large-M GEMMs and the fused MLP (matrix-core bound, flops counted by the
-        # library per launch) and the decoder cross-attention (HBM bound: streams K and V^T of every image once per
-        # launch, shared by all query rows).
-        was = model.use_graph
-        model.use_graph = False
-        h = _lib.lib()
-        n_groups = max(1, min(4, (a.steps + G - 1) // G))
-        with torch.cuda.stream(stream):
-            run_group(0, G)
-            torch.cuda.synchronize()
-            h.omp_prof_enable(7)
-            for i in range(n_groups):
-                run_group(i * G, G)
-            torch.cuda.synchronize()
-
-        def read(cls):
-            tot, cnt, work = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
-            h.omp_prof_read_class(cls, ctypes.byref(tot), ctypes.byref(cnt), ctypes.byref(work))
-            return tot.value, cnt.value, work.value
-        def read_roof(cls):
-            by, rs = ctypes.c_double(0), ctypes.c_double(0)
-            h.omp_prof_read_roofline(cls, ctypes.byref(by), ctypes.byref(rs))
-            return by.value, rs.value
-        t_cross, n_cross, _ = read(0)
-        t_gemm, n_gemm, f_gemm = read(1)
-        t_mlp, n_mlp, f_mlp = read(2)
-        (b_gemm, r_gemm), (b_mlp, r_mlp) = read_roof(1), read_roof(2)
-        h.omp_prof_enable(0)
-        model.use_graph = was
-        M = (a.size // 16) ** 2
-        esz = 2 if a.dtype == 'bf16' else 4   # K / V^T slabs: bf16, or fp32 (fp32 and bf16x3 engines)
-        BI = B * G   # images per launch
-        recs = []
-        if n_gemm:
-            tf = f_gemm / (t_gemm / 1e3) / 1e12
-            gt = pmc_gemm_traffic(a.size, a.dtype)
-            grec = dict(bound='mfma', kernel='gemm_256 + gemm_dma<128,128,2> (Swin qkv / proj / fc1 / fc2 / merge, FPN, input_proj, K-V projection)',
-                        achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=gt[0] if gt else None,
-                        launches=int(n_gemm), avg_us=t_gemm / n_gemm * 1e3, flops_per_launch=f_gemm / n_gemm,
-                        gpu_ms_per_image=t_gemm / (n_groups * BI))
-            # the class mixes matrix-core-bound (stage 2 / 3) and HBM-bound products (K = 128 / 256, fp32 decoder outputs): the time
-            # its launches would take on their OWN rooflines, max(flops / 2.5 PF, algorithmic bytes / 8 TB/s) each, over the measured time
-            grec['alg_bytes_per_launch'] = b_gemm / n_gemm
-            grec['frac_of_launch_rooflines'] = r_gemm / (t_gemm / 1e3)
-            if gt:
-                grec['traffic_over_algorithmic'] = gt[1]
-                grec['traffic_scope'] = ('HBM bytes per GEMM launch of one 32-image encoder chunk + its K / V^T projection (profiles/pmc_gemm.json); '
-                                         'the decoder-phase GEMMs of this class are not in that pass')
-            recs.append((t_gemm, grec))
-        if n_mlp:
-            tf = f_mlp / (t_mlp / 1e3) / 1e12
-            recs.append((t_mlp, dict(bound='mfma', kernel='mlp_fused_kernel (Swin stages 0/1: LayerNorm + fc1 + GELU + fc2 + residual)',
-                                     achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None,
-                                     launches=int(n_mlp), avg_us=t_mlp / n_mlp * 1e3, flops_per_launch=f_mlp / n_mlp,
-                                     alg_bytes_per_launch=b_mlp / n_mlp, frac_of_launch_rooflines=r_mlp / (t_mlp / 1e3),
-                                     gpu_ms_per_image=t_mlp / (n_groups * BI))))
-        if n_cross:
-            # algorithmic bytes per launch: K + V^T of the images in the call (d = 512) + q in / o out of the
-            # rows (launch-weighted: 1 row/image in the point phase, N rows/image in polygon / recognition)
-            rows_avg = BI * (1 * (2 * N + 6) + N * (34 + 27)) / float((2 * N + 6) + 34 + 27)
-            alg = BI * 2 * M * 512 * esz + rows_avg * 2 * 512 * esz
-            avg_s = (t_cross / 1e3) / n_cross
-            ach = alg / avg_s / 1e9
-            recs.append((t_cross, dict(bound='hbm', kernel='dec_cross_attn_kernel / dec_cross_attn_q4_kernel', achieved=ach, peak=HBM_PEAK_GBS,
-                                       unit='GB/s', frac=ach / HBM_PEAK_GBS, traffic=pmc_traffic(BI), launches=int(n_cross),
-                                       avg_us=avg_s * 1e6, alg_bytes_per_launch=alg, images_per_launch=BI,
-                                       gpu_ms_per_image=t_cross / (n_groups * BI))))
-        recs.sort(key=lambda r: -r[0])
-        note = ('hipEvent-bracketed eager launches of %d engine calls of %d images on one stream (graph replay cannot be bracketed); '
-                'ordered by GPU time; traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch from the committed '
-                'PMC passes (profiles/pmc_cross_attn.json, profiles/pmc_gemm.json), null for classes / sizes without a pass' % (n_groups, BI))
-        if recs:
-            roof = dict(recs[0][1], note=note)
-            roof_other = [r for _, r in recs[1:]]
+        roof, roof_other = measure_rooflines(model, a.dtype, max(1, min(4, (a.steps + G - 1) // G)))
 
     if rank == 0:
         rec = dict(metric='images/sec (1024x1024) + chars/sec decoded, OmniParser text-spotting', value=ips, unit='images/s',

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 16
+#define OMP_ABI_VERSION 17
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -98,7 +98,10 @@ typedef struct {
    *   VBLK: operands swapped by the caller (A = Wv [n_slabs*kv_heads*64, K], W = memory tokens
    *         [kv_images*kv_tokens, K], bias_along_m = 1) ->
    *         C[slab][image][head][kv_mpad/kv_key_block][64][kv_key_block], keys of a block in
-   *         matrix-core order (bf16, block 32: slot 8g+4*half+r <- key 16*half+4g+r; f32, block 16: natural) */
+   *         matrix-core order (bf16, block 32: slot 8g+4*half+r <- key 16*half+4g+r; f32, block 16: natural)
+   *   with out_dtype OMP_BF16X2 (kv_key_block 32): SPLIT-PLANE slabs -- every 32-key block holds [hi plane | lo plane] of bf16,
+   *         KBLK C[slab][image][head][kv_mpad/32][2][32][64], VBLK C[slab][image][head][kv_mpad/32][2][64][32] (the bytes of the
+   *         fp32 slabs; read by omp_dec_cross_attn_step with dtype OMP_BF16X2) */
   int32_t store_mode;
   int32_t bias_along_m; /* bias[m] instead of bias[n] */
   int32_t kv_images, kv_tokens, kv_mpad, kv_heads, kv_key_block;
@@ -237,6 +240,10 @@ int omp_dec_self_attn_step(const void* qkv, void* kcache, void* vcache, void* ou
  * key range of one (image, head) once for all rows of the group.  Keys are cut in n_split workgroup
  * splits (power of two <= 16) x 4 waves; n_split > 1 goes through `partial`
  * (fp32 [R][nH][n_split][68]) and a merge kernel.  The memory is never replicated per query row.
+ * dtype OMP_BF16X2 (round 4, the parity engine): K / Vt are SPLIT-PLANE slabs -- every 32-key block is [hi plane | lo plane] of
+ * bf16 (K [image][head][Mpad/32][2][32][64], V^T [image][head][Mpad/32][2][64][32], img_stride = nH*Mpad*128 bf16 elements; the
+ * bytes of the fp32 slabs, written by omp_gemm_bias_act with out_dtype OMP_BF16X2 and a blocked store mode), q and out are fp32
+ * rows; scores and values run as three bf16 matrix-core products each, i.e. fp32-grade results at the HBM rate.
  * Replaces multihead_attn of transformer.py:416-420/:442-446 with memory.repeat (transformer.py:88-96). */
 int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K, const void* Vt, int64_t img_stride,
                             int Mpad, const uint8_t* key_mask, const int32_t* groups, int n_groups,
@@ -298,6 +305,10 @@ typedef struct {
    * (sa_in_w ... ff2_w, h0_w ... h2_w) is the [out, 3 * in] bf16 image [w_hi | w_hi | w_lo] of the fp32 weight and the step's
    * products run as split-bf16 products (omp_gemm_args.a_wrap); activations, caches, slabs and every other kernel stay fp32. */
   int32_t gemm_x3;
+  /* kv_split = 1 (dtype OMP_F32): crossK / crossVt are split-plane slabs (OMP_BF16X2 with OMP_STORE_KBLK / OMP_STORE_VBLK, 32-key
+   * blocks of [hi plane | lo plane]); q and the attention output stay fp32 (with gemm_x3 the kernels write the out-projection's
+   * pair rows themselves).  kv_img_stride then counts bf16 elements: nH * Mpad * 128. */
+  int32_t kv_split;
   float eps;
   omp_dec_layer layers[OMP_MAX_DEC_LAYERS];
   const float *word_emb, *pos_tab, *emb_g, *emb_b, *fn_g, *fn_b;

@@ -484,6 +484,81 @@ def check_cross_attn():
     return out
 
 
+def check_cross_attn_split():
+    """The parity engine's SPLIT-PLANE slabs (round 4): K / V^T projection of an fp32 memory as bf16x3 products into 32-key blocks of
+    [hi plane | lo plane] (OMP_BF16X2 + OMP_STORE_KBLK / OMP_STORE_VBLK, both GEMM kernels: the scalar store path of the small
+    shapes and the 256x256 kernel's vector epilogue at 32768 tokens), then omp_dec_cross_attn_step on them with fp32 q / out -- every
+    query-tile count, key split, both ring geometries of the 64-row kernel -- vs softmax attention in fp64 (what
+    nn.MultiheadAttention computes, transformer.py:442-446).  Gates are the fp32 engine's."""
+    from advancedliteratemachinery_amd import _lib
+    from advancedliteratemachinery_amd.model.transformer import Decoder
+    out = []
+    nH, d, KB = 8, 512, 32
+    bf = torch.bfloat16
+    for (B, M, counts, masked) in ((2, 77, [19, 3], True), (3, 300, [1, 1, 1], False), (2, 130, [40, 64], True), (1, 4096, [5], False),
+                                    (2, 1000, [64, 50], False), (8, 4096, [1, 64, 1, 33, 1, 1, 2, 1], False)):
+        Mpad = (M + KB - 1) // KB * KB
+        mem = rnd(B * M, d, seed=M)
+        NLd = 2 * d   # two (decoder, layer) slabs
+        Wk, Wv = rnd(NLd, d, seed=1) / math.sqrt(d), rnd(NLd, d, seed=2) / math.sqrt(d)
+        bk, bv = rnd(NLd, seed=3) * 0.1, rnd(NLd, seed=4) * 0.1
+        Kd = torch.zeros(2, B, nH, Mpad // 32, 2, 32, 64, device=DEV, dtype=bf)
+        Vd = torch.zeros(2, B, nH, Mpad // 32, 2, 64, 32, device=DEV, dtype=bf)
+        geom = (B, M, Mpad, nH, KB)
+        memd = mem.to(DEV)
+        ops.gemm(ops.split_bf16(memd), ops.split_weight3(Wk.to(DEV)), bk.to(DEV), out=Kd, out_dtype=ops.SPLIT, store_mode=_lib.STORE_KBLK, kv=geom,
+                 a_wrap=2 * d, M=B * M, N=NLd, K=3 * d)
+        ops.gemm(ops.split_weight2(Wv.to(DEV)), ops.split_bf16(memd, triple=True), bv.to(DEV), out=Vd, out_dtype=ops.SPLIT, store_mode=_lib.STORE_VBLK,
+                 kv=geom, bias_along_m=True, a_wrap=2 * d, M=NLd, N=B * M, K=3 * d)
+        Kref = (mem.double() @ Wk.double().t() + bk.double()).reshape(B, M, 2, nH, 64)
+        Vref = (mem.double() @ Wv.double().t() + bv.double()).reshape(B, M, 2, nH, 64)
+        # the slabs themselves (slab 1): value = hi + lo
+        kval = Kd[1].float().sum(3).reshape(B, nH, Mpad, 64).cpu()          # [B][nH][blk][32][64] -> keys in natural order
+        kerr = (kval[:, :, :M].double() - Kref[:, :, 1].permute(0, 2, 1, 3)).abs().max().item()
+        vblk = Vd[1].float().sum(3).cpu()                                     # [B][nH][blk][64][32 slots]
+        kl = torch.arange(32)
+        pos = ((kl & 15) >> 2) * 8 + (kl >> 4) * 4 + (kl & 3)
+        nat = torch.empty_like(vblk)
+        nat[..., kl] = vblk[..., pos]
+        vnat = nat.permute(0, 1, 2, 4, 3).reshape(B, nH, Mpad, 64)[:, :, :M]
+        verr = (vnat.double() - Vref[:, :, 1].permute(0, 2, 1, 3)).abs().max().item()
+        lo_used = Kd[1, :, :, :, 1].float().abs().max().item() > 0 and Vd[1, :, :, :, 1].float().abs().max().item() > 0
+        pad_zero = (Kd[1].float().sum(3).reshape(B, nH, Mpad, 64)[:, :, M:].abs().max().item() if Mpad > M else 0.0)
+        out.append(rec('kv_split_slabs[B%d,M%d] K (hi + lo vs fp64)' % (B, M), kerr, 6e-5, 'lo planes written: %s' % lo_used))
+        out.append(rec('kv_split_slabs[B%d,M%d] V^T (hi + lo vs fp64)' % (B, M), verr, 6e-5))
+        out.append(rec('kv_split_slabs[B%d,M%d] lo planes in use, padded keys zero' % (B, M), (0.0 if lo_used else 1.0) + pad_zero, 0.0))
+        R = sum(counts)
+        qq = rnd(R, d, seed=7)
+        kmask = torch.zeros(B, M, dtype=torch.bool)
+        if masked:
+            kmask[B - 1, M - M // 3:] = True
+        ref = torch.empty(R, d, dtype=torch.float64)
+        r0 = 0
+        for b, n in enumerate(counts):
+            qh = qq[r0:r0 + n].double().reshape(n, nH, 64).permute(1, 0, 2) / 8.0
+            kh = Kref[b, :, 1].permute(1, 0, 2)
+            vh = Vref[b, :, 1].permute(1, 0, 2)
+            att = qh @ kh.transpose(-2, -1)
+            att = att.masked_fill(kmask[b][None, None, :], float('-inf')).softmax(-1)
+            ref[r0:r0 + n] = (att @ vh).permute(1, 0, 2).reshape(n, d)
+            r0 += n
+        groups, qt = Decoder.make_tiles(counts)
+        gd = torch.tensor(groups, dtype=torch.int32, device=DEV)
+        km = kmask.to(torch.uint8).to(DEV) if masked else None
+        for S in (1, 2, 8):
+            # qt == 4: the LDS-ring kernel in both geometries (1: four one-block stages, 4: eight stages in 64-key chunks) and the
+            # register-streaming kernel (0)
+            for ring in ((1, 4, 0) if qt == 4 else (1,)):
+                ops.cross_q4(ring)
+                o = torch.full((R, d), float('nan'), device=DEV)
+                partial = torch.full((R, nH, S, 68), float('nan'), device=DEV)
+                ops.dec_cross_attn_step(qq.to(DEV), Kd[1], Vd[1], nH * Mpad * 128, Mpad, km, gd, len(groups), qt, partial, o, M, nH, S)
+                out.append(rec('cross_attn_split[B%d,M%d,qt%d,S%d,mask=%s,ring=%d]' % (B, M, qt, S, masked, ring),
+                               (o.double().cpu() - ref).abs().max().item(), 5e-5))
+        ops.cross_q4(1)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # decoder: teacher-forced logits vs oracle.decode on random memories (2 images, ragged counts)
 # ---------------------------------------------------------------------------------------------

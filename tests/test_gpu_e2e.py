@@ -24,7 +24,8 @@ def test_golden_fp32(C, name):
     _assert_all(C.check_e2e(name, 'fp32'))
 
 
-@pytest.mark.parametrize('name', ['spot_odd', 'spot_224', 'kie_sroie', 'postnorm_nofpn', 'spot_1024', 'spot_640', 'kie_960x1280', 'spot_padded'])
+@pytest.mark.parametrize('name', ['spot_odd', 'spot_224', 'kie_sroie', 'postnorm_nofpn', 'spot_1024', 'spot_640', 'kie_960x1280', 'spot_padded',
+                                  'spot_1024_n40', 'spot_640_n64'])
 def test_parity_engine_bf16x3(C, name):
     """The PARITY engine (fp32 storage, large products as three bf16 products of split operands on the bf16 matrix cores,
     model/backbone.py) is held to the fp32 gates on every fixture: memory / logits within 1e-3, decoded ids identical."""
@@ -43,14 +44,16 @@ def test_golden_bf16(C, name):
 
 
 # BASELINE.json configurations at their stated shapes (fixtures written by the REAL reference, oracle/gen_golden.py
-# BIG_CASES): c2 1024x1024 (M = 4096, the bench shape), c1 640x640, c3 960x1280 --infer_vie, and a padded two-size batch
-@pytest.mark.parametrize('name', ['spot_1024', 'spot_640', 'kie_960x1280', 'spot_padded'])
+# BIG_CASES): c2 1024x1024 (M = 4096, the bench shape), c1 640x640, c3 960x1280 --infer_vie, and a padded two-size batch;
+# round 4: spot_1024_n40 / spot_640_n64 = the BENCH's decode shape end to end (40 instances over M = 4096, 64 over M = 1600: the
+# 33..64-row cross-attention kernel and the 64-row self-attention path inside a whole engine call, transformer.py:252-284)
+@pytest.mark.parametrize('name', ['spot_1024', 'spot_640', 'kie_960x1280', 'spot_padded', 'spot_1024_n40', 'spot_640_n64'])
 def test_config_shapes_fp32(C, name):
     """fp32 engine at the benchmarked shapes: memory / logits within 1e-3, decoded token ids identical."""
     _assert_all(C.check_e2e(name, 'fp32'))
 
 
-@pytest.mark.parametrize('name', ['spot_1024', 'spot_640', 'kie_960x1280', 'spot_padded'])
+@pytest.mark.parametrize('name', ['spot_1024', 'spot_640', 'kie_960x1280', 'spot_padded', 'spot_1024_n40', 'spot_640_n64'])
 def test_config_shapes_bf16(C, name):
     """the benchmarked precision at the benchmarked shapes (same gates as test_golden_bf16)."""
     _assert_all(C.check_e2e(name, 'bf16'))

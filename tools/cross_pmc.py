@@ -2,7 +2,7 @@
 images, M = 4096 memory tokens, bf16), for the rocprofv3 --pmc passes that feed roofline.traffic when profiling the
 whole bench at that size is impractical (PMC mode serialises ~16 k dispatches per pass).  Launch mix 22 : 10 =
 the bench's 3752 : 1708 (point-decoder launches with 1 row per image : polygon / recognition launches with 64).
-    python tools/cross_pmc.py [images]"""
+    python tools/cross_pmc.py [images] [split]      split: the parity engine's kernels (fp32 q / out over split-bf16 plane slabs)"""
 import os
 import sys
 
@@ -16,22 +16,29 @@ from advancedliteratemachinery_amd.model.transformer import Decoder  # noqa: E40
 
 def main():
     I = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    split = len(sys.argv) > 2 and sys.argv[2] == 'split'
     M, nH, d, KB = 4096, 8, 512, 32
     dev = 'cuda'
     g = torch.Generator(device='cpu').manual_seed(0)
-    K = torch.randn(2, I, nH, M, 64, generator=g).to(dev, torch.bfloat16)            # two layer slabs, alternated
-    Vt = torch.randn(2, I, nH, M // KB, 64, KB, generator=g).to(dev, torch.bfloat16)
+    if split:   # 32-key blocks of [hi plane | lo plane]
+        K = torch.randn(2, I, nH, M // KB, 2, KB, 64, generator=g).to(dev, torch.bfloat16)
+        Vt = torch.randn(2, I, nH, M // KB, 2, 64, KB, generator=g).to(dev, torch.bfloat16)
+    else:
+        K = torch.randn(2, I, nH, M, 64, generator=g).to(dev, torch.bfloat16)            # two layer slabs, alternated
+        Vt = torch.randn(2, I, nH, M // KB, 64, KB, generator=g).to(dev, torch.bfloat16)
+    qdt = torch.float32 if split else torch.bfloat16
+    stride = nH * M * 64 * (2 if split else 1)
 
     def run(rows_per_img, n_launch, S):
         counts = [rows_per_img] * I
         groups, qt = Decoder.make_tiles(counts)
         gd = torch.tensor(groups, dtype=torch.int32, device=dev)
         R = sum(counts)
-        q = torch.randn(R, d, device=dev).to(torch.bfloat16)
-        out = torch.empty(R, d, device=dev, dtype=torch.bfloat16)
+        q = torch.randn(R, d, device=dev).to(qdt)
+        out = torch.empty(R, d, device=dev, dtype=qdt)
         partial = torch.empty(R, nH, S, 68, device=dev)
         for i in range(n_launch):
-            ops.dec_cross_attn_step(q, K[i & 1], Vt[i & 1], nH * M * 64, M, None, gd, len(groups), qt, partial, out, M, nH, S)
+            ops.dec_cross_attn_step(q, K[i & 1], Vt[i & 1], stride, M, None, gd, len(groups), qt, partial, out, M, nH, S)
         torch.cuda.synchronize()
         print('rows/img %d: %d launches, q_tiles %d, S %d, groups %d' % (rows_per_img, n_launch, qt, S, len(groups)), flush=True)
 

@@ -100,6 +100,42 @@ def bench_cross128(dtype=torch.bfloat16):
     h.omp_debug_cross_q4(1)
 
 
+def bench_cross_split():
+    """fp32-grade cross-attention at the bench's engine-call size (KBENCH_CROSS_IMAGES images, default 160, M = 4096): the fp32 slabs
+    (16-key blocks, fp32 matrix cores) vs the split-plane slabs (32-key blocks of [hi | lo] bf16, three bf16 products), same bytes."""
+    I, M, nH, d = int(os.environ.get('KBENCH_CROSS_IMAGES', '160')), 4096, 8, 512
+    from advancedliteratemachinery_amd.model.transformer import Decoder
+    g = torch.Generator(device='cpu').manual_seed(0)
+    h = _lib.lib()
+    slabs = {
+        'f32': (torch.randn(2, I, nH, M, 64, generator=g).to(DEV), torch.randn(2, I, nH, M // 16, 64, 16, generator=g).to(DEV), nH * M * 64),
+        'split': (torch.randn(2, I, nH, M // 32, 2, 32, 64, generator=g).to(DEV, torch.bfloat16),
+                  torch.randn(2, I, nH, M // 32, 2, 64, 32, generator=g).to(DEV, torch.bfloat16), nH * M * 128),
+    }
+    for rows_per_img, splits in ((1, (1, 2)), (64, (1, 2))):
+        counts = [rows_per_img] * I
+        groups, qt = Decoder.make_tiles(counts)
+        gd = torch.tensor(groups, dtype=torch.int32, device=DEV)
+        R = sum(counts)
+        q = torch.randn(R, d, device=DEV)
+        out = torch.empty(R, d, device=DEV)
+        alg = I * 2 * M * d * 4 + 2 * R * d * 4
+        for name, (K, Vt, stride) in slabs.items():
+            for S in splits:
+                partial = torch.empty(R, nH, S, 68, device=DEV)
+                for ring in ((1, 4) if (rows_per_img == 64 and name == 'split') else (1,)):
+                    h.omp_debug_cross_q4(ring)
+                    st = [0]
+
+                    def fn():
+                        st[0] += 1
+                        ops.dec_cross_attn_step(q, K[st[0] & 1], Vt[st[0] & 1], stride, M, None, gd, len(groups), qt, partial, out, M, nH, S)
+                    us = timeit(fn, iters=30, warm=4)
+                    print('cross_fp32grade[%-5s] images=%d rows/img=%-2d S=%d ring=%d : %7.1f us  %6.0f GB/s (%.2f of 8 TB/s)'
+                          % (name, I, rows_per_img, S, ring, us, alg / us / 1e3, alg / us / 1e3 / 8000), flush=True)
+    h.omp_debug_cross_q4(1)
+
+
 def bench_gemm(dtype=torch.bfloat16):
     # (M, N, K, act, residual) of the Swin-B stages at B=8 1024x1024 and the K/V projection
     shapes = [(524288, 384, 128, 0, 0), (524288, 128, 128, 0, 1), (524288, 512, 128, 1, 0), (524288, 128, 512, 0, 1),
@@ -258,6 +294,38 @@ def bench_dec_gemm(dtype=torch.bfloat16):
                   % (str(dtype)[6:], which, R, N, K, ln, us, N * K * 2 / 1e6, N * K * 2 / us / 1e3, 2.0 * R * N * K / us / 1e6), flush=True)
 
 
+def bench_dec_gemm_rows():
+    """the many-row decoder phases (polygon / recognition: 64 rows per image): every Linear of a step at R = KBENCH_DEC_ROWS rows, bf16 and
+    bf16x3 (K' = 3 K, split-pair A), per kernel selector -- the dispatch table of launch_gemm for these shapes is read off this."""
+    R = int(os.environ.get('KBENCH_DEC_ROWS', '10240'))
+    bf = torch.bfloat16
+    variants = [int(v) for v in os.environ.get('KBENCH_GEMM_VARIANTS', '0,5,6,9').split(',')]
+    for x3 in (0, 1):
+        for (N, K, res, name) in ((1536, 512, 0, 'sa_in'), (512, 512, 1, 'sa_out'), (512, 512, 0, 'ca_q'), (2048, 512, 0, 'ff1'), (512, 2048, 1, 'ff2'), (1104, 512, 0, 'head')):
+            w = torch.randn(N, K, device=DEV) / K ** 0.5
+            bias = torch.randn(N, device=DEV)
+            a = torch.randn(R, K, device=DEV)
+            if x3:
+                W, A, kw = ops.split_weight3(w), ops.split_bf16(a), dict(a_wrap=2 * K)
+            else:
+                W, A, kw = w.to(bf), a.to(bf), {}
+            f32o = res or name in ('ca_q', 'head') or x3 and name == 'sa_in'
+            sp = x3 and name == 'ff1'
+            out = (torch.empty(R, 2 * N, device=DEV, dtype=bf) if sp else torch.zeros(R, N, device=DEV, dtype=torch.float32 if f32o else bf))
+            r = out if res else None
+            fl = 2.0 * R * N * K * (3 if x3 else 1)
+            for which in variants:
+                ops.force_gemm_kernel(which)
+                try:
+                    us = timeit(lambda: ops.gemm(A, W, bias, residual=r, out=out, out_dtype=(ops.SPLIT if sp else out.dtype), **kw), iters=30, warm=3)
+                except Exception as e:   # a selector that does not take this shape
+                    print('dec_rows[%s,k%d] %s : %s' % ('x3' if x3 else 'bf16', which, name, str(e)[:90]), flush=True)
+                    continue
+                print('dec_rows[%s,k%d] R=%d %-6s N=%-4d K=%-4d out=%s : %7.1f us  %6.1f TF/s'
+                      % ('x3' if x3 else 'bf16', which, R, name, N, K * (3 if x3 else 1), 'split' if sp else str(out.dtype)[6:], us, fl / us / 1e6), flush=True)
+            ops.force_gemm_kernel(0)
+
+
 def bench_selfattn(dtype=torch.bfloat16):
     ops.force_gemm_kernel(0)
     d, nH = 512, 8
@@ -307,6 +375,10 @@ if __name__ == '__main__':
         bench_cross()
     if 'dec_gemm' in what or 'all' in what:
         bench_dec_gemm()
+    if 'cross_split' in what:
+        bench_cross_split()
+    if 'dec_rows' in what:
+        bench_dec_gemm_rows()
     if 'selfattn' in what or 'all' in what:
         bench_selfattn()
     if 'gemm' in what or 'all' in what:

@@ -29,8 +29,9 @@ def main():
             out = {str(old['images_per_launch']): old} if 'images_per_launch' in old else dict(old)
         except (OSError, ValueError):
             out = {}
-    out[str(int(sys.argv[3]))] = dict(kernel='dec_cross_attn*', fetch_kib_mean=fm, write_kib_mean=wm, launches_fetch=fn, launches_write=wn,
-                                      images_per_launch=int(sys.argv[3]), command=sys.argv[4] if len(sys.argv) > 4 else '',
+    key = sys.argv[3]   # images per launch; 'x3_<images>' = the split-plane kernels of the parity engine
+    out[key] = dict(kernel='dec_cross_attn*', fetch_kib_mean=fm, write_kib_mean=wm, launches_fetch=fn, launches_write=wn,
+                                      images_per_launch=int(key.split('_')[-1]), command=sys.argv[4] if len(sys.argv) > 4 else '',
                                       units='KiB as reported by rocprofv3; bench.py applies the gfx950 x2 correction to FETCH_SIZE')
     print(json.dumps(out, indent=1))
 
