@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libomp355.so')
 SOURCES = ['api.hip', 'gemm.hip', 'mlp.hip', 'norm.hip', 'swin_attn.hip', 'swin_block.hip', 'fpn.hip', 'decoder.hip', 'vit.hip', 'preprocess.hip']
-HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'omp355_debug.h'), os.path.join(CSRC, 'gemm256.inc'), os.path.join(os.path.dirname(HERE), 'include', 'omp355.h')]
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'omp355_debug.h'), os.path.join(CSRC, 'gemm256.inc'), os.path.join(CSRC, 'gemm4w.inc'), os.path.join(os.path.dirname(HERE), 'include', 'omp355.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 
@@ -43,7 +43,8 @@ def build(force=False, verbose=True):
         o = os.path.join(OBJ, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            jobs.append([hipcc] + FLAGS + ['-c', s, '-o', o])
+            # gemm.hip keeps its device assembly next to the object: the audit below reads it
+            jobs.append([hipcc] + FLAGS + (['-save-temps=obj'] if src == 'gemm.hip' else []) + ['-c', s, '-o', o])
 
     def run(cmd):
         if verbose:
@@ -58,7 +59,24 @@ def build(force=False, verbose=True):
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    _audit_gemm4w()
     return LIB
+
+
+def _audit_gemm4w():
+    """gemm_4w names all 256 accumulator registers in asm: refuse a build in which the compiler spilled or used the accumulator file
+    itself (tools/audit_gemm4w.py; silent corruption otherwise)."""
+    asm = os.path.join(OBJ, 'gemm-hip-amdgcn-amd-amdhsa-gfx950.s')
+    if not os.path.exists(asm):
+        return   # objects from an older build tree: the next rebuild of gemm.hip writes it
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tools'))
+    try:
+        import audit_gemm4w
+        n, bad = audit_gemm4w.audit(asm)
+    finally:
+        sys.path.pop(0)
+    if bad or n == 0:
+        raise RuntimeError('gemm_4w register audit failed (%d kernels):\n%s' % (n, '\n'.join(bad) or 'no gemm_4w kernel found in ' + asm))
 
 
 if __name__ == '__main__':

@@ -511,6 +511,7 @@ int launch_dma(GemmP& p, hipStream_t st) {
 }
 
 #include "gemm256.inc"
+#include "gemm4w.inc"
 
 template <typename T, typename TOut>
 __global__ __launch_bounds__(256) void gemm_rows(GemmP p) {
@@ -773,7 +774,7 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
       if (which == 5 && p.N >= 256 && fills && gemm256_ok(p, true, std::is_same<TOut, bf16_t>::value)) which = 9;
     }
   }
-  if (p.C2 != nullptr && which != 5 && which != 6 && which != 9 && which != 15) {
+  if (p.C2 != nullptr && which != 5 && which != 6 && which != 9 && which != 10 && which != 11 && which != 15) {
     omp_set_error("omp_gemm_bias_act: kernel selector %d has no second destination (C2)", which);
     return OMP_ERR_UNSUPPORTED;
   }
@@ -802,6 +803,30 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
       if (rc != OMP_OK) return rc;
     } else {
       omp_set_error("omp_gemm_bias_act: selector 9 (256x256 tiles) is bf16-only");
+      return OMP_ERR_UNSUPPORTED;
+    }
+  } else if (which == 10 || which == 11) {   // 256x256 tiles on four waves (gemm4w.inc), ring of 4 / 5 stages
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (!gemm4w_ok(p, true, std::is_same<TOut, bf16_t>::value)) {
+        omp_set_error("omp_gemm_bias_act: selector %d (256x256 tiles on four waves) takes the shapes of selector 9", which);
+        return OMP_ERR_UNSUPPORTED;
+      }
+      const int slot = omp_prof_active(OMP_PROF_GEMM) ? omp_prof_begin(OMP_PROF_GEMM, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
+      int rc = which == 10 ? launch_4w<TOut, 4>(p, st) : launch_4w<TOut, 5>(p, st);
+      if (slot >= 0) omp_prof_end(OMP_PROF_GEMM, slot, st);
+      if (rc != OMP_OK) return rc;
+    } else {
+      omp_set_error("omp_gemm_bias_act: selector %d (256x256 tiles on four waves) is bf16-only", which);
+      return OMP_ERR_UNSUPPORTED;
+    }
+  } else if (which >= 12 && which <= 14) {   // development: gemm_4w ablations (wrong results, valid timing), plain bf16 destination only
+    if constexpr (std::is_same<T, bf16_t>::value && std::is_same<TOut, bf16_t>::value) {
+      if (!gemm4w_ok(p, true, true) || p.store_mode != OMP_STORE_PLAIN || p.split_out) { omp_set_error("omp_gemm_bias_act: selectors 12..14 take plain bf16 products"); return OMP_ERR_UNSUPPORTED; }
+      int rc = which == 12 ? launch_4w_sm<TOut, OMP_STORE_PLAIN, false, 4, 1>(p, st) : which == 13 ? launch_4w_sm<TOut, OMP_STORE_PLAIN, false, 4, 2>(p, st)
+                                                                                                     : launch_4w_sm<TOut, OMP_STORE_PLAIN, false, 4, 3>(p, st);
+      if (rc != OMP_OK) return rc;
+    } else {
+      omp_set_error("omp_gemm_bias_act: selectors 12..14 take plain bf16 products");
       return OMP_ERR_UNSUPPORTED;
     }
   } else if (which == 15) {          // development: gemm_dma<128,128,2> with per-workgroup phase timestamps

@@ -1172,6 +1172,104 @@ def check_gemm_x3():
     return out
 
 
+def check_gemm_4w():
+    """gemm_4w (256x256 tiles on four waves, accumulators addressed literally in the accumulator file; csrc/gemm4w.inc), ring of 4
+    and of 5 stages, against gemm_dma (k5) on the SAME operands: the kernels share the MFMA, the operand orientation and the
+    ascending-k accumulation order, so every output must be equal BIT FOR BIT -- ragged M / N edges, K from 64 (fewer stages than
+    the ring holds) to 6144, odd stage counts, bias / GELU / ReLU / bf16 and fp32 residual, second destination, per-position bias
+    table, split-pair rows, bf16x3 operands (a_wrap), and the blocked K / V^T slabs (bf16 and split planes).  Plus one fp64
+    reference per dtype so that 'equal' cannot mean 'equally wrong'."""
+    from advancedliteratemachinery_amd import _lib
+    out = []
+    bf = torch.bfloat16
+
+    def run(which, fn):
+        ops.force_gemm_kernel(which)
+        try:
+            return fn()
+        finally:
+            ops.force_gemm_kernel(0)
+
+    def same(tag, fn, ref_check=None):
+        base = run(5, fn)
+        for which in (10, 11):
+            got = run(which, fn)
+            for i, (g, b) in enumerate(zip(got, base)):
+                neq = (g.view(torch.int16 if g.dtype == bf else torch.int32) != b.view(torch.int16 if b.dtype == bf else torch.int32)).sum().item()
+                out.append(rec('gemm_4w[k%d == k5, %s, out%d]' % (which, tag, i), float(neq), 0.0, 'elements that differ, of %d' % g.numel()))
+        if ref_check is not None:
+            ref_check(base)
+
+    for (M, N, K) in ((300, 384, 128), (1000, 512, 2048), (513, 1128, 512), (2049, 256, 1024), (777, 1536, 64), (4100, 520, 2048), (256, 256, 96 * 2),
+                      (70000, 768, 256), (9000, 512, 6144)):
+        A, W = rnd(M, K, seed=M).to(DEV, bf), (rnd(N, K, seed=N + 1) / math.sqrt(K)).to(DEV, bf)
+        bias = rnd(N, seed=3).to(DEV)
+        rb, rf = rnd(M, N, seed=4).to(DEV, bf), rnd(M, N, seed=5).to(DEV)
+        tag = '%dx%dx%d' % (M, N, K)
+
+        def chk(base, A=A, W=W, bias=bias, tag=tag):
+            ref = A.double().cpu() @ W.double().cpu().t() + bias.double().cpu()
+            out.append(rec('gemm_4w[k5 vs fp64, %s]' % tag, (base[0].double().cpu() - ref).abs().max().item(), max(2e-4, ref.abs().max().item() * 2.0 ** -8)))
+        same(tag + ' bias', lambda: (ops.gemm(A, W, bias),), chk if K <= 2048 and M <= 5000 else None)
+        same(tag + ' gelu', lambda: (ops.gemm(A, W, bias, act=ops.ACT_GELU),))
+        same(tag + ' relu + bf16 residual', lambda: (ops.gemm(A, W, bias, residual=rb, act=ops.ACT_RELU),))
+        same(tag + ' f32 out + f32 residual', lambda: (ops.gemm(A, W, bias, residual=rf, out_dtype=torch.float32),))
+        if N % 8 == 0:
+            same(tag + ' gelu, split rows', lambda: (ops.gemm(A, W, bias, act=ops.ACT_GELU, out_dtype=ops.SPLIT),))
+
+            def two():
+                c2 = torch.empty(M, N, device=DEV, dtype=bf)
+                y = ops.gemm(A, W, bias, residual=rb, out_noresidual=c2)
+                return y, c2
+            same(tag + ' two destinations', two)
+    # bf16x3 operands: split-pair A wrapped over [hi | lo | hi]
+    for (M, N, K) in ((3000, 512, 512), (1100, 1536, 512), (2049, 256, 1024)):
+        As, W3 = ops.split_bf16(rnd(M, K, seed=M).to(DEV)), ops.split_weight3((rnd(N, K, seed=N + 1) / math.sqrt(K)).to(DEV))
+        bias, rf = rnd(N, seed=3).to(DEV), rnd(M, N, seed=5).to(DEV)
+        same('x3 %dx%dx%d f32 + residual' % (M, N, 3 * K), lambda: (ops.gemm(As, W3, bias, residual=rf, out_dtype=torch.float32, a_wrap=2 * K),))
+        same('x3 %dx%dx%d gelu split' % (M, N, 3 * K), lambda: (ops.gemm(As, W3, bias, act=ops.ACT_GELU, out_dtype=ops.SPLIT, a_wrap=2 * K),))
+    # per-position bias table
+    Ab, Wb = rnd(1500, 512, seed=21).to(DEV, bf), (rnd(1536, 512, seed=22) / math.sqrt(512)).to(DEV, bf)
+    tabb, rowb = rnd(9, 1536, seed=23).to(DEV), torch.tensor([6], dtype=torch.int32, device=DEV)
+    same('bias_row', lambda: (ops.gemm(Ab, Wb, tabb, bias_row=rowb, bias_row_stride=1536),))
+    # blocked K / V^T slabs, bf16 and split planes
+    nH, d, K = 8, 512, 512
+    for (Bn, tok) in ((2, 72), (3, 257), (5, 1000)):
+        Mpad = (tok + 31) // 32 * 32
+        memf = rnd(Bn * tok, K, seed=tok).to(DEV)
+        Wf = (rnd(2 * d, K, seed=tok + 1) / math.sqrt(K)).to(DEV)
+        bk = rnd(2 * d, seed=tok + 2).to(DEV)
+        geom = (Bn, tok, Mpad, nH, 32)
+        mem, Wk = memf.to(bf), Wf.to(bf)
+
+        def kslab():
+            Kd = torch.zeros(2, Bn, nH, Mpad, 64, dtype=bf, device=DEV)
+            ops.gemm(mem, Wk, bk, out=Kd, store_mode=_lib.STORE_KBLK, kv=geom)
+            return (Kd,)
+
+        def ksplit():
+            Kd = torch.zeros(2, Bn, nH, Mpad // 32, 2, 32, 64, dtype=bf, device=DEV)
+            ops.gemm(ops.split_bf16(memf), ops.split_weight3(Wf), bk, out=Kd, out_dtype=ops.SPLIT, store_mode=_lib.STORE_KBLK, kv=geom, a_wrap=2 * K,
+                     M=Bn * tok, N=2 * d, K=3 * K)
+            return (Kd,)
+        same('K slab B%d tok%d' % (Bn, tok), kslab)
+        same('K split planes B%d tok%d' % (Bn, tok), ksplit)
+        if tok % 8 == 0:
+            def vslab():
+                Vd = torch.zeros(2, Bn, nH, Mpad // 32, 64, 32, dtype=bf, device=DEV)
+                ops.gemm(Wk, mem, bk, out=Vd, store_mode=_lib.STORE_VBLK, kv=geom, bias_along_m=True, M=2 * d, N=Bn * tok, K=K)
+                return (Vd,)
+
+            def vsplit():
+                Vd = torch.zeros(2, Bn, nH, Mpad // 32, 2, 64, 32, dtype=bf, device=DEV)
+                ops.gemm(ops.split_weight2(Wf), ops.split_bf16(memf, triple=True), bk, out=Vd, out_dtype=ops.SPLIT, store_mode=_lib.STORE_VBLK, kv=geom,
+                         bias_along_m=True, a_wrap=2 * K, M=2 * d, N=Bn * tok, K=3 * K)
+                return (Vd,)
+            same('V^T slab B%d tok%d' % (Bn, tok), vslab)
+            same('V^T split planes B%d tok%d' % (Bn, tok), vsplit)
+    return out
+
+
 def check_window_attn_split():
     """fp32 window attention writing split pairs == its own fp32 output split (the proj GEMM's bf16x3 operand)."""
     out = []

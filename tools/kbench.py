@@ -146,20 +146,34 @@ def bench_gemm(dtype=torch.bfloat16):
     ms = int(os.environ.get('KBENCH_GEMM_MSCALE', '1'))   # 4 = the encoder's 32-image chunks
     f32res = os.environ.get('KBENCH_GEMM_F32RES', '1') == '1'   # the engines keep the residual stream in fp32
     lib = os.environ.get('KBENCH_GEMM_LIB', '0') == '1'         # calibration: torch's library GEMM (hipBLASLt) on the same product
+    x3 = os.environ.get('KBENCH_GEMM_X3', '0') == '1'           # the parity engine's products: split-pair A, [hi | hi | lo] weight image, K' = 3 K
+    only = os.environ.get('KBENCH_GEMM_ONLY')                   # e.g. "8,9,10,11": indices into the shape list
+    if only:
+        shapes = [shapes[int(i)] for i in only.split(',')]
     for (M, N, K, act, res) in shapes:
         M = M * ms
-        A = torch.randn(M, K, device=DEV).to(dtype)
-        W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(dtype)
+        if x3:
+            A = ops.split_bf16(torch.randn(M, K, device=DEV))
+            W = ops.split_weight3(torch.randn(N, K, device=DEV) / K ** 0.5)
+        else:
+            A = torch.randn(M, K, device=DEV).to(dtype)
+            W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(dtype)
         bias = torch.randn(N, device=DEV)
-        odt = torch.float32 if (res and f32res) else dtype
-        out = torch.empty(M, N, device=DEV, dtype=odt)
+        odt = torch.float32 if ((res and f32res) or (x3 and not act)) else dtype
+        split = x3 and act
+        out = torch.empty(M, 2 * N if split else N, device=DEV, dtype=odt)
         r = torch.randn(M, N, device=DEV).to(odt) if res else None
-        fl = 2.0 * M * N * K
-        by = (M * K + N * K) * 2 + M * N * (2 if res else 1) * out.element_size()
+        kw = dict(a_wrap=2 * K, out_dtype=(ops.SPLIT if split else odt)) if x3 else {}
+        fl = 2.0 * M * N * K * (3 if x3 else 1)
+        by = (M * K + N * K) * 2 * (2 if x3 else 1) + M * N * (2 if res else 1) * out.element_size() * (2 if split else 1)
         for which in GEMM_VARIANTS:
             ops.force_gemm_kernel(which)
-            us = timeit(lambda: ops.gemm(A, W, bias, residual=r, act=act, out=out), iters=20, warm=3)
-            print('gemm[%s,k%d] %7dx%5dx%5d act=%d res=%d out=%s : %8.1f us  %6.1f TF/s  %6.0f GB/s' % (str(dtype)[6:], which, M, N, K, act, res, str(odt)[6:], us, fl / us / 1e6, by / us / 1e3),
+            try:
+                us = timeit(lambda: ops.gemm(A, W, bias, residual=r, act=act, out=out, **kw), iters=20, warm=3)
+            except Exception as e:   # a selector that does not take this shape
+                print('gemm[k%d] %dx%dx%d : %s' % (which, M, N, K, str(e)[:100]), flush=True)
+                continue
+            print('gemm[%s,k%d] %7dx%5dx%5d act=%d res=%d out=%s : %8.1f us  %6.1f TF/s  %6.0f GB/s' % ('x3' if x3 else str(dtype)[6:], which, M, N, K * (3 if x3 else 1), act, res, 'split' if split else str(odt)[6:], us, fl / us / 1e6, by / us / 1e3),
                   flush=True)
         ops.force_gemm_kernel(0)
         if lib:
