@@ -772,6 +772,10 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
       const int64_t t256 = ceil_div64(p.M, 256) * ceil_div64(p.N, 256);
       const bool fills = t256 >= 192 && 4 * t256 >= 3 * 256 * ceil_div64(t256, 256);
       if (which == 5 && p.N >= 256 && fills && gemm256_ok(p, true, std::is_same<TOut, bf16_t>::value)) which = 9;
+      // the four-wave kernel (gemm4w.inc) produces the same bits; measured against gemm_256 per shape (profiles/r04f_kbench_gemm_4w_v2_*):
+      // equal within the box-to-box spread on most, 7-13 % faster on the half-million-row products of stage 1 without an activation,
+      // 7-13 % slower behind a GELU epilogue (four waves instead of eight do the vector work) -- it takes the former
+      if (which == 9 && p.act == OMP_ACT_NONE && p.store_mode == OMP_STORE_PLAIN && p.M >= 262144 && (p.K >= 1024 || p.N >= 768)) which = 10;
     }
   }
   if (p.C2 != nullptr && which != 5 && which != 6 && which != 9 && which != 10 && which != 11 && which != 15) {
@@ -805,14 +809,14 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
       omp_set_error("omp_gemm_bias_act: selector 9 (256x256 tiles) is bf16-only");
       return OMP_ERR_UNSUPPORTED;
     }
-  } else if (which == 10 || which == 11) {   // 256x256 tiles on four waves (gemm4w.inc), ring of 4 / 5 stages
+  } else if (which == 10 || which == 11) {   // 256x256 tiles on four waves (gemm4w.inc); 11 is kept as an alias of 10
     if constexpr (std::is_same<T, bf16_t>::value) {
       if (!gemm4w_ok(p, true, std::is_same<TOut, bf16_t>::value)) {
         omp_set_error("omp_gemm_bias_act: selector %d (256x256 tiles on four waves) takes the shapes of selector 9", which);
         return OMP_ERR_UNSUPPORTED;
       }
       const int slot = omp_prof_active(OMP_PROF_GEMM) ? omp_prof_begin(OMP_PROF_GEMM, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
-      int rc = which == 10 ? launch_4w<TOut, 4>(p, st) : launch_4w<TOut, 5>(p, st);
+      int rc = launch_4w<TOut, 5>(p, st);
       if (slot >= 0) omp_prof_end(OMP_PROF_GEMM, slot, st);
       if (rc != OMP_OK) return rc;
     } else {
@@ -822,8 +826,8 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
   } else if (which >= 12 && which <= 14) {   // development: gemm_4w ablations (wrong results, valid timing), plain bf16 destination only
     if constexpr (std::is_same<T, bf16_t>::value && std::is_same<TOut, bf16_t>::value) {
       if (!gemm4w_ok(p, true, true) || p.store_mode != OMP_STORE_PLAIN || p.split_out) { omp_set_error("omp_gemm_bias_act: selectors 12..14 take plain bf16 products"); return OMP_ERR_UNSUPPORTED; }
-      int rc = which == 12 ? launch_4w_sm<TOut, OMP_STORE_PLAIN, false, 4, 1>(p, st) : which == 13 ? launch_4w_sm<TOut, OMP_STORE_PLAIN, false, 4, 2>(p, st)
-                                                                                                     : launch_4w_sm<TOut, OMP_STORE_PLAIN, false, 4, 3>(p, st);
+      int rc = which == 12 ? launch_4w_sm<TOut, OMP_STORE_PLAIN, false, 5, 1>(p, st) : which == 13 ? launch_4w_sm<TOut, OMP_STORE_PLAIN, false, 5, 2>(p, st)
+                                                                                                     : launch_4w_sm<TOut, OMP_STORE_PLAIN, false, 5, 3>(p, st);
       if (rc != OMP_OK) return rc;
     } else {
       omp_set_error("omp_gemm_bias_act: selectors 12..14 take plain bf16 products");
