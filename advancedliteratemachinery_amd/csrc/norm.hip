@@ -320,6 +320,89 @@ __global__ __launch_bounds__(256) void patch_embed_tok_kernel(const float* __res
   }
 }
 
+
+// PatchEmbed on the fp32 matrix cores (round 4; E = 16 NB <= 128, fp32 residual stream out).  The thread-per-token kernel above spends
+// 6144 scalar-operand FMAs per token and writes every token's 512-byte row from ONE lane, 16 bytes at a time (64 different rows per
+// store instruction): 1.49-1.6 ms per 32-image chunk = 0.12 of the HBM roofline (profiles/r03m_*).  Here a wave owns 16 consecutive
+// tokens: D[channel][token] = W[channel][k] x[token][k] over k = 48 patch values + 1 (the bias rides along as k = 48 against a
+// constant 1), 13 steps of v_mfma_f32_16x16x4_f32 per 16-channel block; the weights (13 registers per block) stay in registers
+// across the persistent wave's tiles; a step's B operand is ONE coalesced dword load (lane (token, kx) reads pixel kx of the
+// token's patch row: 64 consecutive floats of an image row per instruction); the LayerNorm statistics are in-register sums + two
+// register swaps across the four lane groups; the normalised tile goes through a wave-private LDS transpose so that every store
+// instruction writes 1 KB of consecutive output (two whole token rows).
+template <int NB>
+__global__ __launch_bounds__(256) void patch_embed_mfma_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, const float* __restrict__ g,
+                                                               const float* __restrict__ be, float* __restrict__ out, int B, int H, int W,
+                                                               int Hp, int Wp, float eps, int ntiles) {
+  constexpr int E = 16 * NB, PITCH = E + 4;
+  extern __shared__ __attribute__((aligned(16))) float pe_lds[];   // [4 waves][16 tokens][PITCH]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+  float* T = pe_lds + wave * 16 * PITCH;
+  // A operand: channel cb * 16 + li, k = 4 s + kq (s = 12: the bias against x = 1 in lane group 0)
+  float wr[NB][13];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb) {
+    const float* wc = w + (cb * 16 + li) * 48 + kq;
+#pragma unroll
+    for (int s_ = 0; s_ < 12; ++s_) wr[cb][s_] = wc[4 * s_];
+    wr[cb][12] = kq == 0 ? bias[cb * 16 + li] : 0.f;
+  }
+  const int64_t ntok = (int64_t)B * Hp * Wp;
+  const float one = kq == 0 ? 1.f : 0.f;
+  const int nwaves = gridDim.x * 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += nwaves) {
+    unsigned tok = (unsigned)tile * 16u + (unsigned)li;   // the host sends token counts >= 2^31 to the scalar kernel
+    if (tok > (unsigned)(ntok - 1)) tok = (unsigned)(ntok - 1);
+    const unsigned trow = tok / (unsigned)Wp;
+    const int tx = (int)(tok - trow * (unsigned)Wp), b = (int)(trow / (unsigned)Hp), ty = (int)(trow - (unsigned)b * (unsigned)Hp);
+    const int px = tx * 4 + kq;
+    float x[12];
+#pragma unroll
+    for (int s_ = 0; s_ < 12; ++s_) {
+      const int ch = s_ >> 2, py = ty * 4 + (s_ & 3);
+      const bool in = py < H && px < W;
+      x[s_] = in ? img[(((int64_t)b * 3 + ch) * H + py) * W + px] : 0.f;
+    }
+    f32x4 acc[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s_ = 0; s_ < 12; ++s_) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cb][s_], x[s_], acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[cb][12], one, acc[cb], 0, 0, 0);
+    }
+    // LayerNorm statistics of token li: this lane holds channels cb * 16 + 4 kq + r
+    float sm = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) sm += (acc[cb][0] + acc[cb][1]) + (acc[cb][2] + acc[cb][3]);
+    const float mean = quad_group_sum(sm) * (1.0f / (float)E);
+    float q = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = acc[cb][r] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(quad_group_sum(q) * (1.0f / (float)E) + eps);
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      f32x4 n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) n[r] = (acc[cb][r] - mean) * rstd;
+      *reinterpret_cast<f32x4*>(T + li * PITCH + cb * 16 + kq * 4) = n;
+    }
+    // wave-private tile: LDS operations of one wave complete in order.  Read back row-contiguous, affine, 16-byte stores
+    constexpr int CPR = E / 4;   // 16-byte chunks per token row
+#pragma unroll
+    for (int it = 0; it < 16 * CPR / 64; ++it) {
+      const int idx = it * 64 + lane, t = idx / CPR, c4 = (idx - t * CPR) * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(T + t * PITCH + c4);
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c4), bb = *reinterpret_cast<const f32x4*>(be + c4);
+      const int64_t to = (int64_t)tile * 16 + t;
+      if (to < ntok) *reinterpret_cast<f32x4*>(out + to * E + c4) = f32x4{v[0] * gg[0] + bb[0], v[1] * gg[1] + bb[1], v[2] * gg[2] + bb[2], v[3] * gg[3] + bb[3]};
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int omp_split_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, int triple, omp_stream_t s) {
@@ -371,6 +454,22 @@ extern "C" int omp_patch_embed_ln(const float* img, const float* w, const float*
   OMP_CHECK_ARG(img && w && b && gamma && beta && out, "omp_patch_embed_ln: null pointer");
   OMP_CHECK_ARG(B > 0 && H > 0 && W > 0 && E > 0 && E <= 1024, "omp_patch_embed_ln: bad shape");
   const int Hp = (H + 3) / 4, Wp = (W + 3) / 4;
+  if ((E == 128 || E == 96) && out_dtype == OMP_F32 && (int64_t)B * Hp * Wp < (1ll << 31) - 16 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0 &&
+      getenv("OMP355_PATCH_EMBED_SCALAR") == nullptr) {
+    // fp32 matrix cores, 16 tokens per wave, persistent waves (csrc/norm.hip: patch_embed_mfma_kernel)
+    const int64_t ntok = (int64_t)B * Hp * Wp;
+    const int ntiles = (int)ceil_div64(ntok, 16);
+    int nwg = (int)ceil_div64(ntiles, 4);
+    if (nwg > 512) nwg = 512;   // two resident workgroups per CU (172 registers): the waves are persistent, the weights are read once each
+    if (E == 128)
+      hipLaunchKernelGGL((patch_embed_mfma_kernel<8>), dim3(nwg), dim3(256), 4 * 16 * 132 * sizeof(float), (hipStream_t)s, img, w, b, gamma, beta, (float*)out, B,
+                         H, W, Hp, Wp, eps, ntiles);
+    else
+      hipLaunchKernelGGL((patch_embed_mfma_kernel<6>), dim3(nwg), dim3(256), 4 * 16 * 100 * sizeof(float), (hipStream_t)s, img, w, b, gamma, beta, (float*)out, B,
+                         H, W, Hp, Wp, eps, ntiles);
+    OMP_CHECK_LAUNCH("omp_patch_embed_ln");
+    return OMP_OK;
+  }
   if (E <= 128 && E % 8 == 0 && (out_dtype == OMP_F32 || out_dtype == OMP_BF16)) {   // thread-per-token kernel
     const int64_t ntok = (int64_t)B * Hp * Wp;
     const dim3 tgrid((unsigned)ceil_div64(ntok, 256));

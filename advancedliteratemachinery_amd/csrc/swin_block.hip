@@ -24,6 +24,8 @@
 //     the residual / proj-weight loads are never drained at a barrier
 // Measured (profiles/r03o_kbench_swin_block.txt): 32 images of 256 x 256 tokens, 2.26 ms for the four launches -> 1.11 ms;
 // instruction-issue-bound (about 2 900 instructions per wave and window), HBM floor 0.36 ms.
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -755,6 +757,34 @@ __global__ __launch_bounds__(512, 1) void swin_block256_kernel(SwinBlock256P p) 
 
 }  // namespace
 
+// Per-device launch state, safe under concurrent pipeline lanes: the CU count of the CURRENT device and "dynamic LDS
+// limit raised" flags, in atomics indexed by device ordinal.  A lost race only repeats an idempotent query / attribute call.
+namespace {
+constexpr int MAX_DEVS = 64;
+inline int current_device_cus(int* dev_out) {
+  static std::atomic<int> cus[MAX_DEVS];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVS) return -1;
+  *dev_out = dev;
+  int v = cus[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+template <typename K>
+inline bool raise_lds_limit_once(std::atomic<bool>* done, int dev, K kern_a, K kern_b) {
+  if (done[dev].load(std::memory_order_acquire)) return true;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_a), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern_b), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return false;
+  done[dev].store(true, std::memory_order_release);
+  return true;
+}
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+}  // namespace
+
 // x (fp32 [B*H*W, 128]) -> out = x + proj(W-MSA / SW-MSA(LayerNorm(x))) for Swin-B stage-0 geometry (C = 128, 4 heads, window 7);
 // out may be x.  Replaces LayerNorm + qkv GEMM + window attention + proj GEMM of the bf16 engine (swin_transformer.py:196-253).
 extern "C" int omp_swin_attn_block(const void* x, void* out, const float* ln_g, const float* ln_b, float eps, const void* qkv_w,
@@ -773,22 +803,14 @@ extern "C" int omp_swin_attn_block(const void* x, void* out, const float* ln_g, 
   const int64_t nw = (int64_t)B * p.nWy * p.nWx;
   OMP_CHECK_ARG(nw < (int64_t)1 << 30, "omp_swin_attn_block: too many windows");
   p.n_win = (int)nw;
-  static int n_cu = 0;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(swin_block_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(swin_block_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      omp_set_error("omp_swin_attn_block: cannot raise dynamic LDS limit");
-      return OMP_ERR_LAUNCH;
-    }
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      omp_set_error("omp_swin_attn_block: cannot query the device");
-      return OMP_ERR_LAUNCH;
-    }
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    attr_done = true;
+  OMP_CHECK_ARG(aligned16(x) && aligned16(out) && aligned16(qkv_w) && aligned16(proj_w) && aligned16(bias_expanded),
+                "omp_swin_attn_block: x / out / qkv_w / proj_w / bias_expanded must be 16-byte aligned (the kernel moves 16-byte vectors)");
+  int dev = 0;
+  const int n_cu = current_device_cus(&dev);
+  static std::atomic<bool> lds_done[MAX_DEVS];
+  if (n_cu <= 0 || !raise_lds_limit_once(lds_done, dev, swin_block_kernel<false>, swin_block_kernel<true>)) {
+    omp_set_error("omp_swin_attn_block: cannot query the device / raise the dynamic LDS limit");
+    return OMP_ERR_LAUNCH;
   }
   const int pairs = (int)((nw + 1) / 2);
   const int grid = pairs < n_cu ? pairs : n_cu;
@@ -816,17 +838,13 @@ extern "C" int omp_swin_attn_block_packed(const void* x, void* out, const float*
   const int64_t nw = (int64_t)B * p.nWy * p.nWx;
   OMP_CHECK_ARG(nw < (int64_t)1 << 30, "omp_swin_attn_block_packed: too many windows");
   p.n_win = (int)nw;
-  static int n_cu = 0;
-  static bool attr_done = false;
-  if (!attr_done) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      omp_set_error("omp_swin_attn_block_packed: cannot query the device");
-      return OMP_ERR_LAUNCH;
-    }
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    attr_done = true;
+  OMP_CHECK_ARG(aligned16(x) && aligned16(out) && aligned16(wpack) && aligned16(bias_expanded),
+                "omp_swin_attn_block_packed: x / out / wpack / bias_expanded must be 16-byte aligned (the kernel moves 16-byte vectors)");
+  int dev = 0;
+  const int n_cu = current_device_cus(&dev);
+  if (n_cu <= 0) {
+    omp_set_error("omp_swin_attn_block_packed: cannot query the device");
+    return OMP_ERR_LAUNCH;
   }
   const int grid = (int)(nw < n_cu ? nw : n_cu);
   p.trace = omp_cur().mlp_trace;

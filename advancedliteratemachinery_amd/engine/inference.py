@@ -142,11 +142,18 @@ def _rank_items(dataloader, rank, ws, sharded):
     n_items = len(dataloader)
     lo, hi = udist.shard_range(n_items, rank, ws)
     ds = getattr(dataloader, 'dataset', None)
+    # only a loader that walks its dataset IN ORDER may be re-pointed at a Subset: a full-length non-sequential sampler (a
+    # permutation, a weighted sampler) defines the item order itself -- that falls through to islice below
     if isinstance(dataloader, torch.utils.data.DataLoader) and ds is not None and hasattr(ds, '__getitem__') and \
-            (dataloader.batch_size in (1, None)) and len(ds) == n_items:
+            (dataloader.batch_size in (1, None)) and len(ds) == n_items and \
+            isinstance(getattr(dataloader, 'sampler', None), torch.utils.data.SequentialSampler):
         sub = torch.utils.data.Subset(ds, range(lo, hi))
+        kw = {}
+        if dataloader.num_workers > 0:   # these two are only legal with worker processes
+            kw = dict(prefetch_factor=dataloader.prefetch_factor, persistent_workers=dataloader.persistent_workers)
         return torch.utils.data.DataLoader(sub, batch_size=dataloader.batch_size, shuffle=False, num_workers=dataloader.num_workers,
-                                           collate_fn=dataloader.collate_fn, pin_memory=dataloader.pin_memory), lo, hi
+                                           collate_fn=dataloader.collate_fn, pin_memory=dataloader.pin_memory,
+                                           worker_init_fn=dataloader.worker_init_fn, **kw), lo, hi
     if isinstance(dataloader, (list, tuple)):
         return dataloader[lo:hi], lo, hi
     return itertools.islice(iter(dataloader), lo, hi), lo, hi

@@ -50,19 +50,21 @@ class Encoder(object):
         self.args = args
         self.window = swin_cfg['window']
         self.embed_dim = swin_cfg['embed_dim']
-        if dtype == torch.bfloat16 and self.embed_dim % 64 != 0:
-            # the bf16 matrix-core GEMMs step K in 64-element tiles (csrc/gemm.hip); Swin-T's stage-0 width (96) does not divide
-            raise ValueError('the bf16 engine needs channel widths that are multiples of 64 (embed_dim = %d): run this backbone with '
-                             "engine_dtype='fp32'" % self.embed_dim)
         f32 = lambda k: sd[k].detach().float().contiguous()          # noqa: E731
-        if self.x3:   # [w_hi | w_hi | w_lo] images of the fp32 matrices (ops.split_weight3); K % 64 == 0 for the bf16 K tiles
+        # The bf16 matrix-core GEMMs step K in 64-element tiles (csrc/gemm.hip).  A width that does not divide (BASELINE config 1's
+        # Swin-T: stage 0 is 96 wide) gets its WEIGHT image zero-padded to the next multiple of 64 (round 4; it was refused before):
+        # zero columns cost no accuracy, and what the activation side contributes against them is finite (see _gemm).
+        def pad64(w):
+            k = w.shape[1]
+            return w if k % 64 == 0 else torch.nn.functional.pad(w, (0, 64 - k % 64))
+        if self.x3:   # [w_hi | w_hi | w_lo] images of the fp32 matrices (ops.split_weight3), the IMAGE padded to K' % 64 == 0
             def mat(k):
                 w = sd[k].detach().float()
-                w = w.reshape(w.shape[0], -1)
-                if w.shape[1] % 64 != 0:
-                    raise ValueError('the bf16x3 engine needs GEMM K extents that are multiples of 64 (%s has K = %d): run this backbone with '
-                                     "engine_dtype='fp32'" % (k, w.shape[1]))
-                return ops.split_weight3(w)
+                return pad64(ops.split_weight3(w.reshape(w.shape[0], -1))).contiguous()
+        elif dtype == torch.bfloat16:
+            def mat(k):   # every matrix this encoder multiplies with is [out, in] after flattening (1x1 convolutions included)
+                w = sd[k].detach().to(dtype)
+                return pad64(w.reshape(w.shape[0], -1)).contiguous()
         else:
             mat = lambda k: sd[k].detach().to(dtype).contiguous()    # noqa: E731
         bb = 'backbone.0.'
@@ -117,6 +119,23 @@ class Encoder(object):
         self.proj_w = mat('input_proj.weight').reshape(args.tfm_hidden_dim, -1).contiguous()
         self.proj_b = f32('input_proj.bias')
 
+    @staticmethod
+    def _gemm(A, W, bias=None, **kw):
+        """ops.gemm for a weight whose K was zero-padded to a multiple of 64 (bf16 engine, widths like Swin-T's 96): the product
+        runs over the padded K on the activation's own row pitch, i.e. the last K - C columns of a row are read from the NEXT row
+        (finite activations against zero weights); `_rows` gives those buffers one spare zero row so that the last row reads zeros
+        and not whatever lies behind the tensor."""
+        if W.shape[1] != A.shape[-1] and not kw.get('a_wrap'):
+            kw.update(K=W.shape[1], lda=A.shape[-1])
+        return ops.gemm(A, W, bias, **kw)
+
+    @staticmethod
+    def _rows(rows, C, dtype, device):
+        """GEMM operand buffer [rows, C] (+ a spare zero row when C is not a multiple of 64, see _gemm)."""
+        if C % 64 == 0:
+            return torch.empty((rows, C), dtype=dtype, device=device)
+        return torch.zeros((rows + 1, C), dtype=dtype, device=device)[:rows]
+
     # -- Swin ---------------------------------------------------------------------------------
     def _backbone_x3(self, img, want_f32):
         """The bf16x3 engine's backbone: fp32 residual stream x, split-pair GEMM operands, fp32 window attention.
@@ -168,21 +187,25 @@ class Encoder(object):
                     ops.swin_attn_block_packed(x, blk.n1g, blk.n1b, blk.attn_pack, blk.qkv_b, blk.bias_exp, blk.proj_b, B, H, W, C, st.nH,
                                                blk.shift, window=self.window, eps=LN_EPS)
                 else:
-                    y = ops.layernorm(x, blk.n1g, blk.n1b, out_dtype=T, eps=LN_EPS)
-                    qkv = ops.gemm(y, blk.qkv_w, blk.qkv_b)
+                    if y is None:
+                        y = self._rows(x.shape[0], C, T, x.device)
+                    y = ops.layernorm(x, blk.n1g, blk.n1b, out=y, out_dtype=T, eps=LN_EPS)
+                    qkv = self._gemm(y, blk.qkv_w, blk.qkv_b)
                     att = ops.swin_window_attn(qkv, blk.qkv_b, blk.table, B, H, W, C, st.nH, blk.shift, out=y,
                                                window=self.window, bias_expanded=blk.bias_exp)
-                    ops.gemm(att, blk.proj_w, blk.proj_b, residual=x, out=x)
+                    self._gemm(att, blk.proj_w, blk.proj_b, residual=x, out=x)
                 if blk.mlp_pack is not None:   # norm2 + fc1 + GELU + fc2 + residual in one launch, in place
                     ops.swin_mlp_fused(x, blk.n2g, blk.n2b, blk.mlp_pack, blk.fc2_b, out=x, eps=LN_EPS)
                 else:
+                    if y is None:
+                        y = self._rows(x.shape[0], C, T, x.device)
                     y = ops.layernorm(x, blk.n2g, blk.n2b, out=y, out_dtype=T, eps=LN_EPS)
-                    h = ops.gemm(y, blk.fc1_w, blk.fc1_b, act=ops.ACT_GELU)
-                    ops.gemm(h, blk.fc2_w, blk.fc2_b, residual=x, out=x)
-            outs.append((ops.layernorm(x, st.out_g, st.out_b, out_dtype=T, eps=LN_EPS), H, W))
+                    h = self._gemm(y, blk.fc1_w, blk.fc1_b, act=ops.ACT_GELU)
+                    self._gemm(h, blk.fc2_w, blk.fc2_b, residual=x, out=x)
+            outs.append((ops.layernorm(x, st.out_g, st.out_b, out=self._rows(x.shape[0], C, T, x.device), out_dtype=T, eps=LN_EPS), H, W))
             if st.down_w is not None:
-                y, H2, W2 = ops.patch_merge_gather_ln(x, st.down_g, st.down_b, B, H, W, C, LN_EPS, out_dtype=T)
-                x = ops.gemm(y, st.down_w, out_dtype=torch.float32)
+                ym, H2, W2 = ops.patch_merge_gather_ln(x, st.down_g, st.down_b, B, H, W, C, LN_EPS, out_dtype=T)
+                x = self._gemm(ym, st.down_w, out_dtype=torch.float32)
                 H, W = H2, W2
         return outs
 

@@ -181,13 +181,13 @@ class OmniParser(nn.Module):
     def _decode(self, dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side, packed=None):
         """point decoder -> polygon || recognition decoders (or the KIE walk) on the current stream"""
         a = self.args
+        if packed is not None and a.infer_vie:   # before any work: the KIE branch below returns early
+            raise ValueError('packed results are the text-spotting payload; KIE returns entity lists')
         pts = dec.decode_points(kv, prompt, forced_instances=forced_instances)
         self._mark('pt_decode')
         if a.infer_vie:
             sizes = sequence[3]
             return self._kie(dec, kv, pts, poly_sos, rec_sos, sizes, B, side)
-        if packed is not None and a.infer_vie:
-            raise ValueError('packed results are the text-spotting payload; KIE returns entity lists')
         counts = [int(ids.numel()) // 2 for ids, _ in pts]
         R = sum(counts)
         if R == 0:

@@ -75,14 +75,33 @@ def unpack_results(ids, probs, n_inst):
     return out
 
 
+def pack_payload(ids, probs, n_inst=None):
+    """ids int32 [b, N, T], probs fp32 [b, N, L] (and n_inst int32 [b]) -> ONE int32 tensor [b, N * (T + L) (+ 1)]: the probabilities
+    travel as their bit patterns, so an engine call costs a single collective (its latency term, not its bandwidth, is what counts)."""
+    b = ids.shape[0]
+    parts = [ids.reshape(b, -1), probs.reshape(b, -1).contiguous().view(torch.int32)]
+    if n_inst is not None:
+        parts.append(n_inst.reshape(b, 1).to(torch.int32))
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def unpack_payload(buf, ids_shape, probs_shape, with_n=True):
+    """Inverse of pack_payload for a gathered buffer [B, ...]: ids_shape / probs_shape are the per-image shapes (N, T) / (N, L)."""
+    B = buf.shape[0]
+    ni, npb = ids_shape[0] * ids_shape[1], probs_shape[0] * probs_shape[1]
+    ids = buf[:, :ni].reshape((B,) + tuple(ids_shape))
+    probs = buf[:, ni:ni + npb].contiguous().view(torch.float32).reshape((B,) + tuple(probs_shape))
+    n_inst = buf[:, ni + npb].contiguous() if with_n else None
+    return ids, probs, n_inst
+
+
 def all_gather_results(ids, probs, n_inst):
-    """One all-gather per tensor; every rank must contribute the same local batch size."""
+    """ONE all-gather per engine call (ids, probabilities and instance counts in one int32 payload); every rank must contribute the
+    same local batch size."""
     rank, ws = world()
     if ws == 1:
         return ids, probs, n_inst
-    outs = []
-    for t in (ids, probs, n_inst):
-        buf = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(buf, t.contiguous())
-        outs.append(buf)
-    return tuple(outs)
+    payload = pack_payload(ids, probs, n_inst)
+    buf = torch.empty((ws * payload.shape[0], payload.shape[1]), dtype=torch.int32, device=payload.device)
+    dist.all_gather_into_tensor(buf, payload)
+    return unpack_payload(buf, ids.shape[1:], probs.shape[1:])

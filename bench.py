@@ -47,6 +47,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+from advancedliteratemachinery_amd.utils.dist import pack_payload, unpack_payload  # noqa: E402
+
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 MFMA_PEAK_TFS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix-core peak
 
@@ -242,6 +244,24 @@ def cpu_baseline(args, sd, size, instances, pt_steps, budget_s=32.0):
                           chars_per_sec=n_small * args.rec_length / t_small,
                           sample='oracle.forward end to end: 512x512 image, pt_seq_length 4 (%d instances), %d threads' % (n_small, min(cores, 64)))
     print('[cpu_baseline] measured end to end: 512x512, %d instances: %.2fs' % (n_small, t_small), file=sys.stderr, flush=True)
+    # -- measured: BASELINE config 1 COMPLETE (Swin-T widths, one 640x640 image, pt_seq_length 32 -> 16 instances with their 32-token
+    #    polygons and 25-token transcriptions; the case of tools/cpu_full_c1.py): ~10 s on 16 threads, skipped on small hosts
+    measured_c1 = None
+    if cores >= 8:
+        from oracle import gen_golden as G_
+        case = dict(args=dict(tfm_pre_norm=True, use_fpn=False, use_char_window_prompt=True, pt_seq_length=32),
+                    hw=(640, 640), depths=(2, 2, 6, 2), swin=dict(embed_dim=96, num_heads=(3, 6, 12, 24)))
+        a1, sd1, img1, mask1_, seqs1 = G_.case_inputs(case)
+        with torch.no_grad():
+            t0 = time.time()
+            out1 = O.forward(sd1, a1, img1, mask1_, seqs1, depths=case['depths'], num_heads=case['swin']['num_heads'])
+            t_c1 = time.time() - t0
+        n1 = 0 if out1 is None else int(out1[0][0].numel()) // 2
+        measured_c1 = dict(value=1.0 / t_c1, unit='images/s', seconds=t_c1, image_size=640, instances=n1, chars_per_sec=n1 * a1.rec_length / t_c1,
+                           sample='BASELINE config 1 run COMPLETE, not extrapolated: oracle.forward on one 640x640 image, Swin-T widths (embed 96, depths 2-2-6-2, '
+                                  'no FPN), pt_seq_length 32 (%d instances), %d threads' % (n1, min(cores, 64)))
+        print('[cpu_baseline] config 1 complete: 640x640, %d instances: %.2fs' % (n1, t_c1), file=sys.stderr, flush=True)
+        del sd1, img1
     t_start = time.time()
     left = lambda: budget_s - (time.time() - t_start)   # noqa: E731
     log = lambda m: print('[cpu_baseline] ' + m, file=sys.stderr, flush=True)  # noqa: E731
@@ -290,7 +310,7 @@ def cpu_baseline(args, sd, size, instances, pt_steps, budget_s=32.0):
         notes.append('polygon/recognition steps estimated from the point step (budget)')
     t_pt = pt_steps * 0.5 * (t_pt_a + t_pt_b)
     t_total = t_enc + t_pt + (32 * t_poly + args.rec_length * t_rec) * (instances / n_s)
-    return dict(value=1.0 / t_total, unit='images/s', cores=cores, kind='port', estimated=True, measured_small=measured_small,
+    return dict(value=1.0 / t_total, unit='images/s', cores=cores, kind='port', estimated=True, measured_small=measured_small, measured_c1=measured_c1,
                 sample=('ESTIMATE from a bounded sample (the measured end-to-end run is `measured_small`) -- oracle (CPU restatement of the reference path, fp32, %d threads): encode of one %dx%d image '
                         'measured and scaled x%.0f to %dx%d = %.2fs; point-decoder call %.3fs (L=7) / %.3fs (L=%d) '
                         'measured against a %d-token memory, x%d steps; polygon / recognition call %.3fs / %.3fs '
@@ -549,12 +569,13 @@ def main():
         # results were produced on a lane stream and are consumed by RCCL on this one: tell the caching allocator
         ids.record_stream(torch.cuda.current_stream())
         probs.record_stream(torch.cuda.current_stream())
-        all_ids = torch.empty(world * B * g_, N, ids.shape[2], dtype=torch.int32, device=device)
-        all_pr = torch.empty(world * B * g_, N, args.rec_length, dtype=torch.float32, device=device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        dist.all_gather_into_tensor(all_ids, ids)
-        dist.all_gather_into_tensor(all_pr, probs)
+        # ONE collective per engine call: ids and probability bit patterns in one int32 payload (utils/dist.py::pack_payload)
+        payload = pack_payload(ids, probs)
+        buf = torch.empty(world * payload.shape[0], payload.shape[1], dtype=torch.int32, device=device)
+        dist.all_gather_into_tensor(buf, payload)
+        all_ids, all_pr, _ = unpack_payload(buf, ids.shape[1:], probs.shape[1:], with_n=False)
         e1.record()
         gather_ev.append((e0, e1))
         return all_ids, all_pr
@@ -900,7 +921,7 @@ def main():
             rec['ranks'] = rank_diag
             rec['per_rank_ms_per_step'] = per_rank_ms
             rec['all_gather_ms'] = dict(calls=len(gather_ms), median=pct(gather_ms, 0.5), p90=pct(gather_ms, 0.9),
-                                        note='two all_gather_into_tensor (ids, probs) per engine call, HIP events on rank 0')
+                                        note='ONE all_gather_into_tensor per engine call (ids + probability bit patterns in one int32 payload), packing included, HIP events on rank 0')
         if roof is not None:
             rec['roofline'] = roof
             rec['roofline_other'] = roof_other

@@ -781,10 +781,21 @@ def check_e2e(name, dtype_name='fp32', graph=False):
 BF16_REL = dict(stage=0.02, fpn=0.025, memory=0.025, pos=0.01)   # round 3 (fp32 residual stream): measured <= 0.0085 / 0.0096 / 0.0097
 BF16_LOGIT_REL = 0.03
 MARGIN_K = 2.0
-BF16_TOKEN_FLOOR = {   # fixture -> (pt, poly, rec) minimum fraction of tokens identical to the reference's
-    'spot_odd': (1.0, 0.70, 0.68), 'spot_224': (1.0, 0.82, 0.78), 'spot_1024': (1.0, 0.75, 0.78), 'spot_640': (0.30, 0.24, 0.16),
-    'spot_padded,img0': (1.0, 0.70, 0.68), 'spot_padded,img1': (1.0, 0.82, 0.78),
+# Round 4: the POINT tokens are no longer held to a per-fixture fraction (spot_640's was 0.30 -- a gate that low
+# tests nothing) but to a statement that has a reason: the engine's point sequence equals the reference's up to the FIRST position where
+# the reference's own margin (its token's logit minus the logit of the token the engine chose, from the reference's teacher-forced
+# logits in the fixture) lies inside the measured bf16 noise band (MARGIN_K x the engine's teacher-forced logit error) -- a flip
+# anywhere else fails.  Polygon / recognition tokens are conditioned on the points: their floors apply when the point tokens are
+# identical and are only reported otherwise.  KIE: the same number of entities as the reference and at least BF16_KIE_FLOOR of them
+# identical in text and class (measured: 1 of 2 on kie_960x1280, all on kie_sroie).
+BF16_TOKEN_FLOOR = {   # fixture -> (poly, rec) minimum fraction of tokens identical to the reference's, given identical point tokens
+    'spot_odd': (0.70, 0.68), 'spot_224': (0.82, 0.78), 'spot_1024': (0.75, 0.78), 'spot_640': (0.70, 0.68),
+    'spot_padded,img0': (0.70, 0.68), 'spot_padded,img1': (0.82, 0.78),
+    'spot_1024_n40': (0.72, 0.76),   # measured 0.835 / 0.878 (profiles/r04c_parity_report_split_slabs.json), 40 instances over M = 4096
+    'spot_640_n64': (0.60, 0.50),    # measured 0.687 / 0.575 with the points diverging at token 24 (a near-tie): applies if they do not
+    'swint_nofpn': (0.60, 0.60),
 }
+BF16_KIE_FLOOR = 0.4
 REPORT = []   # records of the measured errors (tools/parity_report.py dumps them for profiles/)
 
 
@@ -877,11 +888,16 @@ def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
             n_same = sum(1 for a, b_ in zip(res or [], go or []) if a[0] == b_[0] and a[1] == b_[1])
             REPORT.append(dict(name='e2e[%s,bf16] kie result identical' % name, value=bool(same), entities=len(res or []),
                                reference_entities=len(go or []), entities_with_identical_text_and_class=n_same))
-            out.append(rec('e2e[%s,bf16] kie result non-empty like the reference' % name, 0 if bool(res) == bool(go) else 1, 0))
+            out.append(rec('e2e[%s,bf16] kie: as many entities as the reference' % name, abs(len(res or []) - len(go or [])), 0,
+                           '%d vs %d' % (len(res or []), len(go or []))))
+            frac = n_same / float(len(go)) if go else 1.0
+            out.append(rec('e2e[%s,bf16] kie: entities identical in text and class >= %.2f' % (name, BF16_KIE_FLOOR), max(0.0, BF16_KIE_FLOOR - frac), 0.0,
+                           '%d of %d' % (n_same, len(go or []))))
         return out
     # teacher-forced logits (decision-level parity without greedy cascades)
     tf = gold['tf']
     noisy_positions = 0
+    pt_err = None   # measured teacher-forced point-logit error of this engine on this fixture (the bf16 noise band's unit)
     if tf:
         memb = e['memory'].reshape(B, M, -1)[b].contiguous()
         mpb = e['mem_pos'].reshape(B, M, -1)[b].contiguous()
@@ -893,6 +909,8 @@ def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
             lg = dec.teacher_forced_logits(kind, kv, s_in, [s_in.shape[0]], n_prompt).float().cpu()
             scale = ref.abs().max().item()
             err = (lg - ref).abs().max().item()
+            if kind == 'pt':
+                pt_err = err
             REPORT.append(dict(name='e2e[%s,%s] teacher-forced %s logits' % (name, dtype_name, kind), abs_err=err, rel_err=err / scale, ref_absmax=scale))
             out.append(rec('e2e[%s,%s] teacher-forced %s logits' % (name, dtype_name, kind), err if f32 else err / scale,
                            1e-3 if f32 else BF16_LOGIT_REL, 'max|logit|=%.1f abs err %.3g' % (scale, err)))
@@ -912,6 +930,7 @@ def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
         return out
     ids = [t.cpu() for t in res[0]]
     floors = BF16_TOKEN_FLOOR.get(name.replace(',graph', ''))
+    pt_same = ids[0].shape == go['pt'].shape and bool((ids[0] == go['pt']).all())
     for ki, (key, t) in enumerate(zip(('pt', 'poly', 'rec'), ids)):
         same = t.shape == go[key].shape and bool((t == go[key]).all())
         frac = float((t.reshape(-1) == go[key].reshape(-1)).float().mean()) if t.shape == go[key].shape else 0.0
@@ -919,11 +938,55 @@ def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
                            first_divergence=_first_div(t, go[key]), n=int(go[key].numel())))
         if f32:
             out.append(rec('e2e[%s,%s] %s tokens' % (name, dtype_name, key), 0 if same else 1, 0, 'match=%.3f' % frac))
-        elif floors is not None:   # bf16: unconditional measured floor
-            out.append(rec('e2e[%s,%s] %s tokens >= %.2f of the reference\'s' % (name, dtype_name, key, floors[ki]), max(0.0, floors[ki] - frac), 0.0,
+        elif key == 'pt':
+            # bf16: identical up to the first reference near-tie (see BF16_TOKEN_FLOOR above)
+            d = _first_div(t, go['pt'])
+            if same or not tf or pt_err is None:
+                out.append(rec('e2e[%s,%s] pt tokens identical (or no teacher-forced logits to explain a flip)' % (name, dtype_name), 0 if same else 1, 0, 'match=%.3f' % frac))
+            elif d >= min(t.numel(), go['pt'].numel()):
+                # one sequence is a prefix of the other: the flip is EOS against a coordinate at position d
+                out.append(rec('e2e[%s,%s] pt tokens: lengths %d vs %d' % (name, dtype_name, t.numel(), go['pt'].numel()), 1, 0, 'prefix identical'))
+            else:
+                npr = O.prompt_len(args)
+                ref_lg = tf['pt_logits'][0, npr - 1 + d].float()
+                tok_ref, tok_eng = int(go['pt'].reshape(-1)[d]), int(t.reshape(-1)[d])
+                margin = float(ref_lg[tok_ref] - ref_lg[tok_eng])
+                band = MARGIN_K * pt_err
+                REPORT.append(dict(name='e2e[%s,%s] pt first flip' % (name, dtype_name), position=d, reference_margin=margin, noise_band=band))
+                out.append(rec('e2e[%s,%s] pt tokens identical up to a reference near-tie (first flip at %d)' % (name, dtype_name, d),
+                               max(0.0, margin - band), 0.0, 'reference margin %.4f over the engine\'s token, noise band %.4f' % (margin, band)))
+        elif floors is not None and pt_same:   # bf16: measured floor, given the same instances
+            fl = floors[ki - 1]
+            out.append(rec('e2e[%s,%s] %s tokens >= %.2f of the reference\'s' % (name, dtype_name, key, fl), max(0.0, fl - frac), 0.0,
                            'match=%.3f first divergence at %d' % (frac, _first_div(t, go[key]))))
     if res[1][0].shape == go['rec_probs'].shape and (f32 or all(bool((t == go[k]).all()) for k, t in zip(('pt', 'poly', 'rec'), ids) if t.shape == go[k].shape)):
         out.append(rec('e2e[%s,%s] rec probs' % (name, dtype_name), maxerr(res[1][0], go['rec_probs']), 1e-3 if f32 else 5e-2))
+    return out
+
+
+def check_fused_attn_unfused_mlp():
+    """a block whose attention half is fused (omp_swin_attn_block) but whose MLP is not (args.fused_mlp = False, or a
+    width without a packed MLP) used to hit an unbound LayerNorm buffer.  bf16 engine, spot_224: the stage maps of that
+    configuration against the reference fixture (the usual bf16 gates) and against the default (both halves fused) engine."""
+    gold = golden('spot_224')
+    case = gold['case']
+    args, sd, img, mask, _ = G.case_inputs(case)
+    out = []
+    feats = {}
+    for tag, fm in (('fused mlp', True), ('unfused mlp', False)):
+        args.fused_mlp, args.fused_attn = fm, True
+        model = build_model(args, sd, case['depths'], torch.bfloat16)
+        enc, _ = model.engine()
+        e = enc.encode(img.to(DEV), mask.to(DEV), want_intermediates=True)
+        feats[tag] = [f.float().cpu() for f, _, _ in e['feats']]
+        fs = gold.get('feat_stride', (8, 3, 3))
+        if not fm:
+            out.append(rec('fused attention + unfused MLP: attention half really fused', 0 if enc.stages[0].blocks[0].attn_fused and enc.stages[0].blocks[0].mlp_pack is None else 1, 0))
+            for i, ((f, h, w), smp) in enumerate(zip(e['feats'], gold['feat_sample'])):
+                fm_ = f.reshape(1, h, w, -1).permute(0, 3, 1, 2)
+                out.append(rec('fused attention + unfused MLP: stage%d vs reference' % i, _rel(fm_[0, ::fs[0], ::fs[1], ::fs[2]], smp), BF16_REL['stage']))
+    for i, (a, b) in enumerate(zip(feats['fused mlp'], feats['unfused mlp'])):
+        out.append(rec('fused attention: unfused vs fused MLP, stage%d' % i, _rel(a, b), BF16_REL['stage']))
     return out
 
 

@@ -184,3 +184,13 @@ def test_rank_items_reads_only_the_ranks_own_shard():
     assert inf._rank_items(seq, 1, 2, True)[0] is seq and inf._rank_items(seq, 0, 1, False)[0] is seq   # already sharded / single rank
     with pytest.raises(TypeError):
         inf._rank_items(iter(seq), 0, 2, False)
+    # a full-length NON-sequential sampler defines the item order itself -- the shard is cut from THAT order (islice),
+    # the loader is not silently re-pointed at Subset(dataset, range(lo, hi))
+    order = [9, 0, 8, 1, 7, 2, 6, 3, 5, 4]
+    dl2 = torch.utils.data.DataLoader(Counting(10), batch_size=1, sampler=order, num_workers=0, collate_fn=lambda b: b[0])
+    items, lo, hi = inf._rank_items(dl2, 1, 3, False)
+    assert [int(img[0, 0, 0]) for img, _ in items] == order[lo:hi]
+    # the re-pointed loader keeps the original's worker_init_fn
+    mark = lambda _: None   # noqa: E731
+    dl3 = torch.utils.data.DataLoader(Counting(10), batch_size=1, shuffle=False, num_workers=0, collate_fn=lambda b: b[0], worker_init_fn=mark)
+    assert inf._rank_items(dl3, 0, 2, False)[0].worker_init_fn is mark

@@ -340,6 +340,26 @@ def bench_dec_gemm_rows():
             ops.force_gemm_kernel(0)
 
 
+def bench_patch_embed():
+    """PatchEmbed + LayerNorm of one 32-image encoder chunk at 1024x1024: the fp32 matrix-core kernel vs the thread-per-token kernel."""
+    B, H, W, E = int(os.environ.get('KBENCH_PE_B', '32')), 1024, 1024, 128
+    img = torch.randn(B, 3, H, W, device=DEV)
+    w, b = torch.randn(E, 48, device=DEV) * 0.2, torch.randn(E, device=DEV) * 0.1
+    g, be = torch.ones(E, device=DEV), torch.zeros(E, device=DEV)
+    by = img.numel() * 4 + B * (H // 4) * (W // 4) * E * 4
+    outs = {}
+    for name, env in (('mfma', None), ('thread-per-token', '1')):
+        if env:
+            os.environ['OMP355_PATCH_EMBED_SCALAR'] = env
+        else:
+            os.environ.pop('OMP355_PATCH_EMBED_SCALAR', None)
+        us = timeit(lambda: ops.patch_embed_ln(img, w, b, g, be, torch.float32), iters=10, warm=2)
+        outs[name] = ops.patch_embed_ln(img, w, b, g, be, torch.float32)[0]
+        print('patch_embed[%-16s] B%d %dx%d E%d : %8.1f us  %6.0f GB/s (%.2f of 8 TB/s)' % (name, B, H, W, E, us, by / us / 1e3, by / us / 1e3 / 8000), flush=True)
+    os.environ.pop('OMP355_PATCH_EMBED_SCALAR', None)
+    print('patch_embed max |mfma - thread-per-token| = %.3g' % (outs['mfma'] - outs['thread-per-token']).abs().max().item(), flush=True)
+
+
 def bench_selfattn(dtype=torch.bfloat16):
     ops.force_gemm_kernel(0)
     d, nH = 512, 8
@@ -389,6 +409,8 @@ if __name__ == '__main__':
         bench_cross()
     if 'dec_gemm' in what or 'all' in what:
         bench_dec_gemm()
+    if 'patch_embed' in what:
+        bench_patch_embed()
     if 'cross_split' in what:
         bench_cross_split()
     if 'dec_rows' in what:
