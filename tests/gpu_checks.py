@@ -770,14 +770,12 @@ def check_e2e(name, dtype_name='fp32', graph=False):
 #   * teacher-forced logits within BF16_LOGIT_REL of max|logit|;
 #   * at every teacher-forced position whose reference top-1/top-2 margin exceeds MARGIN_K x the measured logit error of
 #     that sequence, the engine's argmax equals the reference's (a decision can only flip inside the noise band);
-#   * free-running tokens: UNCONDITIONAL floors per fixture on the fraction of tokens equal to the reference's (round 3; the
-#     round-2 gate was conditional on "no teacher-forced position inside the noise band" and never fired).  One flipped
-#     near-tie changes the rest of a greedy sequence, so the fraction moves by +-0.1 between kernel versions of equal accuracy
-#     (profiles/r03b_parity_report_fp32_residual.json vs r03d: rec 0.82 <-> 0.92 on spot_odd); the floors sit ~0.12 below the
-#     lowest value measured this round.  Point tokens are identical to the reference's on every fixture but spot_640, whose
-#     FIRST generated token is a reference near-tie inside the bf16 noise band (everything after it differs: 0.375).
-#     The engine that is token-exact is bf16x3 (test_parity_engine_bf16x3), not this one.
-#   * KIE (a free-running greedy walk): the result list is compared entity by entity and REPORTED; gated on being non-empty.
+#   * free-running tokens (round 4): identical to the reference's up to the first position where the reference's own margin over the
+#     engine's choice lies inside the measured noise band -- point tokens always, polygon / recognition tokens for the instances whose
+#     reference logits the fixture holds; see the block above BF16_TOKEN_SANITY.  (Rounds 2-3 used per-fixture fractions of equal
+#     tokens; one flipped near-tie changes the rest of a greedy sequence, so those floors either tested nothing -- spot_640: 0.30 -- or
+#     failed on luck.)  The engine that is token-exact is bf16x3 (test_parity_engine_bf16x3), not this one.
+#   * KIE (a free-running greedy walk): as many entities as the reference, at least BF16_KIE_FLOOR of them identical in text and class.
 BF16_REL = dict(stage=0.02, fpn=0.025, memory=0.025, pos=0.01)   # round 3 (fp32 residual stream): measured <= 0.0085 / 0.0096 / 0.0097
 BF16_LOGIT_REL = 0.03
 MARGIN_K = 2.0
@@ -788,13 +786,11 @@ MARGIN_K = 2.0
 # anywhere else fails.  Polygon / recognition tokens are conditioned on the points: their floors apply when the point tokens are
 # identical and are only reported otherwise.  KIE: the same number of entities as the reference and at least BF16_KIE_FLOOR of them
 # identical in text and class (measured: 1 of 2 on kie_960x1280, all on kie_sroie).
-BF16_TOKEN_FLOOR = {   # fixture -> (poly, rec) minimum fraction of tokens identical to the reference's, given identical point tokens
-    'spot_odd': (0.70, 0.68), 'spot_224': (0.82, 0.78), 'spot_1024': (0.75, 0.78), 'spot_640': (0.70, 0.68),
-    'spot_padded,img0': (0.70, 0.68), 'spot_padded,img1': (0.82, 0.78),
-    'spot_1024_n40': (0.72, 0.76),   # measured 0.835 / 0.878 (profiles/r04c_parity_report_split_slabs.json), 40 instances over M = 4096
-    'spot_640_n64': (0.60, 0.50),    # measured 0.687 / 0.575 with the points diverging at token 24 (a near-tie): applies if they do not
-    'swint_nofpn': (0.60, 0.60),
-}
+# Polygon / recognition tokens (given identical points): for the instances whose reference logits the fixture holds (the first two),
+# the same statement -- identical up to the first reference near-tie; over ALL instances only a sanity floor on the fraction of equal
+# tokens (one flipped near-tie changes the rest of a greedy sequence: the fraction moved 0.82 <-> 0.64 on spot_224 between two kernel
+# versions of equal accuracy -- r03l vs r04g -- so a tight per-fixture floor measures luck, not parity).
+BF16_TOKEN_SANITY = 0.35
 BF16_KIE_FLOOR = 0.4
 REPORT = []   # records of the measured errors (tools/parity_report.py dumps them for profiles/)
 
@@ -929,7 +925,8 @@ def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
         out.append(rec('e2e[%s,%s] empty result' % (name, dtype_name), 0 if (res is None) == (go is None) else 1, 0))
         return out
     ids = [t.cpu() for t in res[0]]
-    floors = BF16_TOKEN_FLOOR.get(name.replace(',graph', ''))
+    kind_err = {r_['name'].split('teacher-forced ')[1].split(' ')[0]: r_['abs_err'] for r_ in REPORT
+                if r_.get('name', '').startswith('e2e[%s,%s] teacher-forced' % (name, dtype_name)) and r_['name'].endswith('logits')}
     pt_same = ids[0].shape == go['pt'].shape and bool((ids[0] == go['pt']).all())
     for ki, (key, t) in enumerate(zip(('pt', 'poly', 'rec'), ids)):
         same = t.shape == go[key].shape and bool((t == go[key]).all())
@@ -939,7 +936,7 @@ def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
         if f32:
             out.append(rec('e2e[%s,%s] %s tokens' % (name, dtype_name, key), 0 if same else 1, 0, 'match=%.3f' % frac))
         elif key == 'pt':
-            # bf16: identical up to the first reference near-tie (see BF16_TOKEN_FLOOR above)
+            # bf16: identical up to the first reference near-tie (see the gate description above BF16_TOKEN_SANITY)
             d = _first_div(t, go['pt'])
             if same or not tf or pt_err is None:
                 out.append(rec('e2e[%s,%s] pt tokens identical (or no teacher-forced logits to explain a flip)' % (name, dtype_name), 0 if same else 1, 0, 'match=%.3f' % frac))
@@ -955,9 +952,21 @@ def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
                 REPORT.append(dict(name='e2e[%s,%s] pt first flip' % (name, dtype_name), position=d, reference_margin=margin, noise_band=band))
                 out.append(rec('e2e[%s,%s] pt tokens identical up to a reference near-tie (first flip at %d)' % (name, dtype_name, d),
                                max(0.0, margin - band), 0.0, 'reference margin %.4f over the engine\'s token, noise band %.4f' % (margin, band)))
-        elif floors is not None and pt_same:   # bf16: measured floor, given the same instances
-            fl = floors[ki - 1]
-            out.append(rec('e2e[%s,%s] %s tokens >= %.2f of the reference\'s' % (name, dtype_name, key, fl), max(0.0, fl - frac), 0.0,
+        elif pt_same:   # bf16, same instances: near-tie gate on the instances with reference logits + a sanity floor over all
+            L = 32 if key == 'poly' else go[key].shape[-1]
+            te, tr = t.reshape(-1, L), go[key].reshape(-1, L)
+            n_tf = tf[key + '_in'].shape[0] if tf else 0
+            for i in range(min(n_tf, te.shape[0])):
+                d = _first_div(te[i], tr[i])
+                if d >= L:
+                    continue
+                ref_lg = tf[key + '_logits'][i, 3 - 1 + d].float()
+                margin = float(ref_lg[int(tr[i, d])] - ref_lg[int(te[i, d])])
+                band = MARGIN_K * kind_err.get(key, 0.0)
+                REPORT.append(dict(name='e2e[%s,%s] %s first flip, instance %d' % (name, dtype_name, key, i), position=d, reference_margin=margin, noise_band=band))
+                out.append(rec('e2e[%s,%s] %s tokens of instance %d identical up to a reference near-tie (first flip at %d)' % (name, dtype_name, key, i, d),
+                               max(0.0, margin - band), 0.0, 'reference margin %.4f over the engine\'s token, noise band %.4f' % (margin, band)))
+            out.append(rec('e2e[%s,%s] %s tokens >= %.2f of the reference\'s (sanity)' % (name, dtype_name, key, BF16_TOKEN_SANITY), max(0.0, BF16_TOKEN_SANITY - frac), 0.0,
                            'match=%.3f first divergence at %d' % (frac, _first_div(t, go[key]))))
     if res[1][0].shape == go['rec_probs'].shape and (f32 or all(bool((t == go[k]).all()) for k, t in zip(('pt', 'poly', 'rec'), ids) if t.shape == go[k].shape)):
         out.append(rec('e2e[%s,%s] rec probs' % (name, dtype_name), maxerr(res[1][0], go['rec_probs']), 1e-3 if f32 else 5e-2))
