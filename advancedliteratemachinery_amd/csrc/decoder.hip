@@ -1353,12 +1353,15 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
   const bool f = dtype == OMP_F32;
   const bool nt_on = cx.cross_nt == 1 || (cx.cross_nt == 2 && n_groups >= 32);
   if (dtype == OMP_BF16X2) {
-    // split-plane slabs (the parity engine): fp32 q / out, three bf16 products per score / value block.  A ring stage is 16 KB: four
-    // stages of one block each (64 KB, two workgroups per CU; selector 4: eight stages in 64-key chunks, one workgroup per CU);
+    // split-plane slabs (the parity engine): fp32 q / out, three bf16 products per score / value block.  A ring stage is 16 KB;
     // the register-streaming kernel keeps 2 blocks (32 KB) in flight per wave.
     if (q4) {
+      // ring geometry, measured at 160 images x 64 rows (profiles/r04h_kbench_cross_split_rings.txt): THREE one-block stages (48 KB: three
+      // workgroups per CU) 481 us = 0.71 of HBM; four stages (two workgroups) 528; five 520; eight stages in 64-key chunks (one) 577
       if (cx.cross_q4 == 4) rc = nt_on ? launch_cross_q4<bf16s_t, 8, 2, true>(cp, n_groups, S, st) : launch_cross_q4<bf16s_t, 8, 2, false>(cp, n_groups, S, st);
-      else rc = nt_on ? launch_cross_q4<bf16s_t, 4, 1, true>(cp, n_groups, S, st) : launch_cross_q4<bf16s_t, 4, 1, false>(cp, n_groups, S, st);
+      else if (cx.cross_q4 == 5) rc = launch_cross_q4<bf16s_t, 4, 1, true>(cp, n_groups, S, st);   // A/B: four stages (64 KB, two workgroups per CU)
+      else if (cx.cross_q4 == 6) rc = launch_cross_q4<bf16s_t, 2, 1, true>(cp, n_groups, S, st);   // A/B: two stages (32 KB, five workgroups per CU)
+      else rc = nt_on ? launch_cross_q4<bf16s_t, 3, 1, true>(cp, n_groups, S, st) : launch_cross_q4<bf16s_t, 3, 1, false>(cp, n_groups, S, st);
     }
     else if (qt == 1) rc = nt_on ? launch_cross_t<bf16s_t, 1, 2, true>(cp, n_groups, S, st) : launch_cross_t<bf16s_t, 1, 2>(cp, n_groups, S, st);
     else if (qt == 2) rc = launch_cross_t<bf16s_t, 2, 2>(cp, n_groups, S, st);
@@ -1709,7 +1712,7 @@ extern "C" int omp_debug_cross_nt(int on) {
 }
 
 extern "C" int omp_debug_cross_q4(int on) {
-  omp_cur().cross_q4 = (on == 0 || on == 2 || on == 4) ? on : 1;
+  omp_cur().cross_q4 = (on == 0 || on == 2 || on == 4 || on == 5 || on == 6) ? on : 1;
   return OMP_OK;
 }
 

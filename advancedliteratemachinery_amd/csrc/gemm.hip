@@ -192,7 +192,7 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, const float* bias
   for (int r = 0; r < 4; ++r) {
     float b = 0.0f;
     if (bias != nullptr) b = p.bias_m ? bias[m] : (n + r < p.N ? bias[n + r] : 0.0f);
-    v[r] = apply_act<TOut>(acc[r] + b, p.act, p.split_out != 0);
+    v[r] = apply_act<TOut>(acc[r] + b, p.act);
   }
   store4<TOut>(p, m, n, v);
 }
@@ -427,14 +427,7 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
             if constexpr (decltype(ACT)::value == OMP_ACT_GELU && !std::is_same<TOut, bf16_t>::value) v[q] = gelu_erf(v[q]);
             if constexpr (decltype(ACT)::value == OMP_ACT_RELU) v[q] = fmaxf(v[q], 0.0f);
           }
-          if constexpr (decltype(ACT)::value == OMP_ACT_GELU && std::is_same<TOut, bf16_t>::value) {
-            if (p.split_out) {   // fp32-grade destination: the < 1 ulp erf form
-#pragma unroll
-              for (int q = 0; q < CH; ++q) v[q] = gelu_erf(v[q]);
-            } else {
-              gelu_fast_n<CH>(v);
-            }
-          }
+          if constexpr (decltype(ACT)::value == OMP_ACT_GELU && std::is_same<TOut, bf16_t>::value) gelu_fast_n<CH>(v);   // bf16 and split pairs alike
           if constexpr (std::is_same<TOut, bf16_t>::value) {
             if (p.split_out) {
               bf16x8 hi, lo;
@@ -485,7 +478,7 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
       if (bias != nullptr && p.bias_m && m0 + r < p.M) bm = bias[m0 + r];
       float v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = apply_act<TOut>(t[u] + bcol[q + u] + bm, p.act, p.split_out != 0);
+      for (int u = 0; u < 4; ++u) v[u] = apply_act<TOut>(t[u] + bcol[q + u] + bm, p.act);
       store4<TOut>(p, m0 + r, n + q, v);
     }
   }

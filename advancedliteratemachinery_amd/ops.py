@@ -424,8 +424,9 @@ def force_gemm_kernel(which):
 
 
 def cross_q4(on):
-    """debug/testing: 1 = LDS-ring cross-attention kernel for 33..64 rows per image, 64-key chunks (default), 2 = the same ring
-    consumed one 32-key block per step, 0 = register-streaming kernel."""
+    """debug/testing: 1 = LDS-ring cross-attention kernel for 33..64 rows per image (default: 64-key chunks on bf16 / fp32 slabs, three
+    one-block stages on split-plane slabs), 2 = the ring consumed one 32-key block per step, 4 = chunks with temporal loads (split
+    planes: eight stages in 64-key chunks), 5 / 6 = split planes with four / two stages, 0 = register-streaming kernel."""
     _lib.check(_lib.lib().omp_debug_cross_q4(int(on)), 'omp_debug_cross_q4')
 
 

@@ -546,9 +546,9 @@ def check_cross_attn_split():
         gd = torch.tensor(groups, dtype=torch.int32, device=DEV)
         km = kmask.to(torch.uint8).to(DEV) if masked else None
         for S in (1, 2, 8):
-            # qt == 4: the LDS-ring kernel in both geometries (1: four one-block stages, 4: eight stages in 64-key chunks) and the
-            # register-streaming kernel (0)
-            for ring in ((1, 4, 0) if qt == 4 else (1,)):
+            # qt == 4: the LDS-ring kernel in every built geometry (1: three one-block stages, 5: four, 6: two, 4: eight stages in 64-key
+            # chunks) and the register-streaming kernel (0)
+            for ring in ((1, 4, 5, 6, 0) if qt == 4 else (1,)):
                 ops.cross_q4(ring)
                 o = torch.full((R, d), float('nan'), device=DEV)
                 partial = torch.full((R, nH, S, 68), float('nan'), device=DEV)

@@ -123,7 +123,7 @@ def bench_cross_split():
         for name, (K, Vt, stride) in slabs.items():
             for S in splits:
                 partial = torch.empty(R, nH, S, 68, device=DEV)
-                for ring in ((1, 4) if (rows_per_img == 64 and name == 'split') else (1,)):
+                for ring in ((1, 4, 5, 6) if (rows_per_img == 64 and name == 'split') else (1,)):
                     h.omp_debug_cross_q4(ring)
                     st = [0]
 
