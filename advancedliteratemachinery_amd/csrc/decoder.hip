@@ -1356,12 +1356,13 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
     // split-plane slabs (the parity engine): fp32 q / out, three bf16 products per score / value block.  A ring stage is 16 KB;
     // the register-streaming kernel keeps 2 blocks (32 KB) in flight per wave.
     if (q4) {
-      // ring geometry, measured at 160 images x 64 rows (profiles/r04h_kbench_cross_split_rings.txt): THREE one-block stages (48 KB: three
-      // workgroups per CU) 481 us = 0.71 of HBM; four stages (two workgroups) 528; five 520; eight stages in 64-key chunks (one) 577
+      // ring geometry, measured at 160 images x 64 rows (profiles/r04h_kbench_cross_split_rings.txt, r04i_*): the more workgroups per CU the
+      // better -- TWO one-block stages (32 KB, five workgroups per CU) 474 us = 0.72 of HBM, three stages 481-489, four 528, eight stages
+      // in 64-key chunks (one workgroup) 577-587
       if (cx.cross_q4 == 4) rc = nt_on ? launch_cross_q4<bf16s_t, 8, 2, true>(cp, n_groups, S, st) : launch_cross_q4<bf16s_t, 8, 2, false>(cp, n_groups, S, st);
       else if (cx.cross_q4 == 5) rc = launch_cross_q4<bf16s_t, 4, 1, true>(cp, n_groups, S, st);   // A/B: four stages (64 KB, two workgroups per CU)
-      else if (cx.cross_q4 == 6) rc = launch_cross_q4<bf16s_t, 2, 1, true>(cp, n_groups, S, st);   // A/B: two stages (32 KB, five workgroups per CU)
-      else rc = nt_on ? launch_cross_q4<bf16s_t, 3, 1, true>(cp, n_groups, S, st) : launch_cross_q4<bf16s_t, 3, 1, false>(cp, n_groups, S, st);
+      else if (cx.cross_q4 == 6) rc = launch_cross_q4<bf16s_t, 3, 1, true>(cp, n_groups, S, st);   // A/B: three stages (48 KB, three workgroups per CU)
+      else rc = nt_on ? launch_cross_q4<bf16s_t, 2, 1, true>(cp, n_groups, S, st) : launch_cross_q4<bf16s_t, 2, 1, false>(cp, n_groups, S, st);   // two stages: 32 KB, five workgroups per CU
     }
     else if (qt == 1) rc = nt_on ? launch_cross_t<bf16s_t, 1, 2, true>(cp, n_groups, S, st) : launch_cross_t<bf16s_t, 1, 2>(cp, n_groups, S, st);
     else if (qt == 2) rc = launch_cross_t<bf16s_t, 2, 2>(cp, n_groups, S, st);
@@ -1382,9 +1383,12 @@ int launch_cross(CrossP cp, int n_groups, int dtype, int S, int qt, hipStream_t 
     switch (cx.cross_q4) {
       case 2: rc = f ? launch_cross_q4<float, 8, 1, false>(cp, n_groups, S, st) : launch_cross_q4<bf16_t, 8, 1, false>(cp, n_groups, S, st); break;    // one block per step (round-2 start)
       case 4: rc = f ? launch_cross_q4<float, 8, 2, false>(cp, n_groups, S, st) : launch_cross_q4<bf16_t, 8, 2, false>(cp, n_groups, S, st); break;    // A/B: chunks with temporal loads (an 80 KB ring, 4 chunks ahead, measured equal: r02y)
+      case 5: rc = f ? launch_cross_q4<float, 6, 2, true>(cp, n_groups, S, st) : launch_cross_q4<bf16_t, 8, 2, true>(cp, n_groups, S, st); break;      // A/B (round 4): fp32 48 KB ring; bf16: the 64 KB ring of rounds 2-3
+      case 6: rc = f ? launch_cross_q4<float, 4, 1, true>(cp, n_groups, S, st) : launch_cross_q4<bf16_t, 4, 1, true>(cp, n_groups, S, st); break;      // A/B (round 4): 32 KB ring of one-block stages, five workgroups per CU
       default:
+        // round 4: the bf16 ring at 48 KB (three workgroups per CU) 223.8 vs 230.8 us at 64 KB per 160 images (profiles/r04i_*)
         if (f) rc = nt ? launch_cross_q4<float, 8, 2, true>(cp, n_groups, S, st) : launch_cross_q4<float, 8, 2, false>(cp, n_groups, S, st);
-        else rc = nt ? launch_cross_q4<bf16_t, 8, 2, true>(cp, n_groups, S, st) : launch_cross_q4<bf16_t, 8, 2, false>(cp, n_groups, S, st);
+        else rc = nt ? launch_cross_q4<bf16_t, 6, 2, true>(cp, n_groups, S, st) : launch_cross_q4<bf16_t, 8, 2, false>(cp, n_groups, S, st);
     }
   }
   else if (qt == 1) rc = f ? launch_cross_t<float, 1, 4>(cp, n_groups, S, st) : ((cx.cross_nt == 1 || (cx.cross_nt == 2 && n_groups >= 32)) ? launch_cross_t<bf16_t, 1, 4, true>(cp, n_groups, S, st) : launch_cross_t<bf16_t, 1, 4>(cp, n_groups, S, st));

@@ -546,7 +546,7 @@ def check_cross_attn_split():
         gd = torch.tensor(groups, dtype=torch.int32, device=DEV)
         km = kmask.to(torch.uint8).to(DEV) if masked else None
         for S in (1, 2, 8):
-            # qt == 4: the LDS-ring kernel in every built geometry (1: three one-block stages, 5: four, 6: two, 4: eight stages in 64-key
+            # qt == 4: the LDS-ring kernel in every built geometry (1: two one-block stages, 5: four, 6: three, 4: eight stages in 64-key
             # chunks) and the register-streaming kernel (0)
             for ring in ((1, 4, 5, 6, 0) if qt == 4 else (1,)):
                 ops.cross_q4(ring)

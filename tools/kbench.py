@@ -84,7 +84,7 @@ def bench_cross128(dtype=torch.bfloat16):
         alg = I * 2 * M * d * 2 + 2 * R * d * 2
         for S in splits:
             partial = torch.empty(R, nH, S, 68, device=DEV)
-            for nt in ((0, 1) if rows_per_img == 1 else (2, 4, 1)):   # 64 rows: nt column = q4 mode (2 = block per step, 4 = 64-key chunks, 1 = + non-temporal DMA)
+            for nt in ((0, 1) if rows_per_img == 1 else (2, 4, 1, 5, 6)):   # 64 rows: nt column = q4 mode (2 = block per step, 4 = 64-key chunks, 1 = + non-temporal DMA)
                 if rows_per_img == 1:
                     h.omp_debug_cross_nt(nt)
                 else:
