@@ -447,6 +447,208 @@ __global__ __launch_bounds__(256, (EXPB && sizeof(T) == 2) ? 4 : 2) void swin_at
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// fp32-grade window attention on the bf16 matrix cores (round 4, the parity engine): fp32 q / k / v in, every operand split
+// x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits) and both products run as three bf16 MFMAs --
+//   S^T = K_hi Q_hi^T + K_lo Q_hi^T + K_hi Q_lo^T,   O^T = V^T_hi P_hi + V^T_lo P_hi + V^T_hi P_lo
+// (the lo x lo terms are 2^-16 relative).  swin_attn_mfma_kernel<float> spends 256 fp32 matrix-core instructions of 32 cycles per
+// (window, head) and is paced by them (400 us per stage-2 launch of 32 images against 206 us for the bf16 kernel,
+// profiles/r04a_kernel_shapes_parity_engine_graph0.txt); this one issues 96 of 16 cycles.  Same decomposition, index arithmetic,
+// expanded bias, base-2 softmax and mask handling as swin_attn_mfma_kernel<bf16_t, true>; fp32 or split-pair rows out.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void swin_attn_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                              const float* __restrict__ bias_exp, float* __restrict__ out, int B, int H,
+                                                              int W, int C, int nH, int shift, int nWy, int nWx, int out_split) {
+  typedef Mma<bf16_t> MM;
+  typedef SwinTraits<bf16_t> ST;
+  typedef bf16x8 frag;
+  constexpr int VP = ST::VP;
+  __shared__ __attribute__((aligned(16))) bf16_t vt[4][2][HD * VP];   // per wave: V^T hi / lo planes [32 dims][64 key slots (+pad)]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y * 4 + wave;
+  if (head >= nH) return;
+  int widx = blockIdx.x;
+  const int wx = widx % nWx; widx /= nWx;
+  const int wy = widx % nWy;
+  const int b = widx / nWy;
+  const int Hp = nWy * WS, Wp = nWx * WS;
+  const int C3 = 3 * C;
+  bf16_t* vh = vt[wave][0];
+  bf16_t* vl = vt[wave][1];
+
+  auto token_of = [&](int t, int& sy, int& sx) -> int64_t {
+    const int ty = (t * 37) >> 8, tx = t - ty * WS;
+    sy = wy * WS + ty; sx = wx * WS + tx;
+    int py = sy + shift, px = sx + shift;
+    if (py >= Hp) py -= Hp;
+    if (px >= Wp) px -= Wp;
+    return (py < H && px < W) ? ((int64_t)b * H + py) * W + px : (int64_t)-1;
+  };
+  const int sy_hi = wy * WS + WS - 1 + shift, sx_hi = wx * WS + WS - 1 + shift;
+  const bool all_real = (sy_hi < Hp ? sy_hi : Hp - 1) < H && (sx_hi < Wp ? sx_hi : Wp - 1) < W;
+  // 8 fp32 values of q (sel 0) / k (1) / v (2) of token tok at head dims [d0, d0 + 8)
+  auto load8 = [&](int64_t tok, int sel, int d0, float* v) {
+    const float* src = qkv + (tok >= 0 ? tok : 0) * C3 + sel * C + head * HD + d0;
+    unpack16(ld16<float>(src), v);
+    unpack16(ld16<float>(src + 4), v + 4);
+    if (!all_real) {
+      if (tok < 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = qkv_bias[sel * C + head * HD + d0 + i];
+      }
+    }
+  };
+  auto split8 = [](const float* v, frag& hi, frag& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { hi[i] = (bf16_t)v[i]; lo[i] = (bf16_t)(v[i] - (float)hi[i]); }
+  };
+
+  // ---- q / k fragments of the four 16-token tiles: lane (token li, dims 8 g .. 8 g + 7) ------------------------------
+  frag qh[4], ql[4], kh[4], kl[4];
+  int64_t qtok[4];
+  int qsy[4], qsx[4];
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4) {
+    int i = t4 * 16 + li; if (i > WT - 1) i = WT - 1;
+    int sy, sx;
+    const int64_t tok = token_of(i, sy, sx);
+    qtok[t4] = (t4 * 16 + li < WT) ? tok : (int64_t)-1;
+    qsy[t4] = sy; qsx[t4] = sx;
+    float t[8];
+    load8(tok, 0, g * 8, t);
+    split8(t, qh[t4], ql[t4]);
+    load8(tok, 1, g * 8, t);
+    split8(t, kh[t4], kl[t4]);
+  }
+  // ---- V^T -> LDS (both planes): lane (key = it * 16 + lane / 4, dims 8 (lane % 4) ..) ------------------------------
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int j = it * 16 + (lane >> 2), dc = lane & 3;
+    float t[8];
+    if (j < WT) {
+      int sy, sx;
+      load8(token_of(j, sy, sx), 2, dc * 8, t);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = 0.f;   // padded key slots must be finite: P = 0 there
+    }
+    const int pos = ST::slot(j);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bf16_t hi = (bf16_t)t[e];
+      vh[(dc * 8 + e) * VP + pos] = hi;
+      vl[(dc * 8 + e) * VP + pos] = (bf16_t)(t[e] - (float)hi);
+    }
+  }
+  const float* be = bias_exp + (int64_t)head * 4096 + li * 64 + g * 4;   // [query][key] of this head
+  f32x4 bnext[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) bnext[kt] = *reinterpret_cast<const f32x4*>(be + kt * 16);
+
+  const float scale2 = 0.17677669529663687f * 1.4426950408889634f;   // 32^-0.5 * log2(e): base-2 softmax
+  const bool edge = shift > 0 && (wy == nWy - 1 || wx == nWx - 1);
+  int krid[16];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = kt * 16 + g * 4 + r;
+      const int ty = (j * 37) >> 8, tx = j - ty * WS;
+      int rid = 0;
+      if (edge) {
+        const int ssy = wy * WS + ty, ssx = wx * WS + tx;
+        const int ry = ssy < Hp - WS ? 0 : (ssy < Hp - shift ? 1 : 2);
+        const int rx = ssx < Wp - WS ? 0 : (ssx < Wp - shift ? 1 : 2);
+        rid = ry * 3 + rx;
+      }
+      krid[kt * 4 + r] = rid;
+    }
+
+  f32x4 oacc[2][4];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) oacc[dt][t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's V^T stores have landed (own data only)
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4) {
+    int rid_i = 0;
+    if (edge) {
+      const int ry = qsy[t4] < Hp - WS ? 0 : (qsy[t4] < Hp - shift ? 1 : 2);
+      const int rx = qsx[t4] < Wp - WS ? 0 : (qsx[t4] < Wp - shift ? 1 : 2);
+      rid_i = ry * 3 + rx;
+    }
+    float sc[16];
+    float mx = -INFINITY;
+    f32x4 bcur[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) bcur[kt] = bnext[kt];
+    if (t4 < 3) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) bnext[kt] = *reinterpret_cast<const f32x4*>(be + (t4 + 1) * 16 * 64 + kt * 16);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 st = bcur[kt];
+      MM::mma(st, kl[kt], qh[t4]);
+      MM::mma(st, kh[kt], ql[t4]);
+      MM::mma(st, kh[kt], qh[t4]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = st[r] * scale2;   // (q.k + bias / scale) * scale * log2 e; padding keys are -inf through the seed
+        if (edge && krid[kt * 4 + r] != rid_i) a += -100.0f * 1.4426950408889634f;
+        sc[kt * 4 + r] = a;
+        mx = fmaxf(mx, a);
+      }
+    }
+    mx = quad_group_max(mx);
+    float l = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { sc[k] = __builtin_amdgcn_exp2f(sc[k] - mx); l += sc[k]; }
+    l = quad_group_sum(l);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sc[k] *= inv;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {   // 32 keys per step
+      frag ph, pl;
+      split8(sc + ps * 8, ph, pl);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int off = (dt * 16 + li) * VP + ps * 32 + g * 8;
+        const frag vfh = *reinterpret_cast<const frag*>(vh + off);
+        const frag vfl = *reinterpret_cast<const frag*>(vl + off);
+        MM::mma(oacc[dt][t4], vfl, ph);
+        MM::mma(oacc[dt][t4], vfh, pl);
+        MM::mma(oacc[dt][t4], vfh, ph);
+      }
+    }
+  }
+
+  // ---- store: acc[r] <-> (dim = dt*16 + 4g + r, query = t4*16 + li) -----------------------------------
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4) {
+    if (qtok[t4] >= 0) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const f32x4 o = oacc[dt][t4];
+        if (out_split) {
+          bf16_t* ds = reinterpret_cast<bf16_t*>(out) + qtok[t4] * 2 * C + head * HD + g * 4 + dt * 16;
+          bf16x4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)o[e]; lo[e] = (bf16_t)(o[e] - (float)hi[e]); }
+          *reinterpret_cast<bf16x4*>(ds) = hi;
+          *reinterpret_cast<bf16x4*>(ds + C) = lo;
+        } else {
+          *reinterpret_cast<f32x4*>(out + qtok[t4] * C + head * HD + g * 4 + dt * 16) = o;
+        }
+      }
+    }
+  }
+}
+
 // relative_position_bias_table [169, nH] -> per head [64 queries][64 keys] fp32: bias[(dy + 6) * 13 + (dx + 6)] / scale for
 // real tokens, -inf for the 15 padding key slots, 0 for padding query rows (never stored)
 __global__ __launch_bounds__(256) void swin_expand_bias_kernel(const float* __restrict__ table, float* __restrict__ out, int nH) {
@@ -505,7 +707,13 @@ extern "C" int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, con
     const bool expb = bias_expanded != nullptr && swin_impl != 2;
     OMP_CHECK_ARG(expb || rel_bias_table != nullptr, "omp_swin_window_attn: the table form of the bias is needed for this path");
     const float* tb = expb ? bias_expanded : rel_bias_table;
-    if (dtype == OMP_F32) {
+    if (dtype == OMP_F32 && expb && out_split && swin_impl != 3) {
+      // the parity engine's call (fp32 qkv from a bf16x3 product, split-pair rows for the next one): three bf16 MFMAs per product
+      // instead of fp32 ones (swin_attn_x3_kernel); selector 3 keeps the fp32 matrix-core kernel for A/B
+      hipLaunchKernelGGL(swin_attn_x3_kernel, grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, 1);
+    } else if (dtype == OMP_F32 && expb && swin_impl == 4) {   // development: the same kernel with fp32 rows out (tests compare it with the reference)
+      hipLaunchKernelGGL(swin_attn_x3_kernel, grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, out_split);
+    } else if (dtype == OMP_F32) {
       if (expb) hipLaunchKernelGGL((swin_attn_mfma_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, out_split);
       else hipLaunchKernelGGL((swin_attn_mfma_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, out_split);
     } else {
@@ -518,6 +726,6 @@ extern "C" int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, con
 }
 
 extern "C" int omp_debug_swin_attn_impl(int which) {
-  omp_cur().swin_impl = (which == 1 || which == 2) ? which : 0;
+  omp_cur().swin_impl = (which >= 1 && which <= 4) ? which : 0;   // 3: fp32 matrix cores also for split-pair output, 4: the split-product kernel also for fp32 output
   return OMP_OK;
 }

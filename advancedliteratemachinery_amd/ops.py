@@ -436,7 +436,9 @@ def dec_fused(mode):
 
 
 def swin_attn_impl(which):
-    """debug/testing: 0 = matrix-core window attention (default), 1 = scalar cross-check kernel, 2 = matrix cores with table lookups."""
+    """debug/testing: 0 = matrix-core window attention (default), 1 = scalar cross-check kernel, 2 = matrix cores with table lookups,
+    3 = fp32 matrix cores also for split-pair output (the parity engine's call otherwise runs three bf16 products of split operands),
+    4 = that split-product kernel also for fp32 output."""
     _lib.check(_lib.lib().omp_debug_swin_attn_impl(which), 'omp_debug_swin_attn_impl')
 
 

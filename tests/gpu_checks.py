@@ -1343,17 +1343,42 @@ def check_gemm_4w():
 
 
 def check_window_attn_split():
-    """fp32 window attention writing split pairs == its own fp32 output split (the proj GEMM's bf16x3 operand)."""
+    """fp32 window attention writing split pairs (the proj GEMM's bf16x3 operand).  Round 4: that call runs on the bf16 matrix cores as
+    three products of split operands per QK^T / PV (swin_attn_x3_kernel): (a) against the oracle's window attention on every shape of
+    check_window_attn incl. padded windows, SW-MSA masks and Swin-T's 3 heads (selector 4 = the same kernel with fp32 rows out), under
+    the fp32 gate; (b) its split-pair output = hi + lo of its own fp32 output; (c) selector 3 = the fp32 matrix-core kernel, whose
+    split output is the split of its fp32 output bit for bit."""
     out = []
+    for (B, H, W, C, nH) in ((2, 10, 13, 128, 4), (1, 14, 14, 256, 8), (2, 5, 7, 1024, 32), (1, 20, 9, 512, 16), (1, 3, 30, 96, 3)):
+        for shift in (0, 3):
+            x = rnd(B, H, W, C, seed=C + shift)
+            Wqkv = rnd(3 * C, C, seed=1) / math.sqrt(C) * 2
+            bqkv, table = rnd(3 * C, seed=2) * 0.3, rnd(169, nH, seed=3) * 0.5
+            qkv_in = x.reshape(-1, C) @ Wqkv.t() + bqkv
+            ref = _ref_window_attention_from_qkv(qkv_in.reshape(B, H, W, 3 * C), bqkv, table, nH, shift)
+            bexp = ops.swin_expand_bias(table.to(DEV))
+            ops.swin_attn_impl(4)
+            y = ops.swin_window_attn(qkv_in.to(DEV), bqkv.to(DEV), table.to(DEV), B, H, W, C, nH, shift, bias_expanded=bexp)
+            ops.swin_attn_impl(0)
+            ys = ops.swin_window_attn(qkv_in.to(DEV), bqkv.to(DEV), table.to(DEV), B, H, W, C, nH, shift, bias_expanded=bexp, out_split=True)
+            tag = 'B%d %dx%d C%d shift%d' % (B, H, W, C, shift)
+            # three-product precision: operands carry 16 mantissa bits (2^-17 relative each) and the scores reach |s| ~ 20 on this data, so the
+            # gate is relative to the output scale -- 5e-5 of max|ref| (measured 1.7-2.3e-5; the fp32 matrix-core kernel: 2e-6)
+            out.append(rec('window_attn[split products,%s] vs oracle' % tag, maxerr(y.reshape(B, H, W, C), ref), 5e-5 * max(1.0, ref.abs().max().item()),
+                           'max|ref|=%.1f' % ref.abs().max().item()))
+            hi, lo = _split_ref(y.cpu())
+            out.append(rec('window_attn[split products,%s] pair rows == split of the fp32 rows' % tag, max(maxerr(ys[:, :C], hi), maxerr(ys[:, C:], lo)), 0.0))
     B, H, W, C, nH = 2, 17, 20, 128, 4
     qkv = rnd(B * H * W, 3 * C, seed=21).to(DEV)
     qb, table = rnd(3 * C, seed=22).to(DEV), (rnd(169, nH, seed=23) * 0.2).to(DEV)
     be = ops.swin_expand_bias(table)
+    ops.swin_attn_impl(3)
     for shift in (0, 3):
         ref = ops.swin_window_attn(qkv, qb, table, B, H, W, C, nH, shift, bias_expanded=be).cpu()
         ys = ops.swin_window_attn(qkv, qb, table, B, H, W, C, nH, shift, bias_expanded=be, out_split=True)
         hi, lo = _split_ref(ref)
-        out.append(rec('window_attn[f32->split,shift %d]' % shift, max(maxerr(ys[:, :C], hi), maxerr(ys[:, C:], lo)), 0.0))
+        out.append(rec('window_attn[f32 matrix cores -> split,shift %d]' % shift, max(maxerr(ys[:, :C], hi), maxerr(ys[:, C:], lo)), 0.0))
+    ops.swin_attn_impl(0)
     return out
 
 
