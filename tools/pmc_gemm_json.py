@@ -24,7 +24,7 @@ def totals(path, pred):
 def main():
     fetch, write, alg = sys.argv[1], sys.argv[2], json.load(open(sys.argv[3]))
     out = {}
-    for name, pred in (('gemm', lambda l: 'gemm_256' in l or ('gemm_dma' in l and 'Li128ELi128E' in l) or 'gemm_dma<' in l and '128, 128' in l),
+    for name, pred in (('gemm', lambda l: 'gemm_256' in l or 'gemm_4w' in l or ('gemm_dma' in l and 'Li128ELi128E' in l) or 'gemm_dma<' in l and '128, 128' in l),
                        ('gemm_slab_epilogues', lambda l: 'gemm_256' in l and ('Li2E' in l or 'Li3E' in l or ', 2, ' in l or ', 3, ' in l)),
                        ('mlp_fused', lambda l: 'mlp_fused_kernel' in l)):
         nf, tf = totals(fetch, pred)
