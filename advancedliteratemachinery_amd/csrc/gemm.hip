@@ -777,9 +777,10 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
   }
   if (which == 5) {
     // bench.py's matrix-core roofline leg: hipEvent bracket + flop count of the large-M GEMMs
-    const int slot = omp_prof_active(OMP_PROF_GEMM) ? omp_prof_begin(OMP_PROF_GEMM, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
+    const int pcls = p.M >= 32768 ? OMP_PROF_GEMM : OMP_PROF_GEMM_DEC;
+    const int slot = omp_prof_active(pcls) ? omp_prof_begin(pcls, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
     int rc = launch_dma<T, TOut, 128, 128, 2>(p, st);
-    if (slot >= 0) omp_prof_end(OMP_PROF_GEMM, slot, st);
+    if (slot >= 0) omp_prof_end(pcls, slot, st);
     if (rc != OMP_OK) return rc;
   } else if (which == 6) {
     // mid-size problems (decoder phases with 65..~4000 rows, small-image encoders): 64x64 tiles and a deep
@@ -794,9 +795,10 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
         omp_set_error("omp_gemm_bias_act: selector 9 (256x256 tiles) needs bf16 operands, K %% 64 == 0, K >= 128, N %% 8 == 0 (blocked K / V^T slabs: bf16 only)");
         return OMP_ERR_UNSUPPORTED;
       }
-      const int slot = omp_prof_active(OMP_PROF_GEMM) ? omp_prof_begin(OMP_PROF_GEMM, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
+      const int pcls = p.M >= 32768 ? OMP_PROF_GEMM : OMP_PROF_GEMM_DEC;
+    const int slot = omp_prof_active(pcls) ? omp_prof_begin(pcls, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
       int rc = launch_256<TOut>(p, st);
-      if (slot >= 0) omp_prof_end(OMP_PROF_GEMM, slot, st);
+      if (slot >= 0) omp_prof_end(pcls, slot, st);
       if (rc != OMP_OK) return rc;
     } else {
       omp_set_error("omp_gemm_bias_act: selector 9 (256x256 tiles) is bf16-only");
@@ -808,9 +810,10 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
         omp_set_error("omp_gemm_bias_act: selector %d (256x256 tiles on four waves) takes the shapes of selector 9", which);
         return OMP_ERR_UNSUPPORTED;
       }
-      const int slot = omp_prof_active(OMP_PROF_GEMM) ? omp_prof_begin(OMP_PROF_GEMM, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
+      const int pcls = p.M >= 32768 ? OMP_PROF_GEMM : OMP_PROF_GEMM_DEC;
+    const int slot = omp_prof_active(pcls) ? omp_prof_begin(pcls, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
       int rc = launch_4w<TOut, 5>(p, st);
-      if (slot >= 0) omp_prof_end(OMP_PROF_GEMM, slot, st);
+      if (slot >= 0) omp_prof_end(pcls, slot, st);
       if (rc != OMP_OK) return rc;
     } else {
       omp_set_error("omp_gemm_bias_act: selector %d (256x256 tiles on four waves) is bf16-only", which);

@@ -24,9 +24,9 @@ int omp_stream_destroy(omp_stream_t s);
 int omp_debug_where(int32_t* out, int n_workgroups, omp_stream_t s);
 
 /* Measurement hooks (bench.py roofline legs): hipEvent-bracket every EAGERLY launched kernel of a class on its launch
- * stream.  Classes (bit c of `mask`): 0 = decoder cross-attention kernels, 1 = large-M GEMMs (gemm_dma 128x128),
- * 2 = fused Swin MLP.  omp_prof_read_class returns total milliseconds, launch count and the summed work of the
- * bracketed launches (flops for classes 1 and 2; 0 for class 0, whose bytes the caller computes).  omp_prof_read =
+ * stream.  Classes (bit c of `mask`): 0 = decoder cross-attention kernels, 1 = large GEMMs of the encoder (gemm_256 / gemm_4w /
+ * gemm_dma 128x128 at M >= 32768 rows), 2 = fused Swin MLP, 3 = the same GEMM kernels on decoder-phase rows (M < 32768; round 4).  omp_prof_read_class returns total milliseconds, launch count and the summed work of the
+ * bracketed launches (flops for classes 1, 2 and 3; 0 for class 0, whose bytes the caller computes).  omp_prof_read =
  * class 0 (kept for round-1 callers). */
 int omp_prof_enable(int mask);
 int omp_prof_read(double* total_ms, int64_t* count);

@@ -737,7 +737,7 @@ def main():
         with torch.cuda.stream(stream):
             run_group(0, G, model=mdl)
             torch.cuda.synchronize()
-            h.omp_prof_enable(7)
+            h.omp_prof_enable(15)
             for i in range(n_groups):
                 run_group(i * G, G, model=mdl)
             torch.cuda.synchronize()
@@ -753,7 +753,8 @@ def main():
         t_cross, n_cross, _ = read(0)
         t_gemm, n_gemm, f_gemm = read(1)
         t_mlp, n_mlp, f_mlp = read(2)
-        (b_gemm, r_gemm), (b_mlp, r_mlp) = read_roof(1), read_roof(2)
+        t_gd, n_gd, f_gd = read(3)   # the same GEMM kernels on decoder-phase rows (M < 32768: the 10240-row polygon / recognition products)
+        (b_gemm, r_gemm), (b_mlp, r_mlp), (b_gd, r_gd) = read_roof(1), read_roof(2), read_roof(3)
         h.omp_prof_enable(0)
         mdl.use_graph = was
         M = (a.size // 16) ** 2
@@ -763,7 +764,7 @@ def main():
         if n_gemm:
             tf = f_gemm / (t_gemm / 1e3) / 1e12
             gt = pmc_gemm_traffic(a.size, dtype_name)
-            grec = dict(bound='mfma', kernel='gemm_256 + gemm_dma<128,128,2> (Swin qkv / proj / fc1 / fc2 / merge, FPN, input_proj, K-V projection)',
+            grec = dict(bound='mfma', kernel='gemm_256 + gemm_dma<128,128,2> + gemm_4w at M >= 32768 rows (Swin qkv / proj / fc1 / fc2 / merge, FPN, input_proj, K-V projection)',
                         achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=gt[0] if gt else None,
                         launches=int(n_gemm), avg_us=t_gemm / n_gemm * 1e3, flops_per_launch=f_gemm / n_gemm,
                         gpu_ms_per_image=t_gemm / (n_groups * BI))
@@ -776,6 +777,13 @@ def main():
                 grec['traffic_scope'] = ('HBM bytes per GEMM launch of one 32-image encoder chunk + its K / V^T projection (profiles/pmc_gemm.json); '
                                          'the decoder-phase GEMMs of this class are not in that pass')
             recs.append((t_gemm, grec))
+        if n_gd:
+            tf = f_gd / (t_gd / 1e3) / 1e12
+            recs.append((t_gd, dict(bound='mfma', kernel='gemm_256 / gemm_dma<128,128,2> on decoder-phase rows (M < 32768: the many-row polygon / recognition steps; '
+                                                        'on the unbracketed 64x64 kernel until round 4)',
+                                    achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None, launches=int(n_gd),
+                                    avg_us=t_gd / n_gd * 1e3, flops_per_launch=f_gd / n_gd, alg_bytes_per_launch=b_gd / n_gd,
+                                    frac_of_launch_rooflines=r_gd / (t_gd / 1e3), gpu_ms_per_image=t_gd / (n_groups * BI))))
         if n_mlp:
             tf = f_mlp / (t_mlp / 1e3) / 1e12
             recs.append((t_mlp, dict(bound='mfma', kernel='mlp_fused_kernel (Swin stages 0/1: LayerNorm + fc1 + GELU + fc2 + residual)',
