@@ -70,3 +70,46 @@ def test_round3_flags_and_host_pinning(monkeypatch):
             assert set(mine).isdisjoint(sorted(before)[:len(before) // 2])
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_split_plane_pmc_record_and_payload_round_trip():
+    """round 4: the parity engine's cross-attention kernels have their own PMC record (`x3_<images>`: 4 bytes per (key, dim) element);
+    the per-call all-gather payload (ids + probability bit patterns + counts in ONE int32 tensor) round-trips exactly."""
+    import torch
+    b = _bench()
+    t = b.pmc_traffic(160, 'x3_')
+    alg = 160 * 2 * 4096 * 512 * 4
+    assert t is not None and 1.0 <= t / alg < 1.03, (t, alg)
+    from advancedliteratemachinery_amd.utils import dist as D
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 1104, (3, 5, 59), generator=g, dtype=torch.int32)
+    pr = torch.rand(3, 5, 25, generator=g)
+    n = torch.tensor([5, 0, 3], dtype=torch.int32)
+    buf = D.pack_payload(ids, pr, n)
+    assert buf.dtype == torch.int32 and buf.shape == (3, 5 * 59 + 5 * 25 + 1)
+    i2, p2, n2 = D.unpack_payload(torch.cat([buf, buf]), ids.shape[1:], pr.shape[1:])
+    assert torch.equal(i2[:3], ids) and torch.equal(p2[3:], pr) and torch.equal(n2[:3], n)
+    i3, p3, n3 = D.unpack_payload(D.pack_payload(ids, pr), ids.shape[1:], pr.shape[1:], with_n=False)
+    assert n3 is None and torch.equal(i3, ids) and torch.equal(p3, pr)
+
+
+def test_gemm4w_register_audit_catches_a_compiler_touch():
+    """tools/audit_gemm4w.py (run by build.py on the device assembly): a compiler-generated v_accvgpr_* / scratch access outside an asm
+    block, a spill count or a short AGPR allocation in a gemm_4w kernel fails the build; the clean form passes."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        import audit_gemm4w
+    finally:
+        sys.path.pop(0)
+    import tempfile
+    clean = ('_ZN1x7gemm_4wIfEEv: ; @k\n\ts_nop 0\n\t;;#ASMSTART\n\tv_accvgpr_write_b32 a[0], 0\n\t;;#ASMEND\n\tv_mov_b32 v0, v1\n\ts_endpgm\n'
+             '  - .name:           _ZN1x7gemm_4wIfEEv\n    .agpr_count:     256\n    .private_segment_fixed_size: 0\n    .vgpr_spill_count: 0\n    .wavefront_size: 64\n')
+    for text, n_bad in ((clean, 0), (clean.replace('\tv_mov_b32 v0, v1', '\tv_accvgpr_read_b32 v0, a3'), 1),
+                        (clean.replace('.vgpr_spill_count: 0', '.vgpr_spill_count: 12'), 1), (clean.replace('.agpr_count:     256', '.agpr_count:     128'), 1)):
+        with tempfile.NamedTemporaryFile('w', suffix='.s', delete=False) as f:
+            f.write(text)
+        try:
+            seen, bad = audit_gemm4w.audit(f.name)
+        finally:
+            os.unlink(f.name)
+        assert seen == 1 and len(bad) == n_bad, (seen, bad)

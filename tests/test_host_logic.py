@@ -557,3 +557,26 @@ def test_swin_block256_tile_layout_identities():
                     for dt in range(2):
                         q, ch = t4 * 16 + li, h * 32 + dt * 16 + 4 * g
                         assert t4 * 8192 + off[dt] == sw_off(q, ch >> 3) + ((ch >> 2) & 1) * 8
+
+
+def test_split_plane_slab_indexing_is_a_bijection():
+    """Round 4, the parity engine's K / V^T slabs: every 32-key block of an (image, head) slab is
+    [hi plane | lo plane]; the element of key k, dim d, plane p sits at ((k // 32) * 2 + p) * 2048 + (k % 32) * 64 + d (K) and at
+    ((k // 32) * 2 + p) * 2048 + d * 32 + slot(k % 32) (V^T, slot = the bf16 slab's matrix-core order) -- the formulas the GEMM
+    epilogues (csrc/gemm.hip::store4, gemm256.inc, gemm4w.inc) and the cross-attention kernels (csrc/decoder.hip, bf16s_t) share.
+    Both maps are bijections onto the slab and a value survives hi + lo to 2^-16 relative."""
+    import numpy as np
+    Mpad = 96
+    k, d, p = np.meshgrid(np.arange(Mpad), np.arange(64), np.arange(2), indexing='ij')
+    ik = ((k // 32) * 2 + p) * 2048 + (k % 32) * 64 + d
+    kl = k % 32
+    slot = ((kl & 15) >> 2) * 8 + (kl >> 4) * 4 + (kl & 3)
+    iv = ((k // 32) * 2 + p) * 2048 + d * 32 + slot
+    for idx in (ik, iv):
+        assert sorted(idx.reshape(-1).tolist()) == list(range(Mpad * 128))
+    import torch
+    x = torch.randn(4096) * 3
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    rel = ((hi.float() + lo.float() - x).abs() / x.abs().clamp_min(1e-30)).max().item()
+    assert rel <= 2.0 ** -16
