@@ -12,6 +12,8 @@ Return value per image (reference transformer.py:240-246,286):
   KIE           : list of (text, class_name, prob, [rects])
   no points     : None
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -54,7 +56,8 @@ class OmniParser(nn.Module):
         self._engine_key = None
         self.use_graph = True          # decoder steps replay as hipGraphs when run on a non-default stream
         self.overlap_decoders = True   # polygon || recognition decoders on two streams
-        self.enc_chunk = 32            # images per encoder pass inside one engine call (see _encode_chunked)
+        # images per encoder pass inside one engine call (see _encode_chunked); OMP355_ENC_CHUNK is the A/B knob of the sweep
+        self.enc_chunk = int(os.environ.get('OMP355_ENC_CHUNK', '32'))
         self._streams = None
         self.phase_events = None       # set to [] to collect (name, torch.cuda.Event) marks per infer()
         self.eval()
