@@ -17,6 +17,7 @@
 // are 8/16-byte vectors instead of 4 scalar stores.
 #include <type_traits>
 
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -505,6 +506,8 @@ int launch_dma(GemmP& p, hipStream_t st) {
 
 #include "gemm256.inc"
 #include "gemm4w.inc"
+#include "gemm4wr.inc"
+#include "gemm4wp.inc"
 
 template <typename T, typename TOut>
 __global__ __launch_bounds__(256) void gemm_rows(GemmP p) {
@@ -769,9 +772,17 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
       // equal within the box-to-box spread on most, 7-13 % faster on the half-million-row products of stage 1 without an activation,
       // 7-13 % slower behind a GELU epilogue (four waves instead of eight do the vector work) -- it takes the former
       if (which == 9 && p.act == OMP_ACT_NONE && p.store_mode == OMP_STORE_PLAIN && p.M >= 262144 && (p.K >= 1024 || p.N >= 768)) which = 10;
+      // the persistent four-wave kernel (gemm4wp.inc; same bits again) where its register-only epilogue and its missing prologues pay
+      // (profiles/r04s_kbench_gemm_4w_p_*.txt, r04v_kbench_ab_k9_k20.txt: three boxes): behind a GELU on a bf16 destination (+9 % at
+      // K = 512, +3-13 % at K = 768, +23-30 % at K = 256, equal at K = 1024) and on the K = 768 products without a residual (ViT-B qkv
+      // +7 %, the bf16x3 stage-1 qkv +7 % over gemm_4w); equal or behind gemm_256 elsewhere (K = 256 without GELU: +12 % on one box,
+      // -7 % on another; long K: the operand stream paces both kernels)
+      if ((which == 9 || which == 10) && !p.split_out && gemm4wp_ok(p, true, std::is_same<TOut, bf16_t>::value) &&
+          ((p.act == OMP_ACT_GELU && std::is_same<TOut, bf16_t>::value) || (p.K == 768 && p.residual == nullptr && p.N >= 768 && p.act == OMP_ACT_NONE)))
+        which = 20;
     }
   }
-  if (p.C2 != nullptr && which != 5 && which != 6 && which != 9 && which != 10 && which != 11 && which != 15) {
+  if (p.C2 != nullptr && which != 5 && which != 6 && which != 9 && which != 10 && which != 11 && which != 15 && which != 16 && which != 18 && which != 20 && which != 21) {
     omp_set_error("omp_gemm_bias_act: kernel selector %d has no second destination (C2)", which);
     return OMP_ERR_UNSUPPORTED;
   }
@@ -827,6 +838,54 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
       if (rc != OMP_OK) return rc;
     } else {
       omp_set_error("omp_gemm_bias_act: selectors 12..14 take plain bf16 products");
+      return OMP_ERR_UNSUPPORTED;
+    }
+  } else if (which >= 16 && which <= 18) {   // 256x256 tiles on four waves, weights streamed into registers (gemm4wr.inc); 17: without its MFMAs (wrong results, valid timing)
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (!gemm4wr_ok(p, true, std::is_same<TOut, bf16_t>::value)) {
+        omp_set_error("omp_gemm_bias_act: selector %d (register-streamed weights) takes row-major destinations of selector 9 with K %% 256 == 0", which);
+        return OMP_ERR_UNSUPPORTED;
+      }
+      const int pcls = p.M >= 32768 ? OMP_PROF_GEMM : OMP_PROF_GEMM_DEC;
+      const int slot = omp_prof_active(pcls) ? omp_prof_begin(pcls, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
+      int rc = OMP_OK;
+      if (which == 16) rc = launch_4wr<TOut>(p, st);
+      else if (which == 18) {   // development: per-workgroup phase timestamps (tools/gemm4wr_trace.py)
+        if (p.split_out || cx.gemm_trace == nullptr || (long long)ceil_div64(p.M, 256) * ceil_div64(p.N, 256) > cx.gemm_trace_cap) {
+          omp_set_error("omp_gemm_bias_act: selector 18 needs omp_debug_set_gemm_trace(buffer for every 256x256 tile) and a plain destination");
+          return OMP_ERR_INVALID;
+        }
+        p.trace = cx.gemm_trace;
+        rc = launch_4wr_t<TOut, false, 4>(p, st);
+      } else if constexpr (std::is_same<TOut, bf16_t>::value) {
+        if (p.split_out) { omp_set_error("omp_gemm_bias_act: selector 17 takes plain bf16 products"); return OMP_ERR_UNSUPPORTED; }
+        rc = launch_4wr_t<TOut, false, 3>(p, st);
+      } else {
+        omp_set_error("omp_gemm_bias_act: selector 17 takes plain bf16 products");
+        return OMP_ERR_UNSUPPORTED;
+      }
+      if (slot >= 0) omp_prof_end(pcls, slot, st);
+      if (rc != OMP_OK) return rc;
+    } else {
+      omp_set_error("omp_gemm_bias_act: selector %d (register-streamed weights) is bf16-only", which);
+      return OMP_ERR_UNSUPPORTED;
+    }
+  } else if (which == 20 || which == 21) {   // persistent 256x256 tiles on four waves, register-only epilogue (gemm4wp.inc); 21: 2/3 of its operand bytes (wrong results, valid timing)
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (!gemm4wp_ok(p, true, std::is_same<TOut, bf16_t>::value)) {
+        omp_set_error("omp_gemm_bias_act: selector 20 (persistent four-wave tiles) takes row-major destinations with M, N, K multiples of 256 and 16-byte aligned bias / rows");
+        return OMP_ERR_UNSUPPORTED;
+      }
+      const int pcls = p.M >= 32768 ? OMP_PROF_GEMM : OMP_PROF_GEMM_DEC;
+      const int slot = omp_prof_active(pcls) ? omp_prof_begin(pcls, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
+      int rc = OMP_OK;
+      if (which == 20) rc = launch_4wp<TOut>(p, st);
+      else if constexpr (!std::is_same<TOut, bf16_t>::value) rc = launch_4wp_t<TOut, false, 5>(p, st);
+      else { omp_set_error("omp_gemm_bias_act: selector 21 takes fp32 destinations"); return OMP_ERR_UNSUPPORTED; }
+      if (slot >= 0) omp_prof_end(pcls, slot, st);
+      if (rc != OMP_OK) return rc;
+    } else {
+      omp_set_error("omp_gemm_bias_act: selector 20 (persistent four-wave tiles) is bf16-only");
       return OMP_ERR_UNSUPPORTED;
     }
   } else if (which == 15) {          // development: gemm_dma<128,128,2> with per-workgroup phase timestamps

@@ -1262,9 +1262,11 @@ def check_gemm_4w():
         finally:
             ops.force_gemm_kernel(0)
 
-    def same(tag, fn, ref_check=None):
+    def same(tag, fn, ref_check=None, k16=False, k20=False):
         base = run(5, fn)
-        for which in (10, 11):
+        # 16 = gemm_4w_r (weights streamed into registers; row-major, K % 256 == 0); 20 = gemm_4w_p (the same, persistent over tiles,
+        # register-only epilogue; M, N, K multiples of 256)
+        for which in (10, 11) + ((16,) if k16 else ()) + ((20,) if k20 else ()):
             got = run(which, fn)
             for i, (g, b) in enumerate(zip(got, base)):
                 neq = (g.view(torch.int16 if g.dtype == bf else torch.int32) != b.view(torch.int16 if b.dtype == bf else torch.int32)).sum().item()
@@ -1282,28 +1284,52 @@ def check_gemm_4w():
         def chk(base, A=A, W=W, bias=bias, tag=tag):
             ref = A.double().cpu() @ W.double().cpu().t() + bias.double().cpu()
             out.append(rec('gemm_4w[k5 vs fp64, %s]' % tag, (base[0].double().cpu() - ref).abs().max().item(), max(2e-4, ref.abs().max().item() * 2.0 ** -8)))
-        same(tag + ' bias', lambda: (ops.gemm(A, W, bias),), chk if K <= 2048 and M <= 5000 else None)
-        same(tag + ' gelu', lambda: (ops.gemm(A, W, bias, act=ops.ACT_GELU),))
-        same(tag + ' relu + bf16 residual', lambda: (ops.gemm(A, W, bias, residual=rb, act=ops.ACT_RELU),))
-        same(tag + ' f32 out + f32 residual', lambda: (ops.gemm(A, W, bias, residual=rf, out_dtype=torch.float32),))
+        same(tag + ' bias', lambda: (ops.gemm(A, W, bias),), chk if K <= 2048 and M <= 5000 else None, k16=K % 256 == 0)
+        same(tag + ' gelu', lambda: (ops.gemm(A, W, bias, act=ops.ACT_GELU),), k16=K % 256 == 0)
+        same(tag + ' relu + bf16 residual', lambda: (ops.gemm(A, W, bias, residual=rb, act=ops.ACT_RELU),), k16=K % 256 == 0)
+        same(tag + ' f32 out + f32 residual', lambda: (ops.gemm(A, W, bias, residual=rf, out_dtype=torch.float32),), k16=K % 256 == 0)
         if N % 8 == 0:
-            same(tag + ' gelu, split rows', lambda: (ops.gemm(A, W, bias, act=ops.ACT_GELU, out_dtype=ops.SPLIT),))
+            same(tag + ' gelu, split rows', lambda: (ops.gemm(A, W, bias, act=ops.ACT_GELU, out_dtype=ops.SPLIT),), k16=K % 256 == 0)
 
             def two():
                 c2 = torch.empty(M, N, device=DEV, dtype=bf)
                 y = ops.gemm(A, W, bias, residual=rb, out_noresidual=c2)
                 return y, c2
-            same(tag + ' two destinations', two)
+            same(tag + ' two destinations', two, k16=K % 256 == 0)
+    # shapes without ragged edges: the persistent kernel too (one tile per workgroup, several tiles per workgroup, one tile in all)
+    for (M, N, K) in ((256, 256, 256), (1024, 512, 512), (7680, 1536, 2048), (16384, 2048, 256), (8192, 4096, 512), (66560, 768, 1024)):
+        A, W = rnd(M, K, seed=M + 7).to(DEV, bf), (rnd(N, K, seed=N + 8) / math.sqrt(K)).to(DEV, bf)
+        bias = rnd(N, seed=9).to(DEV)
+        rb, rf = rnd(M, N, seed=10).to(DEV, bf), rnd(M, N, seed=11).to(DEV)
+        tag = 'even %dx%dx%d' % (M, N, K)
+        same(tag + ' bias', lambda: (ops.gemm(A, W, bias),), k16=True, k20=True)
+        same(tag + ' no bias', lambda: (ops.gemm(A, W, None),), k16=True, k20=True)
+        same(tag + ' gelu', lambda: (ops.gemm(A, W, bias, act=ops.ACT_GELU),), k16=True, k20=True)
+        same(tag + ' relu + bf16 residual', lambda: (ops.gemm(A, W, bias, residual=rb, act=ops.ACT_RELU),), k16=True, k20=True)
+        same(tag + ' f32 out + f32 residual', lambda: (ops.gemm(A, W, bias, residual=rf, out_dtype=torch.float32),), k16=True, k20=True)
+        same(tag + ' f32 out, gelu', lambda: (ops.gemm(A, W, bias, act=ops.ACT_GELU, out_dtype=torch.float32),), k16=True, k20=True)
+        same(tag + ' gelu, split rows', lambda: (ops.gemm(A, W, bias, act=ops.ACT_GELU, out_dtype=ops.SPLIT),), k16=True, k20=True)
+
+        def two2():
+            c2 = torch.empty(M, N, device=DEV, dtype=bf)
+            y = ops.gemm(A, W, bias, residual=rb, out_noresidual=c2)
+            return y, c2
+        same(tag + ' two destinations', two2, k16=True, k20=True)
+    for (M, N, K) in ((3072, 512, 512), (33280, 1536, 512)):
+        As, W3 = ops.split_bf16(rnd(M, K, seed=M + 1).to(DEV)), ops.split_weight3((rnd(N, K, seed=N + 2) / math.sqrt(K)).to(DEV))
+        bias, rf = rnd(N, seed=3).to(DEV), rnd(M, N, seed=5).to(DEV)
+        same('even x3 %dx%dx%d f32 + residual' % (M, N, 3 * K), lambda: (ops.gemm(As, W3, bias, residual=rf, out_dtype=torch.float32, a_wrap=2 * K),), k16=True, k20=True)
+        same('even x3 %dx%dx%d gelu split' % (M, N, 3 * K), lambda: (ops.gemm(As, W3, bias, act=ops.ACT_GELU, out_dtype=ops.SPLIT, a_wrap=2 * K),), k16=True, k20=True)
     # bf16x3 operands: split-pair A wrapped over [hi | lo | hi]
     for (M, N, K) in ((3000, 512, 512), (1100, 1536, 512), (2049, 256, 1024)):
         As, W3 = ops.split_bf16(rnd(M, K, seed=M).to(DEV)), ops.split_weight3((rnd(N, K, seed=N + 1) / math.sqrt(K)).to(DEV))
         bias, rf = rnd(N, seed=3).to(DEV), rnd(M, N, seed=5).to(DEV)
-        same('x3 %dx%dx%d f32 + residual' % (M, N, 3 * K), lambda: (ops.gemm(As, W3, bias, residual=rf, out_dtype=torch.float32, a_wrap=2 * K),))
-        same('x3 %dx%dx%d gelu split' % (M, N, 3 * K), lambda: (ops.gemm(As, W3, bias, act=ops.ACT_GELU, out_dtype=ops.SPLIT, a_wrap=2 * K),))
+        same('x3 %dx%dx%d f32 + residual' % (M, N, 3 * K), lambda: (ops.gemm(As, W3, bias, residual=rf, out_dtype=torch.float32, a_wrap=2 * K),), k16=(3 * K) % 256 == 0)
+        same('x3 %dx%dx%d gelu split' % (M, N, 3 * K), lambda: (ops.gemm(As, W3, bias, act=ops.ACT_GELU, out_dtype=ops.SPLIT, a_wrap=2 * K),), k16=(3 * K) % 256 == 0)
     # per-position bias table
     Ab, Wb = rnd(1500, 512, seed=21).to(DEV, bf), (rnd(1536, 512, seed=22) / math.sqrt(512)).to(DEV, bf)
     tabb, rowb = rnd(9, 1536, seed=23).to(DEV), torch.tensor([6], dtype=torch.int32, device=DEV)
-    same('bias_row', lambda: (ops.gemm(Ab, Wb, tabb, bias_row=rowb, bias_row_stride=1536),))
+    same('bias_row', lambda: (ops.gemm(Ab, Wb, tabb, bias_row=rowb, bias_row_stride=1536),), k16=True)
     # blocked K / V^T slabs, bf16 and split planes
     nH, d, K = 8, 512, 512
     for (Bn, tok) in ((2, 72), (3, 257), (5, 1000)):

