@@ -24,7 +24,7 @@ int omp_stream_destroy(omp_stream_t s);
 int omp_debug_where(int32_t* out, int n_workgroups, omp_stream_t s);
 
 /* Measurement hooks (bench.py roofline legs): hipEvent-bracket every EAGERLY launched kernel of a class on its launch
- * stream.  Classes (bit c of `mask`): 0 = decoder cross-attention kernels, 1 = large GEMMs of the encoder (gemm_256 / gemm_4w /
+ * stream.  Classes (bit c of `mask`): 0 = decoder cross-attention kernels, 1 = large GEMMs of the encoder (gemm_256 / gemm_4w / gemm_4w_p /
  * gemm_dma 128x128 at M >= 32768 rows), 2 = fused Swin MLP, 3 = the same GEMM kernels on decoder-phase rows (M < 32768; round 4).  omp_prof_read_class returns total milliseconds, launch count and the summed work of the
  * bracketed launches (flops for classes 1, 2 and 3; 0 for class 0, whose bytes the caller computes).  omp_prof_read =
  * class 0 (kept for round-1 callers). */
@@ -34,9 +34,13 @@ int omp_prof_read_class(int cls, double* total_ms, int64_t* count, double* work)
 /* classes 1 and 2: summed algorithmic HBM bytes of the bracketed launches and the sum over launches of
  * max(flops / 2.5 PFLOP/s, bytes / 8 TB/s) -- the time they would take on their own rooflines */
 int omp_prof_read_roofline(int cls, double* bytes, double* roofline_seconds);
+/* GEMM kernel selector: 0 auto; 3 row-streaming; 4 split-K small-M; 5 / 6 DMA 128x128 / 64x64; 9 gemm_256; 10 (= 11) gemm_4w; 16 gemm_4w_r
+ * (weights streamed into registers; K % 256 == 0); 20 gemm_4w_p (the same, persistent over tiles, register-only epilogue; M, N, K
+ * multiples of 256).  Wrong results, valid timing: 12..14 gemm_4w without DMA / fragment reads / MFMAs, 17 gemm_4w_r without MFMAs, 21
+ * gemm_4w_p with 2/3 of its operand bytes.  Traces: 15 gemm_dma<128,128,2>, 18 gemm_4w_r (omp_debug_set_gemm_trace). */
 int omp_debug_force_gemm_kernel(int which);
-/* development: device buffer uint64 [n_workgroups][8] that omp_debug_force_gemm_kernel(15) fills with s_memtime stamps
- * per workgroup: 0 start, 1 first K tile landed, 2 K loop done, 3 accumulators in LDS, 4 stores retired, 5 XCC id */
+/* development: device buffer uint64 [n_workgroups][8] that omp_debug_force_gemm_kernel(15 / 18) fills with s_memtime stamps
+ * per workgroup: 0 start, 1 first K tile landed, 2 K loop done, 3 accumulators in LDS (18: every wave done), 4 stores retired, 5 XCC id */
 int omp_debug_set_gemm_trace(void* buffer, int64_t n_workgroups);
 int omp_debug_swin_attn_impl(int which); /* 0 = matrix-core kernel (default), 1 = scalar cross-check kernel, 2 = matrix cores with per-score table lookups */
 int omp_debug_dec_fused(int mode);       /* 0 = fused few-row decoder step kernels where they apply (default), 1 = one launch per op everywhere (A/B, cross-check) */

@@ -418,8 +418,9 @@ def where_probe(n_workgroups):
 
 
 def force_gemm_kernel(which):
-    """debug/testing: 0 auto, 1 tiled 128x128, 2 tiled 64x64, 3 row-streaming, 4 split-K small-M, 5 DMA 128x128 (2 stages),
-    6 DMA 64x64 ring, 7 / 8 DMA 128x128 with 3 / 4 stages."""
+    """debug/testing: 0 auto, 3 row-streaming, 4 split-K small-M, 5 DMA 128x128 (2 stages), 6 DMA 64x64 ring, 9 gemm_256 (256x256 tiles,
+    eight waves), 10 gemm_4w (four waves), 16 gemm_4w_r (four waves, weights streamed into registers), 20 gemm_4w_p (16 made persistent,
+    register-only epilogue); the ablation / trace selectors are listed in csrc/omp355_debug.h."""
     _lib.check(_lib.lib().omp_debug_force_gemm_kernel(which), 'omp_debug_force_gemm_kernel')
 
 

@@ -764,7 +764,7 @@ def main():
         if n_gemm:
             tf = f_gemm / (t_gemm / 1e3) / 1e12
             gt = pmc_gemm_traffic(a.size, dtype_name)
-            grec = dict(bound='mfma', kernel='gemm_256 + gemm_dma<128,128,2> + gemm_4w at M >= 32768 rows (Swin qkv / proj / fc1 / fc2 / merge, FPN, input_proj, K-V projection)',
+            grec = dict(bound='mfma', kernel='gemm_256 + gemm_dma<128,128,2> + gemm_4w + gemm_4w_p at M >= 32768 rows (Swin qkv / proj / fc1 / fc2 / merge, FPN, input_proj, K-V projection)',
                         achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=gt[0] if gt else None,
                         launches=int(n_gemm), avg_us=t_gemm / n_gemm * 1e3, flops_per_launch=f_gemm / n_gemm,
                         gpu_ms_per_image=t_gemm / (n_groups * BI))
