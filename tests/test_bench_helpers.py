@@ -113,3 +113,28 @@ def test_gemm4w_register_audit_catches_a_compiler_touch():
         finally:
             os.unlink(f.name)
         assert seen == 1 and len(bad) == n_bad, (seen, bad)
+
+
+def test_gemm4w_audit_refuses_a_register_copy_in_the_stage_loop():
+    """gemm_4w_r / gemm_4w_p load their fragments with asm statements and count the waits by hand: a compiler-inserted vector-register copy
+    inside the stage loop could read a fragment before it lands.  tools/audit_gemm4w.py demands that the innermost loop of those two
+    kernels holds all 512 MFMAs of its four stages and no such copy (scalar-source moves are fine)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        import audit_gemm4w
+    finally:
+        sys.path.pop(0)
+    import tempfile
+    body = '\tv_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]\n' * 512
+    def kernel(extra):
+        return ('_ZN1x9gemm_4w_pIfLb0ELi0EEEvNS_5GemmPE: ; @k\n\ts_nop 0\n.LBB1_2: ; %loop\n ; =>This Inner Loop Header: Depth=1\n' + body + extra +
+                '\ts_cbranch_scc1 .LBB1_2\n; %bb.3:\n\tv_mov_b32_e32 v9, v8\n\ts_endpgm\n'
+                '  - .name:           _ZN1x9gemm_4w_pIfLb0ELi0EEEvNS_5GemmPE\n    .agpr_count:     256\n    .private_segment_fixed_size: 0\n    .vgpr_spill_count: 0\n    .wavefront_size: 64\n')
+    for extra, n_bad in (('', 0), ('\tv_mov_b32_e32 v1, s3\n', 0), ('\tv_mov_b32_e32 v1, v2\n', 1), ('\tv_mov_b64_e32 v[2:3], v[4:5]\n', 1)):
+        with tempfile.NamedTemporaryFile('w', suffix='.s', delete=False) as f:
+            f.write(kernel(extra))
+        try:
+            seen, bad = audit_gemm4w.audit(f.name)
+        finally:
+            os.unlink(f.name)
+        assert seen == 1 and len(bad) == n_bad, (extra, seen, bad)

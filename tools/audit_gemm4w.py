@@ -1,7 +1,8 @@
 """Build audit of gemm_4w (csrc/gemm4w.inc): the kernel addresses all 256 accumulator registers literally from asm statements, so the
 compiler must neither spill nor touch the accumulator file itself (cdna_hip_programming.md 5.7 item 4).  Reads the device assembly hipcc
 leaves next to the object (advancedliteratemachinery_amd/build.py compiles gemm.hip with -save-temps=obj) and demands, for EVERY gemm_4w
-instantiation: no scratch, no spill, and no v_accvgpr_* / scratch_* instruction outside an ;;#ASMSTART ... ;;#ASMEND block.
+instantiation: no scratch, no spill, and no v_accvgpr_* / scratch_* instruction outside an ;;#ASMSTART ... ;;#ASMEND block; for gemm_4w_r /
+gemm_4w_p (asm fragment loads, hand-counted waits) also no register copy inside the stage loop.
     python tools/audit_gemm4w.py [path/to/gemm-hip-amdgcn-amd-amdhsa-gfx950.s]   -> exit status 1 on a violation"""
 import os
 import re
@@ -28,6 +29,39 @@ def audit(path=DEFAULT):
             elif not inasm and ('v_accvgpr' in ln or 'scratch_' in ln):
                 bad.append('%s: compiler-generated `%s`' % (name, ln.strip()))
                 break
+    # gemm_4w_r / gemm_4w_p load fragments with asm statements and count the waits by hand: the compiler believes a fragment register
+    # holds its value as soon as the statement is issued, so a register-to-register copy inside the stage loop (phi resolution,
+    # rematerialisation) could read it before the data arrives.  Demand that the innermost loop (the stages) holds no v_mov at all.
+    for m in re.finditer(r'^(_ZN\S*gemm_4w_[rp]\S*):[^\n]*\n(.*?)\ts_endpgm', text, re.S | re.M):
+        name, lines = m.group(1), m.group(2).split('\n')
+        if not re.search(r'ELi0EEEvNS', name):
+            continue   # ablation / trace instantiations (wrong results by construction or development only)
+        # innermost loops: the header block carries "Inner Loop Header", its other blocks "in Loop: Header=BBx_y Depth=d" (LLVM's comments)
+        inner = set()
+        for i, ln in enumerate(lines):
+            if 'Inner Loop Header' in ln:
+                for j in range(i, max(-1, i - 4), -1):
+                    mm = re.match(r'^\.L(BB\d+_\d+):', lines[j])
+                    if mm:
+                        inner.add(mm.group(1))
+                        break
+        if not inner:
+            bad.append('%s: no inner loop found (the stage loop)' % name)
+            continue
+        in_loop, n_mfma = False, 0
+        for i, ln in enumerate(lines):
+            if re.match(r'^(\.LBB\d+_\d+:|; %bb\.\d+:)', ln):
+                ctx = ' '.join(lines[i:i + 3])
+                mm = re.match(r'^\.L(BB\d+_\d+):', ln)
+                in_loop = ('Inner Loop Header' in ctx and mm is not None and mm.group(1) in inner) or any('Header=%s ' % h in ctx for h in inner)
+            elif in_loop:
+                if 'v_mfma' in ln:
+                    n_mfma += 1
+                if re.search(r'\bv_mov_b(32|64)(_e32|_e64)?\s+v\S*,\s*v', ln):   # vector-register source
+                    bad.append('%s: register copy inside the stage loop: `%s`' % (name, ln.strip()))
+                    break
+        if n_mfma < 512:
+            bad.append('%s: the stage loop was not recognised (%d MFMAs inside the innermost loop, 512 expected)' % (name, n_mfma))
     for m in re.finditer(r'\.name:\s+(_ZN\S*gemm_4w\S*)\n(.*?)\.wavefront_size', text, re.S):
         name, meta = m.group(1), m.group(2)
         # (scalar-register spills are allowed: hipcc parks them in lanes of a vector register it owns, not in scratch or the accumulator file)
