@@ -780,9 +780,14 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
       if ((which == 9 || which == 10) && !p.split_out && gemm4wp_ok(p, true, std::is_same<TOut, bf16_t>::value) &&
           ((p.act == OMP_ACT_GELU && std::is_same<TOut, bf16_t>::value) || (p.K == 768 && p.residual == nullptr && p.N >= 768 && p.act == OMP_ACT_NONE)))
         which = 20;
+      // bf16x3 operands: the three products fused over shared operand tiles (gemm4wp.inc, X3) wherever a 256x256-tile kernel was chosen
+      // and the shape has no ragged edge -- 2/3 of the operand bytes; faster on every encoder product of the parity engine
+      // (profiles/r04y_kbench_gemm_x3_fused.txt: -1...-17 %).  Its summation order is chunk by chunk, not plane by plane: equal to the
+      // three-pass kernels within fp32 rounding, not bit for bit.
+      if ((which == 9 || which == 10 || which == 20) && gemm4wx3_ok(p, true, std::is_same<TOut, bf16_t>::value)) which = 22;
     }
   }
-  if (p.C2 != nullptr && which != 5 && which != 6 && which != 9 && which != 10 && which != 11 && which != 15 && which != 16 && which != 18 && which != 20 && which != 21) {
+  if (p.C2 != nullptr && which != 5 && which != 6 && which != 9 && which != 10 && which != 11 && which != 15 && which != 16 && which != 18 && which != 20 && which != 21 && which != 22) {
     omp_set_error("omp_gemm_bias_act: kernel selector %d has no second destination (C2)", which);
     return OMP_ERR_UNSUPPORTED;
   }
@@ -886,6 +891,21 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
       if (rc != OMP_OK) return rc;
     } else {
       omp_set_error("omp_gemm_bias_act: selector 20 (persistent four-wave tiles) is bf16-only");
+      return OMP_ERR_UNSUPPORTED;
+    }
+  } else if (which == 22) {          // bf16x3: the three products fused over shared operand tiles (gemm4wp.inc, X3)
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      if (!gemm4wx3_ok(p, true, std::is_same<TOut, bf16_t>::value)) {
+        omp_set_error("omp_gemm_bias_act: selector 22 takes bf16x3 operands (a_wrap = 2 K0, K = 3 K0, K0 %% 128 == 0), M and N multiples of 256, fp32 or split destination");
+        return OMP_ERR_UNSUPPORTED;
+      }
+      const int pcls = p.M >= 32768 ? OMP_PROF_GEMM : OMP_PROF_GEMM_DEC;
+      const int slot = omp_prof_active(pcls) ? omp_prof_begin(pcls, st, 2.0 * (double)p.M * p.N * p.K, gemm_alg_bytes(p, sizeof(T), sizeof(TOut))) : -1;
+      int rc = launch_4wx3<TOut>(p, st);
+      if (slot >= 0) omp_prof_end(pcls, slot, st);
+      if (rc != OMP_OK) return rc;
+    } else {
+      omp_set_error("omp_gemm_bias_act: selector 22 is bf16-only");
       return OMP_ERR_UNSUPPORTED;
     }
   } else if (which == 15) {          // development: gemm_dma<128,128,2> with per-workgroup phase timestamps

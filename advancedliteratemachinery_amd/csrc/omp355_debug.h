@@ -36,7 +36,7 @@ int omp_prof_read_class(int cls, double* total_ms, int64_t* count, double* work)
 int omp_prof_read_roofline(int cls, double* bytes, double* roofline_seconds);
 /* GEMM kernel selector: 0 auto; 3 row-streaming; 4 split-K small-M; 5 / 6 DMA 128x128 / 64x64; 9 gemm_256; 10 (= 11) gemm_4w; 16 gemm_4w_r
  * (weights streamed into registers; K % 256 == 0); 20 gemm_4w_p (the same, persistent over tiles, register-only epilogue; M, N, K
- * multiples of 256).  Wrong results, valid timing: 12..14 gemm_4w without DMA / fragment reads / MFMAs, 17 gemm_4w_r without MFMAs, 21
+ * multiples of 256); 22 its fused three-product instantiation for bf16x3 operands.  Wrong results, valid timing: 12..14 gemm_4w without DMA / fragment reads / MFMAs, 17 gemm_4w_r without MFMAs, 21
  * gemm_4w_p with 2/3 of its operand bytes.  Traces: 15 gemm_dma<128,128,2>, 18 gemm_4w_r (omp_debug_set_gemm_trace). */
 int omp_debug_force_gemm_kernel(int which);
 /* development: device buffer uint64 [n_workgroups][8] that omp_debug_force_gemm_kernel(15 / 18) fills with s_memtime stamps

@@ -844,6 +844,28 @@ def _check_e2e(name, dtype_name, graph):
     return out + _compare_image(tag, dtype_name, args, gold, e, 0, 1, res, dec, model)
 
 
+def check_e2e_replicated(name, dtype_name, copies=8):
+    """A single-image fixture submitted `copies` times in ONE engine call: the encoder's products then have the row counts at which the
+    dispatch picks the chip-filling kernels (256x256 tiles: gemm_256 / gemm_4w_p, and on the parity engine the fused three-product
+    kernel, whose summation order differs from the three-pass kernels') -- kernels a one-image fixture never reaches.  Every copy is held
+    to the fixture's reference under the engine's usual gates (bf16x3: the fp32 gates, ids identical)."""
+    dt = ENGINES[dtype_name]
+    gold = golden(name)
+    case = gold['case']
+    args, sd, img, mask, seqs = G.case_inputs(case)
+    assert 'images' not in gold and img.shape[0] == 1
+    model = build_model(args, sd, case['depths'], dt, False, case.get('swin'))
+    imgs = img.to(DEV).expand(copies, -1, -1, -1).contiguous()
+    masks = mask.to(DEV).expand(copies, -1, -1).contiguous()
+    enc, dec = model.engine()
+    e = enc.encode(imgs, masks, want_intermediates=True)
+    res = model.infer(imgs, masks, seqs)
+    out = []
+    for b in (0, copies - 1):
+        out += _compare_image('%s x%d,img%d' % (name, copies, b), dtype_name, args, gold, e, b, copies, res[b], dec, model)
+    return out
+
+
 def _compare_image(name, dtype_name, args, gold, e, b, B, res, dec, model):
     """One image of an engine call against the reference outputs recorded for it."""
     f32 = dtype_name in ('fp32', 'bf16x3')   # the parity engine answers to the fp32 gates (north_star: 1e-3 on logits, ids identical)
@@ -1320,6 +1342,27 @@ def check_gemm_4w():
         bias, rf = rnd(N, seed=3).to(DEV), rnd(M, N, seed=5).to(DEV)
         same('even x3 %dx%dx%d f32 + residual' % (M, N, 3 * K), lambda: (ops.gemm(As, W3, bias, residual=rf, out_dtype=torch.float32, a_wrap=2 * K),), k16=True, k20=True)
         same('even x3 %dx%dx%d gelu split' % (M, N, 3 * K), lambda: (ops.gemm(As, W3, bias, act=ops.ACT_GELU, out_dtype=ops.SPLIT, a_wrap=2 * K),), k16=True, k20=True)
+    # the fused three-product kernel (selector 22): same operands, chunk-by-chunk summation order -> equal to the three-pass kernels
+    # within fp32 rounding of the accumulation (not bit for bit), and to an fp64 product of the SPLIT operands
+    for (M, N, K) in ((256, 256, 256), (3072, 512, 512), (33280, 1536, 512), (8192, 768, 256), (4096, 512, 2048)):
+        Af, Wf = rnd(M, K, seed=M + 1).to(DEV), (rnd(N, K, seed=N + 2) / math.sqrt(K)).to(DEV)
+        As, W3 = ops.split_bf16(Af), ops.split_weight3(Wf)
+        bias, rf = rnd(N, seed=3).to(DEV), rnd(M, N, seed=5).to(DEV)
+        base = run(5, lambda: ops.gemm(As, W3, bias, residual=rf, out_dtype=torch.float32, a_wrap=2 * K))
+        got = run(22, lambda: ops.gemm(As, W3, bias, residual=rf, out_dtype=torch.float32, a_wrap=2 * K))
+        scale = max(1.0, base.abs().max().item())
+        out.append(rec('gemm_4w[k22 ~ k5, x3 %dx%dx%d f32 + residual]' % (M, N, 3 * K), (got - base).abs().max().item(), 4e-6 * scale, 'fp32 summation order only'))
+        if M <= 8192:
+            a_hi, a_lo = As[:, :K].double().cpu(), As[:, K:].double().cpu()
+            w_hi, w_lo = W3[:, :K].double().cpu(), W3[:, 2 * K:].double().cpu()
+            ref = a_hi @ w_hi.t() + a_lo @ w_hi.t() + a_hi @ w_lo.t() + bias.double().cpu() + rf.double().cpu()
+            out.append(rec('gemm_4w[k22 vs fp64 of the split operands, %dx%dx%d]' % (M, N, 3 * K), (got.double().cpu() - ref).abs().max().item(), 4e-6 * scale))
+        bs = run(5, lambda: ops.gemm(As, W3, bias, act=ops.ACT_GELU, out_dtype=ops.SPLIT, a_wrap=2 * K))
+        gs = run(22, lambda: ops.gemm(As, W3, bias, act=ops.ACT_GELU, out_dtype=ops.SPLIT, a_wrap=2 * K))
+        vb = bs[:, :N].float() + bs[:, N:].float()
+        vg = gs[:, :N].float() + gs[:, N:].float()
+        # pair rows resolve 16 mantissa bits: a last-bit difference of the fp32 value may move hi + lo by one unit of that grid
+        out.append(rec('gemm_4w[k22 ~ k5, x3 %dx%dx%d gelu split]' % (M, N, 3 * K), (vg - vb).abs().max().item(), 2.0 ** -15 * max(1.0, vb.abs().max().item()), 'hi + lo of the pair rows'))
     # bf16x3 operands: split-pair A wrapped over [hi | lo | hi]
     for (M, N, K) in ((3000, 512, 512), (1100, 1536, 512), (2049, 256, 1024)):
         As, W3 = ops.split_bf16(rnd(M, K, seed=M).to(DEV)), ops.split_weight3((rnd(N, K, seed=N + 1) / math.sqrt(K)).to(DEV))

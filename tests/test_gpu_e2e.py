@@ -64,6 +64,13 @@ def test_config2_shape_graph_lanes_bf16(C):
     _assert_all(C.check_e2e('spot_1024', 'bf16', graph=True))
 
 
+@pytest.mark.parametrize('dtype', ['bf16x3', 'bf16'])
+def test_replicated_fixture_reaches_the_chip_filling_kernels(C, dtype):
+    """spot_1024 eight times in one engine call: the encoder's GEMMs get the row counts of a 32-image chunk's (gemm_256, gemm_4w_p, and
+    on the parity engine the fused three-product bf16x3 kernel); every copy under the engine's usual gates."""
+    _assert_all(C.check_e2e_replicated('spot_1024', dtype, 8))
+
+
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'bf16x3'])
 def test_batch_equals_single(C, dtype):
     _assert_all(C.check_batch_equivalence(dtype))

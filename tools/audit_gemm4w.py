@@ -34,7 +34,7 @@ def audit(path=DEFAULT):
     # rematerialisation) could read it before the data arrives.  Demand that the innermost loop (the stages) holds no v_mov at all.
     for m in re.finditer(r'^(_ZN\S*gemm_4w_[rp]\S*):[^\n]*\n(.*?)\ts_endpgm', text, re.S | re.M):
         name, lines = m.group(1), m.group(2).split('\n')
-        if not re.search(r'ELi0EEEvNS', name):
+        if not re.search(r'ELi0E(Lb[01]E)?EEvNS', name):
             continue   # ablation / trace instantiations (wrong results by construction or development only)
         # innermost loops: the header block carries "Inner Loop Header", its other blocks "in Loop: Header=BBx_y Depth=d" (LLVM's comments)
         inner = set()
