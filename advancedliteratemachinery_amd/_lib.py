@@ -96,6 +96,7 @@ _SIGS = {
     'omp_decoder_graph_reset': (c_int, [c_int]),
     'omp_decoder_step_logits': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_void_p]),
     'omp_debug_force_gemm_kernel': (c_int, [c_int]),
+    'omp_debug_gemm_choice': (c_int, [c_void_p]),
     'omp_debug_set_gemm_trace': (c_int, [c_void_p, c_int64]),
     'omp_debug_swin_attn_impl': (c_int, [c_int]),
     'omp_debug_cross_q4': (c_int, [c_int]),

@@ -74,6 +74,8 @@ struct omp_ctx {
   int dec_fused = 0;         // 0 = fused few-row decoder kernels where they apply (csrc/decoder.hip: fused_step_ok), 1 = the launch-per-op path everywhere
   int swin_impl = 0;         // 0 matrix cores, 1 scalar cross-check kernel, 2 matrix cores with per-score table lookups
   int mlp_variant = 0;       // alternative instantiations of the fused MLP; 100 = traced default
+  int gemm_choice_only = 0;  // omp_debug_gemm_choice: launch_gemm records the selector it would take in gemm_last_choice and launches nothing
+  int gemm_last_choice = 0;
   unsigned long long* gemm_trace = nullptr;   // device buffers of the TRACE instantiations
   long long gemm_trace_cap = 0;
   unsigned long long* mlp_trace = nullptr;

@@ -751,6 +751,7 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
       omp_set_error("omp_gemm_bias_act: fused LayerNorm supports K <= 1024");
       return OMP_ERR_UNSUPPORTED;
     }
+    if (cx.gemm_choice_only) { cx.gemm_last_choice = 4; return OMP_OK; }
     return launch_small<T, TOut>(p, st);
   }
   if (which == 0) {
@@ -787,6 +788,7 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
       if ((which == 9 || which == 10 || which == 20) && gemm4wx3_ok(p, true, std::is_same<TOut, bf16_t>::value)) which = 22;
     }
   }
+  if (cx.gemm_choice_only) { cx.gemm_last_choice = which; return OMP_OK; }   // omp_debug_gemm_choice: the dispatch table is host logic, testable without a GPU
   if (p.C2 != nullptr && which != 5 && which != 6 && which != 9 && which != 10 && which != 11 && which != 15 && which != 16 && which != 18 && which != 20 && which != 21 && which != 22) {
     omp_set_error("omp_gemm_bias_act: kernel selector %d has no second destination (C2)", which);
     return OMP_ERR_UNSUPPORTED;
@@ -934,6 +936,17 @@ extern "C" int omp_debug_set_gemm_trace(void* buffer, int64_t n_workgroups) {
   omp_cur().gemm_trace = reinterpret_cast<unsigned long long*>(buffer);
   omp_cur().gemm_trace_cap = buffer ? n_workgroups : 0;
   return OMP_OK;
+}
+
+// The kernel selector omp_gemm_bias_act would take for these arguments (after its argument checks), without launching anything and
+// without touching a device: pointers are only tested for null / alignment.  > 0: selector (omp355_debug.h), < 0: the error code.
+extern "C" int omp_debug_gemm_choice(const omp_gemm_args* a) {
+  omp_ctx& cx = omp_cur();
+  cx.gemm_choice_only = 1;
+  cx.gemm_last_choice = 0;
+  const int rc = omp_gemm_bias_act(a, nullptr);
+  cx.gemm_choice_only = 0;
+  return rc == OMP_OK ? cx.gemm_last_choice : rc;
 }
 
 extern "C" int omp_debug_force_gemm_kernel(int which) {

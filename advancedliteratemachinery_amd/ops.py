@@ -96,6 +96,35 @@ def gemm(A, W, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     return out
 
 
+def gemm_choice(M, N, K, dtype=OMP_BF16, out_dtype=None, act=ACT_NONE, residual=False, bias=True, a_wrap=0, store_mode=0, kv=None,
+                lda=None, ldw=None, ldc=None, two_destinations=False, ln=False, small_m=False, base=1 << 20):
+    """Host logic only (no device, no launch): the kernel selector omp_gemm_bias_act would take for a product of this shape -- the
+    dispatch table of csrc/gemm.hip as a function (tests/test_host_logic.py pins it).  Pointers are synthetic, 4 KB-aligned addresses:
+    the library only tests them for null and alignment.  Returns the selector (csrc/omp355_debug.h) or raises on an argument error."""
+    out_dtype = dtype if out_dtype is None else out_dtype
+    a = _lib.GemmArgs()
+    split = out_dtype == OMP_BF16X2
+    ka = a_wrap if a_wrap else K
+    a.A, a.lda, a.W, a.ldw = base, lda or ka, base + (1 << 30), ldw or K
+    a.bias = base + (2 << 30) if bias else None
+    a.residual, a.ldr = (base + (3 << 30), N) if residual else (None, 0)
+    a.C, a.ldc = base + (4 << 30), ldc or (2 * N if split else N)
+    a.M, a.N, a.K = M, N, K
+    a.dtype, a.out_dtype, a.act, a.a_wrap = dtype, out_dtype, act, int(a_wrap)
+    if ln:
+        a.ln_gamma, a.ln_beta, a.ln_eps = base + (5 << 30), base + (6 << 30), 1e-5
+    a.small_m_splitk = 1 if small_m else 0
+    a.store_mode = store_mode
+    if kv is not None:
+        a.kv_images, a.kv_tokens, a.kv_mpad, a.kv_heads, a.kv_key_block = kv
+    if two_destinations:
+        a.C2, a.ldc2 = base + (7 << 30), N
+    rc = _lib.lib().omp_debug_gemm_choice(ctypes.byref(a))
+    if rc < 0:
+        _lib.check(rc, 'omp_debug_gemm_choice')
+    return rc
+
+
 def swin_mlp_fused(x, ln_g, ln_b, wpack, b2, out=None, eps=1e-5):
     """x [M, C] bf16 or fp32 (fp32 residual stream) -> x + fc2(GELU(fc1(LN(x)))) in one launch, same type; wpack from
     model.packing.pack_mlp (bf16 matrix-core operands either way).  out may be x."""

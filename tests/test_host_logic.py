@@ -580,3 +580,40 @@ def test_split_plane_slab_indexing_is_a_bijection():
     lo = (x - hi.float()).to(torch.bfloat16)
     rel = ((hi.float() + lo.float() - x).abs() / x.abs().clamp_min(1e-30)).max().item()
     assert rel <= 2.0 ** -16
+
+
+def test_gemm_dispatch_table():
+    """The kernel selector of omp_gemm_bias_act is host logic (csrc/gemm.hip: launch_gemm): omp_debug_gemm_choice returns it without a
+    launch or a device.  Pins the table DESIGN.md sections 5 and 10 describe -- which product of which engine runs on which kernel --
+    so that a change of a rule shows up here and not as an unexplained move of a bench leg."""
+    from advancedliteratemachinery_amd import _lib, ops
+    G = ops.gemm_choice
+    F32, BF, SPLIT, GELU = ops.OMP_F32, ops.OMP_BF16, ops.OMP_BF16X2, ops.ACT_GELU
+    # bf16 engine, 32-image chunk of 1024x1024 images
+    assert G(131072, 1536, 512) == 9                                        # stage-2 qkv: gemm_256
+    assert G(131072, 2048, 512, act=GELU) == 20                             # stage-2 fc1 + GELU: persistent four-wave kernel
+    assert G(32768, 4096, 1024, act=GELU) == 20                             # stage-3 fc1
+    assert G(131072, 512, 512, out_dtype=F32, residual=True) == 9           # proj into the fp32 residual stream
+    assert G(131072, 512, 2048, out_dtype=F32, residual=True) == 9          # fc2
+    assert G(524288, 768, 256) == 10                                        # half-million-row stage-1 product without GELU: gemm_4w
+    assert G(131584, 2304, 768) == 20 and G(131584, 3072, 768, act=GELU) == 20   # MGP-STR's ViT-B qkv / fc1 (K = 768)
+    assert G(131000, 1536, 512) == 9                                        # ragged M: not the persistent kernel
+    assert G(655360, 6144, 512, store_mode=_lib.STORE_KBLK, kv=(160, 4096, 4096, 8, 32)) == 9   # K slabs of 160 images
+    # parity engine (bf16x3 operands): the fused three-product kernel wherever a 256x256-tile kernel would run on an even shape
+    assert G(131072, 1536, 1536, out_dtype=F32, a_wrap=1024) == 22
+    assert G(131072, 2048, 1536, out_dtype=SPLIT, act=GELU, a_wrap=1024) == 22
+    assert G(524288, 768, 768, out_dtype=F32, a_wrap=512) == 22
+    assert G(32768, 1024, 12288, out_dtype=F32, residual=True, a_wrap=8192) == 22
+    assert G(2097152, 512, 384, out_dtype=SPLIT, act=GELU, a_wrap=256) == 9    # stage 0: K0 = 128 is below the fused kernel's granularity
+    # decoder phases
+    assert G(10240, 512, 512, out_dtype=F32, residual=True) == 5            # 160 images x 64 rows: 320 tiles of 128x128
+    assert G(10240, 1536, 512) == 9                                         # ... its qkv fills the chip with 256x256 tiles (240 of them)
+    assert G(160, 1536, 512) == 6                                           # point decoder of a 160-image call: 64x64 ring
+    assert G(8, 512, 512, small_m=True) == 4                                # few rows: split-K over the waves
+    assert G(32, 1536, 512, ln=True, small_m=True, lda=512) == 4            # ... with the LayerNorm prologue
+    assert G(300, 384, 128) == 6
+    # fp32 engine: no 256x256 kernels
+    assert G(131072, 1536, 512, dtype=F32) == 5
+    # argument errors surface as errors, not as a selector
+    with pytest.raises(RuntimeError):
+        G(128, 512, 100)
