@@ -40,7 +40,8 @@ int omp_prof_read_roofline(int cls, double* bytes, double* roofline_seconds);
  * gemm_4w_p with 2/3 of its operand bytes.  Traces: 15 gemm_dma<128,128,2>, 18 gemm_4w_r (omp_debug_set_gemm_trace). */
 int omp_debug_force_gemm_kernel(int which);
 /* the selector omp_gemm_bias_act would take for these arguments (no launch, no device access: host logic, tests/test_host_logic.py);
- * < 0: the error code of its argument checks */
+ * < 0: the error code of its argument checks.  Like every hook of this header it acts on the calling thread's current context: do not
+ * call it while another thread launches through the same context (its launches would be answered instead of executed) */
 int omp_debug_gemm_choice(const omp_gemm_args* args);
 /* development: device buffer uint64 [n_workgroups][8] that omp_debug_force_gemm_kernel(15 / 18) fills with s_memtime stamps
  * per workgroup: 0 start, 1 first K tile landed, 2 K loop done, 3 accumulators in LDS (18: every wave done), 4 stores retired, 5 XCC id */
