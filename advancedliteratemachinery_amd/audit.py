@@ -3,13 +3,15 @@ compiler must neither spill nor touch the accumulator file itself (cdna_hip_prog
 leaves next to the object (advancedliteratemachinery_amd/build.py compiles gemm.hip with -save-temps=obj) and demands, for EVERY gemm_4w
 instantiation: no scratch, no spill, and no v_accvgpr_* / scratch_* instruction outside an ;;#ASMSTART ... ;;#ASMEND block; for gemm_4w_r /
 gemm_4w_p (asm fragment loads, hand-counted waits) also no register copy inside the stage loop.
-    python tools/audit_gemm4w.py [path/to/gemm-hip-amdgcn-amd-amdhsa-gfx950.s]   -> exit status 1 on a violation"""
+    python -m advancedliteratemachinery_amd.audit [path/to/gemm-hip-amdgcn-amd-amdhsa-gfx950.s]   -> exit status 1 on a violation
+Part of the package (round 5; it lived under tools/): build.py runs it on the assembly BEFORE it links, so a library whose asm-addressed
+kernels the compiler broke is never left on disk."""
 import os
 import re
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT = os.path.join(ROOT, 'advancedliteratemachinery_amd', 'csrc', 'build', 'gemm-hip-amdgcn-amd-amdhsa-gfx950.s')
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT = os.path.join(HERE, 'csrc', 'build', 'gemm-hip-amdgcn-amd-amdhsa-gfx950.s')
 
 
 def audit(path=DEFAULT):
@@ -75,9 +77,68 @@ def audit(path=DEFAULT):
     return seen, bad
 
 
+def audit_dec_rows(path):
+    """csrc/dec_rows.hip (round 5): every wave of the decoders' row-owner kernel walks a linear stream of weight fragments that it loads with
+    asm statements into a register ring and waits for with hand-counted `s_waitcnt vmcnt(n)`.  The compiler believes such a register holds its
+    value from the moment the load is issued; a vector-register copy of it (phi resolution, rematerialisation) before the wait would read stale
+    data.  The ring registers are recognised as the destinations of the asm `global_load_dwordx4` statements of a kernel; the audit demands
+    that no compiler-generated instruction (outside ;;#ASMSTART ... ;;#ASMEND) READS one of them between its load and the wait that covers
+    it -- conservatively: no `v_mov` / `v_accvgpr_write` with a ring register as source anywhere in the kernel -- and that the kernel neither
+    spills nor uses scratch.  -> (number of dec_rows kernels seen, list of violation strings)"""
+    text = open(path).read()
+    bad, seen = [], 0
+    for m in re.finditer(r'^(_ZN\S*dec_rows\S*kernel\S*):[^\n]*\n(.*?)\ts_endpgm', text, re.S | re.M):
+        name, lines = m.group(1), m.group(2).split('\n')
+        seen += 1
+        ring = set()
+        inasm = False
+        for ln in lines:
+            if 'ASMSTART' in ln:
+                inasm = True
+            elif 'ASMEND' in ln:
+                inasm = False
+            elif inasm:
+                mm = re.match(r'\s*global_load_dwordx4\s+v\[(\d+):(\d+)\]', ln)
+                if mm:
+                    ring.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+        if not ring:
+            bad.append('%s: no asm fragment load found' % name)
+            continue
+        inasm = False
+        for ln in lines:
+            if 'ASMSTART' in ln:
+                inasm = True
+                continue
+            if 'ASMEND' in ln:
+                inasm = False
+                continue
+            if inasm:
+                continue
+            mm = re.match(r'\s*(v_mov_b32\S*|v_mov_b64\S*|v_accvgpr_write\S*|v_pk_mov\S*)\s+([^,]+),\s*(.*)$', ln)
+            if not mm:
+                continue
+            srcs = set()
+            for r in re.finditer(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b', mm.group(3)):
+                if r.group(3) is not None:
+                    srcs.add(int(r.group(3)))
+                else:
+                    srcs.update(range(int(r.group(1)), int(r.group(2)) + 1))
+            if srcs & ring:
+                bad.append('%s: copy of a fragment-ring register: `%s`' % (name, ln.strip()))
+                break
+    for m in re.finditer(r'\.name:\s+(_ZN\S*dec_rows\S*kernel\S*)\n(.*?)\.wavefront_size', text, re.S):
+        name, meta = m.group(1), m.group(2)
+        for key in ('.private_segment_fixed_size', '.vgpr_spill_count'):
+            v = re.search(re.escape(key) + r':\s+(\d+)', meta)
+            if v and int(v.group(1)) != 0:
+                bad.append('%s: %s = %s' % (name, key, v.group(1)))
+    return seen, bad
+
+
 if __name__ == '__main__':
-    n, bad = audit(sys.argv[1] if len(sys.argv) > 1 else DEFAULT)
-    print('gemm_4w audit: %d kernels, %d violations' % (n, len(bad)))
+    path = sys.argv[1] if len(sys.argv) > 1 else DEFAULT
+    n, bad = audit_dec_rows(path) if 'dec_rows' in os.path.basename(path) else audit(path)
+    print('register audit of %s: %d kernels, %d violations' % (os.path.basename(path), n, len(bad)))
     for b in bad:
         print('  ' + b)
     sys.exit(1 if bad or n == 0 else 0)

@@ -53,7 +53,7 @@ class Encoder(object):
         f32 = lambda k: sd[k].detach().float().contiguous()          # noqa: E731
         # The bf16 matrix-core GEMMs step K in 64-element tiles (csrc/gemm.hip).  A width that does not divide (BASELINE config 1's
         # Swin-T: stage 0 is 96 wide) gets its WEIGHT image zero-padded to the next multiple of 64 (round 4; it was refused before):
-        # zero columns cost no accuracy, and what the activation side contributes against them is finite (see _gemm).
+        # zero columns cost no accuracy; the activation is zero-padded to the same pitch (see _gemm).
         def pad64(w):
             k = w.shape[1]
             return w if k % 64 == 0 else torch.nn.functional.pad(w, (0, 64 - k % 64))
@@ -121,20 +121,20 @@ class Encoder(object):
 
     @staticmethod
     def _gemm(A, W, bias=None, **kw):
-        """ops.gemm for a weight whose K was zero-padded to a multiple of 64 (bf16 engine, widths like Swin-T's 96): the product
-        runs over the padded K on the activation's own row pitch, i.e. the last K - C columns of a row are read from the NEXT row
-        (finite activations against zero weights); `_rows` gives those buffers one spare zero row so that the last row reads zeros
-        and not whatever lies behind the tensor."""
+        """ops.gemm for a weight whose K was zero-padded to a multiple of 64 (bf16 engine, widths like Swin-T's 96).  The activation
+        gets the same treatment: it is copied into a zero-filled operand of the padded pitch, so a row's product reads its OWN
+        columns and zeros -- never a neighbour's values (round 4 read the next row against the zero weights: one Inf / NaN there
+        poisoned this row, 0 x Inf = NaN).  One extra pass over a 96-wide tensor, on the Swin-T path only."""
         if W.shape[1] != A.shape[-1] and not kw.get('a_wrap'):
-            kw.update(K=W.shape[1], lda=A.shape[-1])
+            Ap = torch.zeros((A.shape[0], W.shape[1]), dtype=A.dtype, device=A.device)
+            Ap[:, :A.shape[-1]].copy_(A)
+            A = Ap
         return ops.gemm(A, W, bias, **kw)
 
     @staticmethod
     def _rows(rows, C, dtype, device):
-        """GEMM operand buffer [rows, C] (+ a spare zero row when C is not a multiple of 64, see _gemm)."""
-        if C % 64 == 0:
-            return torch.empty((rows, C), dtype=dtype, device=device)
-        return torch.zeros((rows + 1, C), dtype=dtype, device=device)[:rows]
+        """GEMM operand buffer [rows, C]."""
+        return torch.empty((rows, C), dtype=dtype, device=device)
 
     # -- Swin ---------------------------------------------------------------------------------
     def _backbone_x3(self, img, want_f32):
@@ -233,10 +233,11 @@ class Encoder(object):
                 lat = lambda i, lvl: ops.gemm(sfeats[lvl][0], self.fpn_w[i], out_dtype=torch.float32, a_wrap=sfeats[lvl][0].shape[1])  # noqa: E731
                 l5, l4, l3, l2 = lat(0, 3), lat(1, 2), lat(2, 1), lat(3, 0)
             else:
-                l5 = ops.gemm(c5, self.fpn_w[0])
-                l4 = ops.gemm(c4, self.fpn_w[1])
-                l3 = ops.gemm(c3, self.fpn_w[2])
-                l2 = ops.gemm(c2, self.fpn_w[3])
+                # through _gemm: a stage map whose width is not a multiple of 64 (Swin-T's c2: 96) meets a zero-padded weight image
+                l5 = self._gemm(c5, self.fpn_w[0])
+                l4 = self._gemm(c4, self.fpn_w[1])
+                l3 = self._gemm(c3, self.fpn_w[2])
+                l2 = self._gemm(c2, self.fpn_w[3])
             sizes = ((h2, w2), (h3, w3), (h4, w4), (h5, w5))
             src, ho, wo = ops.fpn_fuse(l2, l3, l4, l5, B, sizes, 2)
             lvl = (h4, w4)

@@ -94,13 +94,9 @@ def test_split_plane_pmc_record_and_payload_round_trip():
 
 
 def test_gemm4w_register_audit_catches_a_compiler_touch():
-    """tools/audit_gemm4w.py (run by build.py on the device assembly): a compiler-generated v_accvgpr_* / scratch access outside an asm
+    """advancedliteratemachinery_amd/audit.py (run by build.py on the device assembly): a compiler-generated v_accvgpr_* / scratch access outside an asm
     block, a spill count or a short AGPR allocation in a gemm_4w kernel fails the build; the clean form passes."""
-    sys.path.insert(0, os.path.join(ROOT, 'tools'))
-    try:
-        import audit_gemm4w
-    finally:
-        sys.path.pop(0)
+    from advancedliteratemachinery_amd import audit as audit_gemm4w
     import tempfile
     clean = ('_ZN1x7gemm_4wIfEEv: ; @k\n\ts_nop 0\n\t;;#ASMSTART\n\tv_accvgpr_write_b32 a[0], 0\n\t;;#ASMEND\n\tv_mov_b32 v0, v1\n\ts_endpgm\n'
              '  - .name:           _ZN1x7gemm_4wIfEEv\n    .agpr_count:     256\n    .private_segment_fixed_size: 0\n    .vgpr_spill_count: 0\n    .wavefront_size: 64\n')
@@ -117,13 +113,9 @@ def test_gemm4w_register_audit_catches_a_compiler_touch():
 
 def test_gemm4w_audit_refuses_a_register_copy_in_the_stage_loop():
     """gemm_4w_r / gemm_4w_p load their fragments with asm statements and count the waits by hand: a compiler-inserted vector-register copy
-    inside the stage loop could read a fragment before it lands.  tools/audit_gemm4w.py demands that the innermost loop of those two
+    inside the stage loop could read a fragment before it lands.  advancedliteratemachinery_amd/audit.py demands that the innermost loop of those two
     kernels holds all 512 MFMAs of its four stages and no such copy (scalar-source moves are fine)."""
-    sys.path.insert(0, os.path.join(ROOT, 'tools'))
-    try:
-        import audit_gemm4w
-    finally:
-        sys.path.pop(0)
+    from advancedliteratemachinery_amd import audit as audit_gemm4w
     import tempfile
     body = '\tv_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]\n' * 512
     def kernel(extra):
