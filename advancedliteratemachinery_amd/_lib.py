@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16, OMP_BF16X2 = 0, 1, 2   # BF16X2: split-bf16 pair rows [hi | lo] (include/omp355.h)
-ABI_VERSION = 17
+ABI_VERSION = 18
 STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
@@ -43,13 +43,23 @@ class DecLayer(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         'sa_in_w', 'sa_bias_tab', 'sa_out_w', 'sa_out_b', 'ca_q_w', 'ca_qbias_tab', 'ca_out_w',
         'ca_out_b', 'ff1_w', 'ff1_b', 'ff2_w', 'ff2_b', 'n1_g', 'n1_b', 'n2_g', 'n2_b', 'n3_g', 'n3_b',
-        'kcache', 'vcache', 'crossK', 'crossVt')]
+        'kcache', 'vcache', 'crossK', 'crossVt', 'rows_mid', 'rows_ffn')]
+
+
+class DecRowsArgs(ctypes.Structure):
+    """omp_dec_rows_args (include/omp355.h): the row-owner chains of the decoders' many-row phases"""
+    _fields_ = [('R', c_int32), ('eps', c_float), ('d_pos', c_void_p), ('x', c_void_p), ('att', c_void_p), ('wstream', c_void_p),
+                ('wave_stride', c_int64), ('out_b', c_void_p), ('ln_g', c_void_p), ('ln_b', c_void_p), ('qbias_tab', c_void_p), ('q', c_void_p),
+                ('prologue', c_int32), ('tail', c_int32), ('ff1_b', c_void_p), ('ff2_b', c_void_p), ('seq', c_void_p), ('seq_ld', c_int32),
+                ('word_emb', c_void_p), ('pos_tab', c_void_p), ('emb_g', c_void_p), ('emb_b', c_void_p), ('lnt_g', c_void_p), ('lnt_b', c_void_p),
+                ('bias_tab', c_void_p), ('qkv', c_void_p), ('h0_b', c_void_p), ('h1_b', c_void_p), ('h2_b', c_void_p), ('logits', c_void_p),
+                ('vocab', c_int32)]
 
 
 class DecoderPlan(ctypes.Structure):
     _fields_ = ([(n, c_int32) for n in ('dtype', 'n_layers', 'd_model', 'n_heads', 'd_ff', 'vocab',
-                                        'pre_norm', 'R', 'Lmax', 'M', 'Mpad', 'n_tiles', 'q_tiles', 'n_split', 'n_prompt', 'gemm_x3', 'kv_split')]
-                + [('eps', c_float), ('layers', DecLayer * MAX_DEC_LAYERS)]
+                                        'pre_norm', 'R', 'Lmax', 'M', 'Mpad', 'n_tiles', 'q_tiles', 'n_split', 'n_prompt', 'gemm_x3', 'kv_split', 'rows_fused')]
+                + [('eps', c_float), ('rows_embed', c_void_p), ('layers', DecLayer * MAX_DEC_LAYERS)]
                 + [(n, c_void_p) for n in ('word_emb', 'pos_tab', 'emb_g', 'emb_b', 'fn_g', 'fn_b',
                                            'h0_w', 'h1_w', 'h2_w', 'h0_b', 'h1_b', 'h2_b')]
                 + [('kv_img_stride', c_int64)]
@@ -92,6 +102,10 @@ _SIGS = {
                                              c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'omp_pack_spotting': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),
+    'omp_dec_rows_mid': (c_int, [ctypes.POINTER(DecRowsArgs), c_void_p]),
+    'omp_dec_rows_ffn': (c_int, [ctypes.POINTER(DecRowsArgs), c_void_p]),
+    'omp_dec_rows_tile': (c_int, []),
+    'omp_swin_mlp_rows': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'omp_decoder_run': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_int, c_int, c_void_p]),
     'omp_decoder_graph_reset': (c_int, [c_int]),
     'omp_decoder_step_logits': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_void_p]),

@@ -77,34 +77,35 @@ def audit(path=DEFAULT):
     return seen, bad
 
 
+def _regs(text):
+    out = set()
+    for r in re.finditer(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b', text):
+        if r.group(3) is not None:
+            out.add(int(r.group(3)))
+        else:
+            out.update(range(int(r.group(1)), int(r.group(2)) + 1))
+    return out
+
+
 def audit_dec_rows(path):
-    """csrc/dec_rows.hip (round 5): every wave of the decoders' row-owner kernel walks a linear stream of weight fragments that it loads with
-    asm statements into a register ring and waits for with hand-counted `s_waitcnt vmcnt(n)`.  The compiler believes such a register holds its
-    value from the moment the load is issued; a vector-register copy of it (phi resolution, rematerialisation) before the wait would read stale
-    data.  The ring registers are recognised as the destinations of the asm `global_load_dwordx4` statements of a kernel; the audit demands
-    that no compiler-generated instruction (outside ;;#ASMSTART ... ;;#ASMEND) READS one of them between its load and the wait that covers
-    it -- conservatively: no `v_mov` / `v_accvgpr_write` with a ring register as source anywhere in the kernel -- and that the kernel neither
-    spills nor uses scratch.  -> (number of dec_rows kernels seen, list of violation strings)"""
+    """csrc/dec_rows.hip (round 5): every wave of the decoders' row-owner kernels walks a linear stream of weight fragments that it loads with
+    asm statements into a register ring (`global_load_dwordx4 v[a:b], ... ; ring-load`) and waits for with hand-counted waits
+    (`s_waitcnt vmcnt(7) ; ring-take v[a:b]`).  The compiler believes such a register holds its value from the moment the load is issued; any
+    compiler-generated instruction that touches it between the load and its take (a copy for phi resolution, a spill to scratch, a
+    rematerialisation) would read or destroy data in flight.  Walking the kernel text in layout order with the set of PENDING registers
+    (loaded, not yet taken), the audit demands: no instruction outside the ;;#ASMSTART ... ;;#ASMEND blocks names a pending register; every
+    take names registers that are pending; a load never overwrites a pending register.  (Loop bodies are laid out once, and the ring is
+    periodic over every loop in these kernels, so layout order sees every load / take pair.)  Ordinary spills elsewhere are allowed.
+    -> (number of dec_rows kernels seen, list of violation strings)"""
     text = open(path).read()
     bad, seen = [], 0
-    for m in re.finditer(r'^(_ZN\S*dec_rows\S*kernel\S*):[^\n]*\n(.*?)\ts_endpgm', text, re.S | re.M):
+    for m in re.finditer(r'^(_ZN\S*_rows_\S*kernel\S*):[^\n]*\n(.*?)\ts_endpgm', text, re.S | re.M):
         name, lines = m.group(1), m.group(2).split('\n')
         seen += 1
-        ring = set()
+        pending, landed = set(), set()
+        n_load = n_take = 0
         inasm = False
-        for ln in lines:
-            if 'ASMSTART' in ln:
-                inasm = True
-            elif 'ASMEND' in ln:
-                inasm = False
-            elif inasm:
-                mm = re.match(r'\s*global_load_dwordx4\s+v\[(\d+):(\d+)\]', ln)
-                if mm:
-                    ring.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
-        if not ring:
-            bad.append('%s: no asm fragment load found' % name)
-            continue
-        inasm = False
+        err = None
         for ln in lines:
             if 'ASMSTART' in ln:
                 inasm = True
@@ -112,26 +113,37 @@ def audit_dec_rows(path):
             if 'ASMEND' in ln:
                 inasm = False
                 continue
+            code = ln.split(';')[0]
             if inasm:
-                continue
-            mm = re.match(r'\s*(v_mov_b32\S*|v_mov_b64\S*|v_accvgpr_write\S*|v_pk_mov\S*)\s+([^,]+),\s*(.*)$', ln)
-            if not mm:
-                continue
-            srcs = set()
-            for r in re.finditer(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b', mm.group(3)):
-                if r.group(3) is not None:
-                    srcs.add(int(r.group(3)))
-                else:
-                    srcs.update(range(int(r.group(1)), int(r.group(2)) + 1))
-            if srcs & ring:
-                bad.append('%s: copy of a fragment-ring register: `%s`' % (name, ln.strip()))
+                if 'ring-load' in ln:
+                    mm = re.match(r'\s*global_load_dwordx4\s+(v\[\d+:\d+\])', ln)
+                    dst = _regs(mm.group(1)) if mm else set()
+                    if not dst:
+                        err = 'unparsed ring load `%s`' % ln.strip()
+                    elif dst & pending:
+                        err = 'ring load overwrites a fragment still in flight: `%s`' % ln.strip()
+                    pending |= dst
+                    landed -= dst
+                    n_load += 1
+                elif 'ring-drain' in ln:
+                    landed |= pending   # everything requested has arrived; the registers stay reserved (operands of the drain) until taken
+                    pending = set()
+                elif 'ring-take' in ln:
+                    regs = _regs(ln.split('ring-take')[1])
+                    if not regs or not regs <= (pending | landed):
+                        err = 'take of registers that no ring load filled: `%s`' % ln.strip()
+                    pending -= regs
+                    landed -= regs
+                    n_take += 1
+            elif pending and re.match(r'\s+[a-z]', ln) and (_regs(code) & pending):
+                err = 'compiler-generated instruction touches a fragment in flight: `%s`' % ln.strip()
+            if err:
+                bad.append('%s: %s' % (name, err))
                 break
-    for m in re.finditer(r'\.name:\s+(_ZN\S*dec_rows\S*kernel\S*)\n(.*?)\.wavefront_size', text, re.S):
-        name, meta = m.group(1), m.group(2)
-        for key in ('.private_segment_fixed_size', '.vgpr_spill_count'):
-            v = re.search(re.escape(key) + r':\s+(\d+)', meta)
-            if v and int(v.group(1)) != 0:
-                bad.append('%s: %s = %s' % (name, key, v.group(1)))
+        if not err and pending:
+            bad.append('%s: the kernel ends with fragments in flight (no ring-drain): the registers they land in are not reserved' % name)
+        if not err and (n_load < 8 or n_take < 8):
+            bad.append('%s: ring not recognised (%d loads, %d takes)' % (name, n_load, n_take))
     return seen, bad
 
 

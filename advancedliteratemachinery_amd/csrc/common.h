@@ -50,7 +50,8 @@ void omp_set_error(const char* fmt, ...);
 // measurement hooks (api.hip): hipEvent brackets around the eagerly launched kernels of one class
 // GEMM = encoder-sized products (M >= 32768 rows: the Swin / FPN / projection GEMMs of a chunk, as in rounds 1-3); GEMM_DEC = the same kernels
 // on the decoder phases' rows (round 4: the 10240-row polygon / recognition products moved from the unbracketed 64x64 kernel to these)
-enum { OMP_PROF_CROSS = 0, OMP_PROF_GEMM = 1, OMP_PROF_MLP = 2, OMP_PROF_GEMM_DEC = 3, OMP_PROF_NCLASS = 4 };
+// ROWS = the row-owner chains of the decoders' many-row phases (round 5, csrc/dec_rows.hip)
+enum { OMP_PROF_CROSS = 0, OMP_PROF_GEMM = 1, OMP_PROF_MLP = 2, OMP_PROF_GEMM_DEC = 3, OMP_PROF_ROWS = 4, OMP_PROF_NCLASS = 5 };
 
 // ---------------------------------------------------------------------------------------------
 // omp_ctx: ALL mutable library state (kernel selectors, development trace buffers, the table of captured decoder-step

@@ -1,0 +1,724 @@
+// Many-row decoder phases (polygon / recognition: thousands of rows at d_model = 512): the Linear layers of a pre-norm decoder layer as
+// ROW-OWNER chains, two launches per layer instead of eleven.
+//
+// Reference: OCR/OmniParser/model/transformer.py:430-454 (TransformerDecoderLayer.forward_pre):
+//     x = x + self_attn(norm1(x) ...);  x = x + multihead_attn(norm2(x) ...);  x = x + linear2(relu(linear1(norm3(x))))
+// Round 4 ran every Linear as its own tiled GEMM launch with the LayerNorms as launches of their own: at R = 10 240 rows a launch is
+// 240-320 tiles on a 256-CU chip -- fill, drain and the operand traffic of small tiles (64 flop per operand byte) put the class at 0.09 of
+// the matrix-core peak.  The boundaries between those launches are NOT all-to-all: LayerNorm, residual adds and every
+// Linear are row-local, only the two attention kernels mix rows (keys of the row's own cache; keys of the row's image).  So a workgroup
+// can OWN rows: it keeps RT = 80 rows resident (bf16 operand tile in LDS, fp32 residual / accumulators in registers) and walks the
+// whole chain between two attention kernels, streaming the chain's weights through the matrix cores:
+//
+//     dec_rows_mid_kernel :  att -> out_proj + bias + x -> x' -> LayerNorm2 -> ca_q + position bias -> q
+//     dec_rows_ffn_kernel :  att -> out_proj + bias + x -> LayerNorm3 -> linear1 + ReLU -> linear2 + bias + x -> x'
+//                            -> [next layer's LayerNorm1 -> in_proj (q | k | v) + position bias]  |  [final norm -> 3-layer head -> logits]
+//                            (prologue variant: token + position embedding + LayerNorm instead of the attention / FFN part: layer 0)
+//
+// What makes it fast (tools/probe_stream.hip, profiles/r05a_probe_stream.txt): the only operand that moves is the WEIGHT stream.  It is
+// the same for every workgroup, so it is an L2 / MALL hit everywhere; a compute unit pulls it at 110 GB/s (29 TB/s over the chip), and
+// with 80 resident rows each 1 KB fragment feeds 5 matrix-core instructions: 1.75 PFLOP/s with the loop below, against 0.3-0.6 for the
+// tiled kernels on these shapes.  Design points:
+//   * 8 waves; wave w owns the output features 64 w .. 64 w + 63 of a 512-feature pass (16 w .. + 15 of a 128-feature pass), so its
+//     weight fragments are ITS OWN: they go global -> registers (no LDS, no barrier in the product loop) as one linear stream per wave
+//     that the host packs in consumption order (model/packing.py::pack_rows_*): "next fragment" is `base += 1024`;
+//   * the stream is prefetched PF = 8 fragments deep in a register ring ACROSS products, LayerNorms and barriers (it depends on no data).
+//     hipcc does not keep such a ring in flight (it sinks the loads to their uses and drains vmcnt(0)): the loads are asm statements and
+//     the waits are counted by hand (`s_waitcnt vmcnt(PF - 1)`: exactly PF of these loads are outstanding at every use; loads return in
+//     order, so extra compiler-issued loads or stores only make the wait more conservative).  The build audit
+//     (advancedliteratemachinery_amd/audit.py::audit_dec_rows) refuses a build in which the compiler copies a ring register;
+//   * D[feature][row] = W[feature][:] . a[row][:] on 16x16x32 MFMAs: A operand = weight fragment, B operand = 16 rows x 32 k of the
+//     resident tile (ds_read_b128, row pitch 1056 B = conflict-free); a lane's accumulator quad = 4 consecutive features of one row;
+//   * LayerNorm over accumulator registers: two-pass fp32 statistics, the 8 waves' partial sums meet in LDS (2 barriers), the normalised
+//     rows are written over the operand tile in place;
+//   * FFN in 8 chunks of 256 hidden units: relu(linear1) of a chunk goes through an LDS tile into linear2's accumulators (two barriers
+//     per chunk), which START as x + bias2: the residual add costs nothing;
+//   * the row fragments of the next k-step are read from LDS before the matrix-core instructions of the current one.
+// Operand rounding is where the launch-per-op path rounds (LayerNorm outputs, attention outputs, hidden activations, q / k / v: bf16;
+// residual stream, accumulation, statistics: fp32).
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+
+namespace {
+
+constexpr int NW = 8;                  // waves per workgroup
+constexpr int PF = 8;                  // weight fragments in flight per wave
+constexpr int D = 512;                 // d_model
+constexpr int HC = 256;                // hidden units per FFN chunk
+constexpr int A_PITCH = D * 2 + 32;    // operand tile row pitch, bytes: 264 dwords = 8 mod 64 -> the b128 fragment reads are conflict-free
+constexpr int H_PITCH = HC * 2 + 32;   // hidden chunk tile row pitch: 136 dwords = 8 mod 64
+constexpr int TILE_SLACK = 64;         // behind each tile: the operand prefetch of gemm_pass reads one k-step past the last row
+
+template <int... I, class F>
+__device__ __forceinline__ void sfor_seq(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>()), ...); }
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_seq(std::make_integer_sequence<int, N>(), f); }
+
+struct Stream {
+  const char* base;   // wave-uniform: the next fragment to REQUEST (kept in scalar registers)
+  unsigned voff;      // lane * 16
+};
+
+template <int U>
+__device__ __forceinline__ void ws_issue(u32x4 (&ring)[PF], Stream& st) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 ; ring-load" : "=v"(ring[U]) : "v"(st.voff), "s"(st.base) : "memory");
+  st.base += 1024;
+}
+template <int U>
+__device__ __forceinline__ bf16x8 ws_take(u32x4 (&ring)[PF]) {
+  asm volatile("s_waitcnt vmcnt(%1) ; ring-take %0" : "+v"(ring[U]) : "n"(PF - 1) : "memory");
+  bf16x8 f;
+  __builtin_memcpy(&f, &ring[U], 16);
+  return f;
+}
+// The ring runs PF fragments ahead of the stream's end.  The compiler sees no further use of those registers and would hand them to the
+// code that follows -- where the requests still in flight would land on live values (the build audit caught exactly that).  After a
+// kernel's last product: wait for everything, with the ring registers as operands so that they stay allocated until then.
+__device__ __forceinline__ void ws_drain(u32x4 (&ring)[PF]) {
+  asm volatile("s_waitcnt vmcnt(0) ; ring-drain" : "+v"(ring[0]), "+v"(ring[1]), "+v"(ring[2]), "+v"(ring[3]), "+v"(ring[4]), "+v"(ring[5]), "+v"(ring[6]), "+v"(ring[7])::"memory");
+}
+// A value the optimiser cannot trace back: epilogues index with opaque copies of the lane coordinates so that their address arithmetic is
+// redone where it is used instead of being kept live (as 64-bit pointers, 40+ registers) across the product loops -- the kernels sit at
+// the 256-register budget of two waves per SIMD.
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+// LDS-only barrier: the weight ring stays in flight across it (a __syncthreads() would drain vmcnt(0))
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// acc[ft][rt] += W[feature tile ft of this wave][:] . a[row tile rt][:] over KS k-steps of 32; the wave's next NFT * KS stream fragments,
+// ordered (k-step, feature tile).  a_lane = operand tile + (lane & 15) * PITCH + (lane >> 4) * 16.
+template <int NFT, int KS, int RTT, int PITCH>
+__device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NFT][RTT], const char* a_lane, u32x4 (&ring)[PF], Stream& st) {
+  static_assert(PF % NFT == 0 && (NFT * KS) % PF == 0 && (PF / NFT) % 2 == 0, "a pass is a whole number of ring revolutions, an even number of k-steps each");
+  constexpr int NG = NFT * KS / PF, KPG = PF / NFT;
+  // the row fragments of k-step ks + 1 are requested before the matrix-core instructions of k-step ks (two register sets): a wave hides
+  // its own LDS latency instead of relying on the SIMD's other wave (the read behind the last k-step lands in the tile's padding)
+  bf16x8 bfr[2][RTT];
+#pragma unroll
+  for (int rt = 0; rt < RTT; ++rt) bfr[0][rt] = *reinterpret_cast<const bf16x8*>(a_lane + rt * 16 * PITCH);
+  auto group = [&](int gi) {
+    sfor<PF>([&](auto U) {
+      constexpr int u = decltype(U)::value, ft = u % NFT, kk = u / NFT;
+      if constexpr (ft == 0) {
+        const char* ak = a_lane + (gi * KPG + kk + 1) * 64;
+#pragma unroll
+        for (int rt = 0; rt < RTT; ++rt) bfr[(kk + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(ak + rt * 16 * PITCH);
+      }
+      const bf16x8 wf = ws_take<u>(ring);
+#pragma unroll
+      for (int rt = 0; rt < RTT; ++rt) acc[ft][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, bfr[kk & 1][rt], acc[ft][rt], 0, 0, 0);
+      ws_issue<u>(ring, st);
+    });
+  };
+  if constexpr (NG <= 2) {
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) group(gi);
+  } else {
+#pragma unroll 1
+    for (int gi = 0; gi < NG; ++gi) group(gi);
+  }
+}
+
+template <int NFT, int RTT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NFT][RTT]) {
+#pragma unroll
+  for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+    for (int rt = 0; rt < RTT; ++rt) acc[ft][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// LayerNorm of the RT rows held in accumulator layout (v[ft][rt][r]: row rt * 16 + li, feature 64 w + 16 ft + 4 g + r), written as the
+// bf16 operand tile.  Two-pass statistics; the waves' partial sums meet in red[2][NW][RT].  Barriers: after each partial-sum
+// store (every wave has then also finished the product that read the tile: it may be overwritten) and after the tile is written.
+template <int RTT>
+__device__ __forceinline__ void ln_acc_to_tile(const f32x4 (&v)[4][RTT], const float* __restrict__ gam, const float* __restrict__ bet, float eps,
+                                               char* tile, float* red, int wave, int li_, int g_) {
+  constexpr int RT = RTT * 16;
+  // opaque lane coordinates: the LDS addresses below are rebuilt per call (the compiler otherwise keeps the 40 of them alive -- spilled --
+  // from one LayerNorm of a kernel to the next, across the FFN loop)
+  const int li = opaque(li_), g = opaque(g_);
+  float* redl = red + li;                       // + w * RT + rt * 16: immediate offsets
+  float* red2l = red + NW * RT + li;
+  float mean[RTT], rstd[RTT];
+#pragma unroll
+  for (int rt = 0; rt < RTT; ++rt) {
+    float s = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) s += (v[ft][rt][0] + v[ft][rt][1]) + (v[ft][rt][2] + v[ft][rt][3]);
+    s = quad_group_sum(s);
+    if (g == 0) redl[wave * RT + rt * 16] = s;
+  }
+  lds_barrier();
+#pragma unroll
+  for (int rt = 0; rt < RTT; ++rt) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += redl[w * RT + rt * 16];
+    mean[rt] = s * (1.0f / D);
+  }
+#pragma unroll
+  for (int rt = 0; rt < RTT; ++rt) {
+    float q = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = v[ft][rt][r] - mean[rt]; q += d * d; }
+    q = quad_group_sum(q);
+    if (g == 0) red2l[wave * RT + rt * 16] = q;
+  }
+  lds_barrier();
+#pragma unroll
+  for (int rt = 0; rt < RTT; ++rt) {
+    float q = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) q += red2l[w * RT + rt * 16];
+    rstd[rt] = 1.0f / sqrtf(q * (1.0f / D) + eps);
+  }
+  char* tl = tile + li * A_PITCH + g * 8;       // + rt * 16 * A_PITCH + (64 w + 16 ft) * 2
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) {
+    const int f = wave * 64 + ft * 16 + g * 4;
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(gam + f), bb = *reinterpret_cast<const f32x4*>(bet + f);
+#pragma unroll
+    for (int rt = 0; rt < RTT; ++rt) {
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (bf16_t)((v[ft][rt][r] - mean[rt]) * rstd[rt] * gg[r] + bb[r]);
+      *reinterpret_cast<bf16x4*>(tl + rt * 16 * A_PITCH + (wave * 64 + ft * 16) * 2) = o;
+    }
+  }
+  lds_barrier();
+}
+
+// two-pass LayerNorm of one 512-wide row held 8 values per lane (the embedding prologue: a wave per row)
+__device__ __forceinline__ void ln_row512(float* v, const float* __restrict__ g, const float* __restrict__ b, int lane, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v[i];
+  s = wave_sum(s);
+  const float mean = s * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; q += d * d; }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / D) + eps);
+  const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + lane * 8), g1 = *reinterpret_cast<const f32x4*>(g + lane * 8 + 4);
+  const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + lane * 8), b1 = *reinterpret_cast<const f32x4*>(b + lane * 8 + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = (v[i] - mean) * rstd * g0[i] + b0[i];
+    v[i + 4] = (v[i + 4] - mean) * rstd * g1[i] + b1[i];
+  }
+}
+
+// the attention output rows of this workgroup (bf16 [R, 512]) -> operand tile; rows beyond R repeat the last row (computed, never stored)
+template <int RTT>
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ att, int64_t r0, int R, char* tile, int tid) {
+  constexpr int RT = RTT * 16;
+  for (int c = tid; c < RT * 64; c += NW * 64) {   // 64 sixteen-byte pieces per row
+    const int row = c >> 6, pc = c & 63;
+    int64_t r = r0 + row;
+    if (r > R - 1) r = R - 1;
+    *reinterpret_cast<u32x4*>(tile + row * A_PITCH + pc * 16) = *reinterpret_cast<const u32x4*>(att + r * D + pc * 8);
+  }
+}
+
+// acc = acc + bias[f] + x[row][f]  (the residual add of an attention sub-layer); optionally the new x goes back to memory.
+// xb = x + r0 * 512 (the workgroup's first row), nrow = rows of this workgroup that exist (R - r0, >= 1)
+template <int RTT, bool STORE>
+__device__ __forceinline__ void add_bias_residual(f32x4 (&acc)[4][RTT], const float* __restrict__ bias, float* __restrict__ xb, int nrow,
+                                                  int wave, int li_, int g_) {
+  const int li = opaque(li_), g = opaque(g_);
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) {
+    const int f = wave * 64 + ft * 16 + g * 4;
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + f);
+#pragma unroll
+    for (int rt = 0; rt < RTT; ++rt) {
+      const int lr = rt * 16 + li;
+      const int lc = lr < nrow ? lr : nrow - 1;
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + lc * D + f);
+      const f32x4 v = {acc[ft][rt][0] + bb[0] + xv[0], acc[ft][rt][1] + bb[1] + xv[1], acc[ft][rt][2] + bb[2] + xv[2], acc[ft][rt][3] + bb[3] + xv[3]};
+      acc[ft][rt] = v;
+      if constexpr (STORE) {
+        if (lr < nrow) *reinterpret_cast<f32x4*>(xb + lr * D + f) = v;
+      }
+    }
+    asm volatile("" ::: "memory");   // one feature tile's residual loads at a time (20 registers), not all four hoisted
+  }
+}
+
+// out[row][col0 + f] = T(acc + bias[f]) (optionally ReLU): the q / q k v / logits stores.  ob = out + r0 * ld (first row of the workgroup)
+template <int NFT, int RTT, typename T, bool RELU>
+__device__ __forceinline__ void store_bias(const f32x4 (&acc)[NFT][RTT], const float* __restrict__ bias, T* __restrict__ ob, int ld, int nrow, int fwave, int flimit,
+                                           int li_, int g_) {
+  const int li = opaque(li_), g = opaque(g_);
+#pragma unroll
+  for (int ft = 0; ft < NFT; ++ft) {
+    const int f = fwave + ft * 16 + g * 4;
+    if (f < flimit) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + f);
+#pragma unroll
+      for (int rt = 0; rt < RTT; ++rt) {
+        const int lr = rt * 16 + li;
+        if (lr < nrow) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] = acc[ft][rt][r] + bb[r]; if (RELU) v[r] = fmaxf(v[r], 0.f); }
+          if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x4*>(ob + (int64_t)lr * ld + f) = f32x4{v[0], v[1], v[2], v[3]};
+          else *reinterpret_cast<bf16x4*>(ob + (int64_t)lr * ld + f) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        }
+      }
+    }
+  }
+}
+
+struct RowsP {
+  int R; float eps;
+  const int32_t* d_pos;
+  float* x;                        // [R, 512] fp32 residual stream (in place)
+  const bf16_t* att;               // [R, 512] attention output feeding the first product
+  const char* wstream;             // packed weight stream of this launch (model/packing.py)
+  int64_t wave_stride;             // bytes between the streams of consecutive waves
+  const float* out_b;              // bias of the attention out-projection
+  const float *ln_g, *ln_b;        // mid: norm2; ffn: norm3
+  // mid
+  const float* qbias_tab;          // [Pmax, 512]: ca_q bias + position term
+  bf16_t* q;                       // [R, 512]
+  // ffn
+  const float *ff1_b, *ff2_b;
+  // embedding prologue
+  const int32_t* seq; int seq_ld; const float *word_emb, *pos_tab, *emb_g, *emb_b;
+  // tail
+  const float *lnt_g, *lnt_b;      // next layer's norm1, or the decoder's final norm
+  const float* bias_tab;           // [Pmax, 1536]: in_proj bias + position term of q and k
+  bf16_t* qkv;                     // [R, 1536]
+  const float *h0_b, *h1_b, *h2_b;
+  float* logits; int vocab;        // [R, vocab] fp32
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// x' = x + att Wo^T + bo;  q = bf16(LayerNorm2(x') Wq^T + qbias[pos])          stream: Wo (64 fragments per wave), Wq (64)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RTT>
+__global__ __launch_bounds__(NW * 64) void dec_rows_mid_kernel(RowsP p) {
+  constexpr int RT = RTT * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile = smem;                                               // RT x A_PITCH
+  float* red = reinterpret_cast<float*>(smem + RT * A_PITCH + TILE_SLACK);      // 2 x NW x RT
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t r0 = (int64_t)blockIdx.x * RT;
+  Stream st;
+  {
+    const uint64_t bs = reinterpret_cast<uint64_t>(p.wstream + (int64_t)wave * p.wave_stride);
+    st.base = reinterpret_cast<const char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bs >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bs));
+    st.voff = lane * 16;
+  }
+  u32x4 ring[PF];
+  sfor<PF>([&](auto U) { ws_issue<decltype(U)::value>(ring, st); });
+  const int pos = *p.d_pos;
+
+  stage_rows<RTT>(p.att, r0, p.R, tile, tid);
+  lds_barrier();
+  const char* a_lane = tile + li * A_PITCH + g * 16;
+  f32x4 acc[4][RTT];
+  zero_acc(acc);
+  gemm_pass<4, 16, RTT, A_PITCH>(acc, a_lane, ring, st);
+  const int nrow = (int)((int64_t)p.R - r0 < RT ? (int64_t)p.R - r0 : RT);
+  add_bias_residual<RTT, true>(acc, p.out_b, p.x + r0 * D, nrow, wave, li, g);
+  ln_acc_to_tile<RTT>(acc, p.ln_g, p.ln_b, p.eps, tile, red, wave, li, g);
+  zero_acc(acc);
+  gemm_pass<4, 16, RTT, A_PITCH>(acc, a_lane, ring, st);
+  ws_drain(ring);
+  store_bias<4, RTT, bf16_t, false>(acc, p.qbias_tab + (int64_t)pos * D, p.q + r0 * D, D, nrow, wave * 64, D, li, g);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's run-ahead requests (PF fragments of slack behind every stream)
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PRO 0: x1 = x + att Wo^T + bo;  x' = x1 + relu(LayerNorm3(x1) W1^T + b1) W2^T + b2      stream: Wo (64), 8 x [W1 chunk (32), W2 chunk (32)]
+// PRO 1: x' = LayerNorm(word[token] + position)                                            (layer 0: no stream)
+// TAIL 0: qkv = bf16(LayerNorm1'(x') Win^T + bias_tab[pos])                                stream: 3 x 64
+// TAIL 1: logits = h2(relu(h1(relu(h0(LayerNorm_f(x'))))))                                 stream: 64, 64, then ceil(vocab / 128) passes in 512 / 128 steps
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RTT, int PRO, int TAIL>
+__global__ __launch_bounds__(NW * 64) void dec_rows_ffn_kernel(RowsP p) {
+  constexpr int RT = RTT * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile = smem;                                                   // RT x A_PITCH
+  char* hbuf = smem + RT * A_PITCH + TILE_SLACK;                       // RT x H_PITCH
+  float* red = reinterpret_cast<float*>(hbuf + RT * H_PITCH + TILE_SLACK);   // 2 x NW x RT
+  float* b1s = red + 2 * NW * RT;                                      // d_ff floats (PRO 0)
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t r0 = (int64_t)blockIdx.x * RT;
+  Stream st;
+  {
+    const uint64_t bs = reinterpret_cast<uint64_t>(p.wstream + (int64_t)wave * p.wave_stride);
+    st.base = reinterpret_cast<const char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bs >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bs));
+    st.voff = lane * 16;
+  }
+  u32x4 ring[PF];
+  sfor<PF>([&](auto U) { ws_issue<decltype(U)::value>(ring, st); });
+  const int pos = *p.d_pos;
+  const char* a_lane = tile + li * A_PITCH + g * 16;
+  const int nrow = (int)((int64_t)p.R - r0 < RT ? (int64_t)p.R - r0 : RT);
+  f32x4 acc[4][RTT];
+
+  if constexpr (PRO == 0) {
+    stage_rows<RTT>(p.att, r0, p.R, tile, tid);
+    for (int i = tid; i < 4 * D / 4; i += NW * 64) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.ff1_b)[i];
+    lds_barrier();
+    zero_acc(acc);
+    gemm_pass<4, 16, RTT, A_PITCH>(acc, a_lane, ring, st);
+    add_bias_residual<RTT, false>(acc, p.out_b, p.x + r0 * D, nrow, wave, li, g);
+    ln_acc_to_tile<RTT>(acc, p.ln_g, p.ln_b, p.eps, tile, red, wave, li, g);
+    // linear2's accumulators start as x1 + b2
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ff2_b + wave * 64 + ft * 16 + g * 4);
+#pragma unroll
+      for (int rt = 0; rt < RTT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ft][rt][r] += bb[r];
+    }
+#pragma unroll 1
+    for (int c = 0; c < 4 * D / HC; ++c) {
+      f32x4 a1[2][RTT];
+      zero_acc(a1);
+      gemm_pass<2, 16, RTT, A_PITCH>(a1, a_lane, ring, st);   // hidden units c * 256 + 32 w + 16 t + 4 g + r of the rows
+      lds_barrier();   // everybody has left linear2 of chunk c - 1: the hidden tile may be overwritten
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + c * HC + wave * 32 + t * 16 + g * 4);
+#pragma unroll
+        for (int rt = 0; rt < RTT; ++rt) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf(a1[t][rt][r] + bb[r], 0.f);
+          *reinterpret_cast<bf16x4*>(hbuf + (rt * 16 + li) * H_PITCH + (wave * 32 + t * 16 + g * 4) * 2) = o;
+        }
+      }
+      lds_barrier();   // chunk c is complete in LDS
+      gemm_pass<4, HC / 32, RTT, H_PITCH>(acc, hbuf + li * H_PITCH + g * 16, ring, st);
+    }
+    // acc = x' : back to memory (the next attention sub-layer's residual), then the tail consumes it from registers
+    {
+      const int lo = opaque(li), go = opaque(g);
+      float* xb = p.x + r0 * D;
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        const int f = wave * 64 + ft * 16 + go * 4;
+#pragma unroll
+        for (int rt = 0; rt < RTT; ++rt) {
+          const int lr = rt * 16 + lo;
+          if (lr < nrow) *reinterpret_cast<f32x4*>(xb + lr * D + f) = acc[ft][rt];
+        }
+      }
+    }
+    ln_acc_to_tile<RTT>(acc, p.lnt_g, p.lnt_b, p.eps, tile, red, wave, li, g);
+  } else {
+    // embedding + LayerNorm -> x (fp32), then the tail's LayerNorm -> operand tile: a wave per row, RT / NW rows per wave with every
+    // row's loads issued before the first row's arithmetic (one memory round trip for the lot, not one per row)
+    constexpr int RPW = RT / NW;
+    static_assert(RT % NW == 0, "rows per wave");
+    f32x4 ev[RPW][4];
+    bool live[RPW];
+    int64_t rr[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      int64_t r = r0 + wave * RPW + i;
+      live[i] = r < p.R;
+      if (!live[i]) r = p.R - 1;
+      rr[i] = r;
+      const int tok = p.seq[r * p.seq_ld + pos];
+      const float* we = p.word_emb + (int64_t)tok * D + lane * 8;
+      const float* pe = p.pos_tab + (int64_t)pos * D + lane * 8;
+      ev[i][0] = *reinterpret_cast<const f32x4*>(we); ev[i][1] = *reinterpret_cast<const f32x4*>(we + 4);
+      ev[i][2] = *reinterpret_cast<const f32x4*>(pe); ev[i][3] = *reinterpret_cast<const f32x4*>(pe + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = ev[i][0][j] + ev[i][2][j]; v[j + 4] = ev[i][1][j] + ev[i][3][j]; }
+      ln_row512(v, p.emb_g, p.emb_b, lane, p.eps);
+      if (live[i]) {
+        *reinterpret_cast<f32x4*>(p.x + rr[i] * D + lane * 8) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p.x + rr[i] * D + lane * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      }
+      ln_row512(v, p.lnt_g, p.lnt_b, lane, p.eps);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+      *reinterpret_cast<bf16x8*>(tile + (wave * RPW + i) * A_PITCH + lane * 16) = o;
+    }
+    lds_barrier();
+  }
+
+  if constexpr (TAIL == 0) {
+    auto qkv_pass = [&](int ps, auto LAST) {
+      zero_acc(acc);
+      gemm_pass<4, 16, RTT, A_PITCH>(acc, a_lane, ring, st);
+      if constexpr (decltype(LAST)::value) ws_drain(ring);
+      store_bias<4, RTT, bf16_t, false>(acc, p.bias_tab + (int64_t)pos * (3 * D) + ps * D, p.qkv + r0 * (3 * D) + ps * D, 3 * D, nrow, wave * 64, D, li, g);
+    };
+#pragma unroll 1
+    for (int ps = 0; ps < 2; ++ps) qkv_pass(ps, std::false_type());
+    qkv_pass(2, std::true_type());
+  } else {
+    // prediction head (block/mlp.py:11-13): two hidden layers with ReLU through the operand tile, then the vocabulary projection
+#pragma unroll 1
+    for (int hl = 0; hl < 2; ++hl) {
+      zero_acc(acc);
+      gemm_pass<4, 16, RTT, A_PITCH>(acc, a_lane, ring, st);
+      lds_barrier();   // every wave has read the tile: it may be overwritten
+      const float* hb_ = hl == 0 ? p.h0_b : p.h1_b;
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        const int f = wave * 64 + ft * 16 + g * 4;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(hb_ + f);
+#pragma unroll
+        for (int rt = 0; rt < RTT; ++rt) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf(acc[ft][rt][r] + bb[r], 0.f);
+          *reinterpret_cast<bf16x4*>(tile + (rt * 16 + li) * A_PITCH + f * 2) = o;
+        }
+      }
+      lds_barrier();
+    }
+    const int V = p.vocab, vpad = (V + 127) / 128 * 128;
+    const int n512 = vpad / 512, n128 = (vpad - n512 * 512) / 128;
+#pragma unroll 1
+    for (int ps = 0; ps < n512; ++ps) {
+      zero_acc(acc);
+      gemm_pass<4, 16, RTT, A_PITCH>(acc, a_lane, ring, st);
+      ws_drain(ring);   // (after EVERY vocabulary pass: which one is the last depends on the vocabulary; once per step, ~0.5 us each)
+      // vocab % 4 == 0 (checked by the host): a quad of features is live or dead as a whole
+      store_bias<4, RTT, float, false>(acc, p.h2_b, p.logits + r0 * V, V, nrow, ps * 512 + wave * 64, V, li, g);
+    }
+#pragma unroll 1
+    for (int ps = 0; ps < n128; ++ps) {
+      f32x4 a1[1][RTT];
+      zero_acc(a1);
+      gemm_pass<1, 16, RTT, A_PITCH>(a1, a_lane, ring, st);
+      ws_drain(ring);
+      store_bias<1, RTT, float, false>(a1, p.h2_b, p.logits + r0 * V, V, nrow, n512 * 512 + ps * 128 + wave * 16, V, li, g);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same chain for the MLP half of a Swin block at C = 512 (stage 2 of Swin-B: 18 of the 24 blocks, 60 % of the encoder):
+//     x = x + fc2(GELU(fc1(LayerNorm(x))))          swin_transformer.py:250 with Mlp.forward (:30-36) inlined
+// Round 4 ran it as LayerNorm + fc1 (GELU epilogue) + fc2 (fp32 residual epilogue): three launches, the [tokens, 2048] hidden tensor and
+// the normalised rows through HBM, 0.70 + 0.92 PFLOP/s on the two products.  Here a workgroup owns 80 tokens: LayerNorm from the fp32
+// residual stream into the operand tile (a wave per row), linear2's accumulators start as x + b2, the hidden activations of a chunk
+// of 256 units go through LDS, only x is read and written.  stream: 8 x [fc1 chunk (32 fragments per wave), fc2 chunk (32)].
+// ---------------------------------------------------------------------------------------------------------------------
+struct MlpRowsP {
+  float* x; int64_t M;
+  const float *ln_g, *ln_b; float eps;
+  const char* wstream; int64_t wave_stride;
+  const float *b1, *b2;
+};
+
+template <int RTT>
+__global__ __launch_bounds__(NW * 64) void swin_rows_mlp_kernel(MlpRowsP p) {
+  constexpr int RT = RTT * 16, RPW = RT / NW;
+  static_assert(RT % NW == 0, "rows per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile = smem;                                                          // RT x A_PITCH
+  char* hbuf = smem + RT * A_PITCH + TILE_SLACK;                              // RT x H_PITCH
+  float* b1s = reinterpret_cast<float*>(hbuf + RT * H_PITCH + TILE_SLACK);    // 2048 floats
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t r0 = (int64_t)blockIdx.x * RT;
+  Stream st;
+  {
+    const uint64_t bs = reinterpret_cast<uint64_t>(p.wstream + (int64_t)wave * p.wave_stride);
+    st.base = reinterpret_cast<const char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bs >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bs));
+    st.voff = lane * 16;
+  }
+  u32x4 ring[PF];
+  sfor<PF>([&](auto U) { ws_issue<decltype(U)::value>(ring, st); });
+  const int nrow = (int)(p.M - r0 < RT ? p.M - r0 : RT);
+  float* xb = p.x + r0 * D;
+  {
+    // LayerNorm: a wave per row, every row's loads first
+    f32x4 xv[RPW][2];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      int lr = wave * RPW + i;
+      if (lr > nrow - 1) lr = nrow - 1;
+      xv[i][0] = *reinterpret_cast<const f32x4*>(xb + lr * D + lane * 8);
+      xv[i][1] = *reinterpret_cast<const f32x4*>(xb + lr * D + lane * 8 + 4);
+    }
+    for (int i = tid; i < 4 * D / 4; i += NW * 64) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      float v[8] = {xv[i][0][0], xv[i][0][1], xv[i][0][2], xv[i][0][3], xv[i][1][0], xv[i][1][1], xv[i][1][2], xv[i][1][3]};
+      ln_row512(v, p.ln_g, p.ln_b, lane, p.eps);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+      *reinterpret_cast<bf16x8*>(tile + (wave * RPW + i) * A_PITCH + lane * 16) = o;
+    }
+  }
+  lds_barrier();
+  const char* a_lane = tile + li * A_PITCH + g * 16;
+  f32x4 acc[4][RTT];
+  zero_acc(acc);
+  add_bias_residual<RTT, false>(acc, p.b2, xb, nrow, wave, li, g);   // fc2's accumulators start as x + b2 (the rows are L2 hits now)
+#pragma unroll 1
+  for (int c = 0; c < 4 * D / HC; ++c) {
+    f32x4 a1[2][RTT];
+    zero_acc(a1);
+    gemm_pass<2, 16, RTT, A_PITCH>(a1, a_lane, ring, st);
+    lds_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + c * HC + wave * 32 + t * 16 + g * 4);
+#pragma unroll
+      for (int rt = 0; rt < RTT; ++rt) {
+        float hv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = a1[t][rt][r] + bb[r];
+        gelu_fast_n<4>(hv);   // the bf16 engine's GELU on every epilogue path (common.h): a value does not depend on the kernel that produced it
+        *reinterpret_cast<bf16x4*>(hbuf + (rt * 16 + li) * H_PITCH + (wave * 32 + t * 16 + g * 4) * 2) = bf16x4{(bf16_t)hv[0], (bf16_t)hv[1], (bf16_t)hv[2], (bf16_t)hv[3]};
+      }
+    }
+    lds_barrier();
+    gemm_pass<4, HC / 32, RTT, H_PITCH>(acc, hbuf + li * H_PITCH + g * 16, ring, st);
+  }
+  ws_drain(ring);
+  {
+    const int lo = opaque(li), go = opaque(g);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const int f = wave * 64 + ft * 16 + go * 4;
+#pragma unroll
+      for (int rt = 0; rt < RTT; ++rt) {
+        const int lr = rt * 16 + lo;
+        if (lr < nrow) *reinterpret_cast<f32x4*>(xb + lr * D + f) = acc[ft][rt];
+      }
+    }
+  }
+}
+
+constexpr int RTT_DEFAULT = 5;   // 80 rows per workgroup: 10 240 rows = 128 workgroups, two decoder streams fill the chip side by side
+
+template <typename K>
+int raise_lds(K kern, const char* what) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+    omp_set_error("%s: cannot raise dynamic LDS limit", what);
+    return OMP_ERR_LAUNCH;
+  }
+  return OMP_OK;
+}
+
+template <int PRO, int TAIL>
+int launch_ffn(const RowsP& p, hipStream_t st) {
+  constexpr int RTT = RTT_DEFAULT, RT = RTT * 16;
+  const size_t smem = (size_t)RT * A_PITCH + TILE_SLACK + RT * H_PITCH + TILE_SLACK + 2 * NW * RT * 4 + 4 * D * 4;
+  auto kern = dec_rows_ffn_kernel<RTT, PRO, TAIL>;
+  static bool done = false;   // per instantiation
+  if (!done) {
+    const int rc = raise_lds(kern, "omp_dec_rows_ffn");
+    if (rc != OMP_OK) return rc;
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((p.R + RT - 1) / RT), dim3(NW * 64), smem, st, p);
+  OMP_CHECK_LAUNCH("omp_dec_rows_ffn");
+  return OMP_OK;
+}
+
+}  // namespace
+
+int omp_rows_tile() { return RTT_DEFAULT * 16; }
+
+extern "C" int omp_dec_rows_mid(const omp_dec_rows_args* a, omp_stream_t s) {
+  OMP_CHECK_ARG(a != nullptr, "omp_dec_rows_mid: null argument block");
+  OMP_CHECK_ARG(a->R > 0 && a->d_pos && a->x && a->att && a->wstream && a->out_b && a->ln_g && a->ln_b && a->qbias_tab && a->q, "omp_dec_rows_mid: null pointer");
+  OMP_CHECK_ARG(a->wave_stride >= 128 * 1024 && a->wave_stride % 16 == 0 && ((uintptr_t)a->wstream % 16) == 0, "omp_dec_rows_mid: a wave's stream holds 128 fragments of 1 KB");
+  RowsP p{};
+  p.R = a->R; p.eps = a->eps; p.d_pos = a->d_pos; p.x = a->x; p.att = reinterpret_cast<const bf16_t*>(a->att);
+  p.wstream = reinterpret_cast<const char*>(a->wstream); p.wave_stride = a->wave_stride;
+  p.out_b = a->out_b; p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.qbias_tab = a->qbias_tab; p.q = reinterpret_cast<bf16_t*>(a->q);
+  constexpr int RTT = RTT_DEFAULT, RT = RTT * 16;
+  const size_t smem = (size_t)RT * A_PITCH + TILE_SLACK + 2 * NW * RT * 4;
+  auto kern = dec_rows_mid_kernel<RTT>;
+  static bool done = false;
+  if (!done) {
+    const int rc = raise_lds(kern, "omp_dec_rows_mid");
+    if (rc != OMP_OK) return rc;
+    done = true;
+  }
+  const int slot = omp_prof_active(OMP_PROF_ROWS) ? omp_prof_begin(OMP_PROF_ROWS, (hipStream_t)s, 4.0 * (double)a->R * D * D, (double)a->R * D * (2 + 4 + 4 + 2) + 2.0 * D * D * 2) : -1;
+  hipLaunchKernelGGL(kern, dim3((p.R + RT - 1) / RT), dim3(NW * 64), smem, (hipStream_t)s, p);
+  if (slot >= 0) omp_prof_end(OMP_PROF_ROWS, slot, (hipStream_t)s);
+  OMP_CHECK_LAUNCH("omp_dec_rows_mid");
+  return OMP_OK;
+}
+
+extern "C" int omp_dec_rows_ffn(const omp_dec_rows_args* a, omp_stream_t s) {
+  OMP_CHECK_ARG(a != nullptr, "omp_dec_rows_ffn: null argument block");
+  OMP_CHECK_ARG(a->R > 0 && a->d_pos && a->x && a->wstream && a->lnt_g && a->lnt_b, "omp_dec_rows_ffn: null pointer");
+  OMP_CHECK_ARG(a->prologue == 0 || a->prologue == 1, "omp_dec_rows_ffn: prologue must be 0 (attention out-projection + FFN) or 1 (embedding)");
+  OMP_CHECK_ARG(a->tail == 0 || a->tail == 1, "omp_dec_rows_ffn: tail must be 0 (next layer's q | k | v) or 1 (prediction head)");
+  if (a->prologue == 0) OMP_CHECK_ARG(a->att && a->out_b && a->ln_g && a->ln_b && a->ff1_b && a->ff2_b, "omp_dec_rows_ffn: null pointer (attention / FFN part)");
+  else OMP_CHECK_ARG(a->seq && a->word_emb && a->pos_tab && a->emb_g && a->emb_b && a->seq_ld > 0, "omp_dec_rows_ffn: null pointer (embedding part)");
+  if (a->tail == 0) OMP_CHECK_ARG(a->bias_tab && a->qkv, "omp_dec_rows_ffn: null pointer (q | k | v tail)");
+  else OMP_CHECK_ARG(a->h0_b && a->h1_b && a->h2_b && a->logits && a->vocab > 0 && a->vocab % 4 == 0, "omp_dec_rows_ffn: prediction-head tail needs its biases, logits and vocab %% 4 == 0");
+  const int vpad = (a->vocab + 127) / 128 * 128;
+  const int64_t frags = (a->prologue == 0 ? 64 + 16 * 32 : 0) + (a->tail == 0 ? 192 : 128 + (vpad / 512) * 64 + ((vpad % 512) / 128) * 16);
+  OMP_CHECK_ARG(a->wave_stride >= frags * 1024 && a->wave_stride % 16 == 0 && ((uintptr_t)a->wstream % 16) == 0, "omp_dec_rows_ffn: a wave's stream holds %lld fragments of 1 KB here", (long long)frags);
+  RowsP p{};
+  p.R = a->R; p.eps = a->eps; p.d_pos = a->d_pos; p.x = a->x; p.att = reinterpret_cast<const bf16_t*>(a->att);
+  p.wstream = reinterpret_cast<const char*>(a->wstream); p.wave_stride = a->wave_stride;
+  p.out_b = a->out_b; p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.ff1_b = a->ff1_b; p.ff2_b = a->ff2_b;
+  p.seq = a->seq; p.seq_ld = a->seq_ld; p.word_emb = a->word_emb; p.pos_tab = a->pos_tab; p.emb_g = a->emb_g; p.emb_b = a->emb_b;
+  p.lnt_g = a->lnt_g; p.lnt_b = a->lnt_b; p.bias_tab = a->bias_tab; p.qkv = reinterpret_cast<bf16_t*>(a->qkv);
+  p.h0_b = a->h0_b; p.h1_b = a->h1_b; p.h2_b = a->h2_b; p.logits = a->logits; p.vocab = a->vocab;
+  hipStream_t st = (hipStream_t)s;
+  const double fl = 2.0 * (double)a->R * D * ((a->prologue == 0 ? D + 8.0 * D : 0.0) + (a->tail == 0 ? 3.0 * D : 2.0 * D + a->vocab));
+  const int slot = omp_prof_active(OMP_PROF_ROWS) ? omp_prof_begin(OMP_PROF_ROWS, st, fl, (double)a->R * D * (2 + 4 + 4) + (double)a->R * (a->tail == 0 ? 3 * D * 2 : a->vocab * 4) + (double)frags * 8192) : -1;
+  int rc;
+  if (a->prologue == 0) rc = a->tail == 0 ? launch_ffn<0, 0>(p, st) : launch_ffn<0, 1>(p, st);
+  else rc = a->tail == 0 ? launch_ffn<1, 0>(p, st) : launch_ffn<1, 1>(p, st);
+  if (slot >= 0) omp_prof_end(OMP_PROF_ROWS, slot, st);
+  return rc;
+}
+
+extern "C" int omp_dec_rows_tile(void) { return omp_rows_tile(); }
+
+extern "C" int omp_swin_mlp_rows(float* x, int64_t M, const float* ln_gamma, const float* ln_beta, float eps, const void* wstream, int64_t wave_stride,
+                                 const float* b1, const float* b2, omp_stream_t s) {
+  OMP_CHECK_ARG(x && ln_gamma && ln_beta && wstream && b1 && b2, "omp_swin_mlp_rows: null pointer");
+  OMP_CHECK_ARG(M > 0 && M < (1ll << 31), "omp_swin_mlp_rows: bad M=%lld", (long long)M);
+  OMP_CHECK_ARG(wave_stride >= 512 * 1024 && wave_stride % 16 == 0 && ((uintptr_t)wstream % 16) == 0 && ((uintptr_t)x % 16) == 0, "omp_swin_mlp_rows: a wave's stream holds 512 fragments of 1 KB; 16-byte aligned pointers");
+  MlpRowsP p{};
+  p.x = x; p.M = M; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.eps = eps; p.wstream = reinterpret_cast<const char*>(wstream); p.wave_stride = wave_stride;
+  p.b1 = b1; p.b2 = b2;
+  constexpr int RTT = RTT_DEFAULT, RT = RTT * 16;
+  const size_t smem = (size_t)RT * A_PITCH + TILE_SLACK + RT * H_PITCH + TILE_SLACK + 4 * D * 4;
+  auto kern = swin_rows_mlp_kernel<RTT>;
+  static bool done = false;
+  if (!done) {
+    const int rc = raise_lds(kern, "omp_swin_mlp_rows");
+    if (rc != OMP_OK) return rc;
+    done = true;
+  }
+  hipStream_t st = (hipStream_t)s;
+  const int slot = omp_prof_active(OMP_PROF_MLP) ? omp_prof_begin(OMP_PROF_MLP, st, 4.0 * (double)M * D * 4 * D, 8.0 * (double)M * D + 4.0 * D * 4 * D) : -1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((M + RT - 1) / RT)), dim3(NW * 64), smem, st, p);
+  if (slot >= 0) omp_prof_end(OMP_PROF_MLP, slot, st);
+  OMP_CHECK_LAUNCH("omp_swin_mlp_rows");
+  return OMP_OK;
+}

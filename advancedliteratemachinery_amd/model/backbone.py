@@ -21,17 +21,23 @@ Engine precisions (model/omniparser.py `engine_dtype`):
 import torch
 
 from .. import ops
-from .packing import pack_attn_block, pack_mlp
+import os
+
+from .packing import pack_attn_block, pack_mlp, pack_rows_mlp
 
 LN_EPS = 1e-5
 # stages whose MLP runs as ONE fused launch in the bf16 engine (csrc/mlp.hip); at C >= 512 the row-stationary kernel is
 # bound by its weight stream and the two GEMMs win (profiles/r02c_kbench_mlp.txt)
 FUSED_MLP_WIDTHS = (128, 256)
+# C = 512 (stage 2 of Swin-B: 18 of the 24 blocks): the MLP half as a ROW-OWNER chain (csrc/dec_rows.hip::swin_rows_mlp_kernel, round 5) once a
+# launch has at least this many tokens -- 899 -> 646 us per block at the encoder's 131 072-token chunks, equal at 32 768, slower below
+# (a workgroup streams the block's 4 MB of weights for its 80 tokens: it needs several workgroups per compute unit to pay)
+ROWS_MLP_MIN_TOKENS = int(os.environ.get('OMP355_MLP_ROWS_MIN', '32768'))
 
 
 class _Block(object):
     __slots__ = ('n1g', 'n1b', 'qkv_w', 'qkv_b', 'table', 'proj_w', 'proj_b', 'n2g', 'n2b', 'fc1_w',
-                 'fc1_b', 'fc2_w', 'fc2_b', 'shift', 'mlp_pack', 'bias_exp', 'attn_fused', 'attn_pack')
+                 'fc1_b', 'fc2_w', 'fc2_b', 'shift', 'mlp_pack', 'bias_exp', 'attn_fused', 'attn_pack', 'mlp_rows')
 
 
 class _Stage(object):
@@ -94,6 +100,8 @@ class Encoder(object):
                 fuse = (dtype == torch.bfloat16 and st.C in FUSED_MLP_WIDTHS and blk.fc1_w.shape[0] % 32 == 0
                         and getattr(args, 'fused_mlp', True))
                 blk.mlp_pack = pack_mlp(blk.fc1_w, blk.fc1_b, blk.fc2_w) if fuse else None
+                blk.mlp_rows = (pack_rows_mlp(blk.fc1_w, blk.fc2_w) if (dtype == torch.bfloat16 and not self.x3 and st.C == 512 and blk.fc1_w.shape == (2048, 512)
+                                                                     and getattr(args, 'fused_mlp', True)) else None)
                 # norm1 + qkv + (S)W-MSA + proj + residual in one launch where the kernel is built (C = 128 with 4 heads: Swin-B stage 0)
                 blk.attn_fused = (dtype == torch.bfloat16 and not self.x3 and st.C == 128 and nh == 4 and self.window == 7
                                   and getattr(args, 'fused_attn', True))
@@ -196,6 +204,8 @@ class Encoder(object):
                     self._gemm(att, blk.proj_w, blk.proj_b, residual=x, out=x)
                 if blk.mlp_pack is not None:   # norm2 + fc1 + GELU + fc2 + residual in one launch, in place
                     ops.swin_mlp_fused(x, blk.n2g, blk.n2b, blk.mlp_pack, blk.fc2_b, out=x, eps=LN_EPS)
+                elif blk.mlp_rows is not None and x.shape[0] >= ROWS_MLP_MIN_TOKENS:   # the same sub-layer as a row-owner chain (C = 512)
+                    ops.swin_mlp_rows(x, blk.n2g, blk.n2b, blk.mlp_rows[0], blk.mlp_rows[1], blk.fc1_b, blk.fc2_b, eps=LN_EPS)
                 else:
                     if y is None:
                         y = self._rows(x.shape[0], C, T, x.device)

@@ -85,3 +85,115 @@ def pack_attn_block(qkv_w, proj_w, n_heads):
     # proj_w[w][nt][li][ks][g][e] -> [w][nt][ks][g][li][e]
     p = proj_w.reshape(n_heads, 2, 16, KS, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
     return torch.cat([q.reshape(-1), p.reshape(-1)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Row-owner chains of the decoders' many-row phases (csrc/dec_rows.hip, include/omp355.h: omp_dec_rows_mid / omp_dec_rows_ffn)
+#
+# A workgroup's 8 waves each walk ONE linear stream of 1 KB matrix-core fragments: for a product with N output features over K,
+# wave w owns features 64 w + 16 t (t = 0..3) of every 512-feature pass (16 w of a 128-feature pass) and consumes, k-step by
+# k-step, the fragment of each of its feature tiles:  fragment[lane = 16 g + li][8] = W[f0 + li][32 ks + 8 g .. + 8].
+# The packers below write those fragments in consumption order, wave-major: buffer = [8 waves][fragments of the chain][64 lanes][8]
+# bf16 + 8 KB of slack (the kernels' register ring of 8 fragments in flight runs ahead of the stream's end).  Pure index permutation.
+# ---------------------------------------------------------------------------------------------------------------------
+ROWS_WAVES = 8
+ROWS_SLACK = 8 * 1024
+
+
+def _rows_pass(w, per_wave_tiles):
+    """w [16 * 8 * per_wave_tiles, K] (one pass: the features of wave 0's tiles first, then wave 1's ...) -> [8 waves][K / 32 k-steps]
+    [tiles][64 lanes][8]: the pass's fragments in the order every wave consumes its own."""
+    n, K = w.shape
+    t = per_wave_tiles
+    if n != 16 * ROWS_WAVES * t or K % 32:
+        raise ValueError('_rows_pass: %d features x %d are not %d waves x %d tiles of 16 x k-steps of 32' % (n, K, ROWS_WAVES, t))
+    # w[wave][tile][li][ks][g][e] -> [wave][ks][tile][g][li][e]
+    return w.reshape(ROWS_WAVES, t, 16, K // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(ROWS_WAVES, (K // 32) * t, 512)
+
+
+def _rows_product(w):
+    """Fragments of y = a W^T for W [N, K], N a multiple of 128: 512-feature passes (4 tiles per wave), then 128-feature passes (1 tile
+    per wave), each over the whole K.  -> list of [8][fragments][512] pieces."""
+    N = w.shape[0]
+    if N % 128:
+        raise ValueError('_rows_product: %d output features are not a multiple of 128' % N)
+    out, f = [], 0
+    while N - f >= 512:
+        out.append(_rows_pass(w[f:f + 512], 4))
+        f += 512
+    while f < N:
+        out.append(_rows_pass(w[f:f + 128], 1))
+        f += 128
+    return out
+
+
+def _rows_finish(pieces):
+    """[8][n_i][512] pieces -> (uint8 buffer, bytes per wave)."""
+    s = torch.cat(pieces, dim=1).contiguous()            # [8 waves][fragments][512 bf16]
+    per_wave = s.shape[1] * 1024
+    buf = torch.zeros(ROWS_WAVES * per_wave + ROWS_SLACK, dtype=torch.uint8, device=s.device)
+    buf[:ROWS_WAVES * per_wave] = s.view(torch.uint8).reshape(-1)
+    return buf, per_wave
+
+
+def _bf16(*ws):
+    for w in ws:
+        if w.dtype != torch.bfloat16:
+            raise TypeError('the row-owner chains take bf16 matrices')
+
+
+def pack_rows_mid(sa_out_w, ca_q_w):
+    """omp_dec_rows_mid: self_attn.out_proj [512, 512], then the query rows of multihead_attn.in_proj [512, 512]."""
+    _bf16(sa_out_w, ca_q_w)
+    return _rows_finish(_rows_product(sa_out_w) + _rows_product(ca_q_w))
+
+
+def _rows_ffn_pieces(ca_out_w, ff1_w, ff2_w, chunk=256):
+    _bf16(ca_out_w, ff1_w, ff2_w)
+    Hd, C = ff1_w.shape
+    if ff2_w.shape != (C, Hd) or Hd % chunk or C != 512:
+        raise ValueError('pack_rows_ffn: unsupported shapes %s / %s' % (tuple(ff1_w.shape), tuple(ff2_w.shape)))
+    pieces = _rows_product(ca_out_w)
+    for c in range(Hd // chunk):      # per chunk of 256 hidden units: linear1's pass (N = 256: TWO tiles per wave, K = 512), then linear2's (N = 512, K = 256)
+        pieces.append(_rows_pass(ff1_w[c * chunk:(c + 1) * chunk], chunk // (16 * ROWS_WAVES)))
+        pieces += _rows_product(ff2_w[:, c * chunk:(c + 1) * chunk].contiguous())
+    return pieces
+
+
+def pack_rows_ffn_qkv(ca_out_w, ff1_w, ff2_w, next_sa_in_w):
+    """omp_dec_rows_ffn(prologue 0, tail 0): multihead_attn.out_proj, linear1 / linear2 in chunks, then the NEXT layer's self_attn.in_proj [1536, 512]."""
+    _bf16(next_sa_in_w)
+    return _rows_finish(_rows_ffn_pieces(ca_out_w, ff1_w, ff2_w) + _rows_product(next_sa_in_w))
+
+
+def _rows_head_pieces(h0_w, h1_w, h2_w):
+    _bf16(h0_w, h1_w, h2_w)
+    V = h2_w.shape[0]
+    vpad = (V + 127) // 128 * 128
+    if vpad != V:
+        h2_w = torch.cat([h2_w, torch.zeros(vpad - V, h2_w.shape[1], dtype=h2_w.dtype, device=h2_w.device)], 0)
+    return _rows_product(h0_w) + _rows_product(h1_w) + _rows_product(h2_w)
+
+
+def pack_rows_ffn_head(ca_out_w, ff1_w, ff2_w, h0_w, h1_w, h2_w):
+    """omp_dec_rows_ffn(prologue 0, tail 1): the last layer's chain, then the 3-layer prediction head (vocabulary rows zero-padded to x128)."""
+    return _rows_finish(_rows_ffn_pieces(ca_out_w, ff1_w, ff2_w) + _rows_head_pieces(h0_w, h1_w, h2_w))
+
+
+def pack_rows_embed_qkv(sa_in_w):
+    """omp_dec_rows_ffn(prologue 1, tail 0): layer 0's self_attn.in_proj behind the embedding."""
+    _bf16(sa_in_w)
+    return _rows_finish(_rows_product(sa_in_w))
+
+
+def pack_rows_mlp(fc1_w, fc2_w, chunk=256):
+    """omp_swin_mlp_rows: fc1 [2048, 512] / fc2 [512, 2048] of a Swin stage-2 block, per chunk of 256 hidden units fc1's pass then fc2's."""
+    _bf16(fc1_w, fc2_w)
+    Hd, C = fc1_w.shape
+    if fc2_w.shape != (C, Hd) or Hd != 4 * C or C != 512:
+        raise ValueError('pack_rows_mlp: the row-owner MLP chain is built for C = 512, hidden 2048 (got %s / %s)' % (tuple(fc1_w.shape), tuple(fc2_w.shape)))
+    pieces = []
+    for c in range(Hd // chunk):
+        pieces.append(_rows_pass(fc1_w[c * chunk:(c + 1) * chunk], chunk // (16 * ROWS_WAVES)))
+        pieces += _rows_product(fc2_w[:, c * chunk:(c + 1) * chunk].contiguous())
+    return _rows_finish(pieces)

@@ -19,6 +19,7 @@ from collections import OrderedDict
 import torch
 
 from .. import _lib, ops
+from . import packing
 
 KINDS = ('pt', 'poly', 'rec')
 KIND_ID = {'pt': _lib.DEC_PT, 'poly': _lib.DEC_POLY, 'rec': _lib.DEC_REC}
@@ -191,9 +192,31 @@ class Decoder(object):
             self.Wk_all, self.bk_all = mat(torch.cat(wk, 0)), torch.cat(bk, 0).contiguous()
             self.Wv_all, self.bv_all = mat(torch.cat(wv, 0)), torch.cat(bv, 0).contiguous()
         self.NL = len(KINDS) * self.L
+        self._rows_cache = {}   # kind -> packed weight streams of the row-owner chains (bf16 engine, many-row phases)
+        self.rows_min = self.ROWS_MIN_ROWS
         self._x3_cache = {}   # kind -> (layers, head) with every matrix as its [w_hi | w_hi | w_lo] image (bf16x3 engine, R > 64)
 
     X3_MIN_ROWS = 65    # phases with more rows run their products as split-bf16 products (csrc/decoder.hip: step_launch_x3)
+    # bf16 engine: phases with at least this many rows run their Linear layers as row-owner chains (csrc/dec_rows.hip: 80 rows per
+    # workgroup, weights streamed from L2): from ~50 workgroups on they beat the launch-per-Linear path (profiles/r05*_kbench_dec_rows*)
+    ROWS_MIN_ROWS = int(os.environ.get('OMP355_ROWS_MIN', '4096'))
+
+    def _rows_streams(self, kind):
+        """Packed weight streams of decoder `kind` for the row-owner chains, built on first use (model/packing.py::pack_rows_*):
+        (embed, [(mid, ffn) per layer]); the last layer's ffn stream ends in the prediction head."""
+        if kind not in self._rows_cache:
+            Ls, hd = self.layers[kind], self.head[kind]
+            embed = packing.pack_rows_embed_qkv(Ls[0]['sa_in_w'])[0]
+            per = []
+            for l, w in enumerate(Ls):
+                mid = packing.pack_rows_mid(w['sa_out_w'], w['ca_q_w'])[0]
+                if l + 1 < len(Ls):
+                    ffn = packing.pack_rows_ffn_qkv(w['ca_out_w'], w['ff1_w'], w['ff2_w'], Ls[l + 1]['sa_in_w'])[0]
+                else:
+                    ffn = packing.pack_rows_ffn_head(w['ca_out_w'], w['ff1_w'], w['ff2_w'], hd[0][0], hd[1][0], hd[2][0])[0]
+                per.append((mid, ffn))
+            self._rows_cache[kind] = (embed, per)
+        return self._rows_cache[kind]
 
     def _x3_weights(self, kind):
         """[out, 3 in] bf16 images of decoder `kind`'s matrices, built on first use (the fp32 masters stay bound for the
@@ -279,6 +302,14 @@ class Decoder(object):
         use_x3 = bool(self.x3 and a.tfm_pre_norm and ph.R >= self.X3_MIN_ROWS and d % 64 == 0 and self.ff % 64 == 0)
         P.gemm_x3 = 1 if use_x3 else 0
         P.kv_split = 1 if self.kv_split else 0
+        use_rows = bool(self.dtype == torch.bfloat16 and a.tfm_pre_norm and ph.R >= self.rows_min and d == 512 and self.ff == 2048 and self.nH == 8
+                        and self.V % 4 == 0)
+        P.rows_fused = 1 if use_rows else 0
+        if use_rows:
+            r_embed, r_layers = self._rows_streams(ph.kind)
+            P.rows_embed = r_embed.data_ptr()
+        else:
+            P.rows_embed = None
         x3_layers, x3_head = self._x3_weights(ph.kind) if use_x3 else (None, None)
         P.R, P.Lmax, P.M, P.Mpad, P.n_tiles, P.q_tiles, P.n_split, P.n_prompt = (ph.R, ph.Lmax, kv['M'], kv['Mpad'], len(tiles), qt,
                                                                                  ph.n_split, n_prompt)
@@ -295,6 +326,7 @@ class Decoder(object):
                          'ca_out_b', 'ff1_w', 'ff1_b', 'ff2_w', 'ff2_b', 'n1_g', 'n1_b', 'n2_g', 'n2_b', 'n3_g', 'n3_b'):
                 setattr(Lc, name, (x3_layers[l][name] if use_x3 and name in x3_layers[l] else w[name]).data_ptr())
             Lc.kcache, Lc.vcache = ph.kc[l].data_ptr(), ph.vc[l].data_ptr()
+            Lc.rows_mid, Lc.rows_ffn = (r_layers[l][0].data_ptr(), r_layers[l][1].data_ptr()) if use_rows else (None, None)
             off = (kidx * self.L + l) * slab * esz
             Lc.crossK = kv['K'].data_ptr() + off
             Lc.crossVt = kv['Vt'].data_ptr() + off

@@ -475,3 +475,56 @@ def swin_attn_impl(which):
 def swin_mlp_variant(v):
     """debug/testing: alternative (rows per wave, waves per workgroup, ring depth) instantiations of the fused MLP kernel."""
     _lib.check(_lib.lib().omp_debug_swin_mlp_variant(int(v)), 'omp_debug_swin_mlp_variant')
+
+
+def dec_rows_mid(att, x, wstream, wave_stride, out_b, ln_g, ln_b, qbias_tab, d_pos, q=None, eps=1e-5):
+    """x += att Wo^T + bo;  q = bf16(LayerNorm(x) Wq^T + qbias_tab[*d_pos])  -- one launch, a workgroup owns 80 rows (include/omp355.h)."""
+    R = x.shape[0]
+    if q is None:
+        q = torch.empty((R, 512), dtype=torch.bfloat16, device=x.device)
+    a = _lib.DecRowsArgs()
+    a.R, a.eps, a.d_pos, a.x, a.att = R, float(eps), ptr(d_pos), ptr(_c(x, 'x')), ptr(_c(att, 'att'))
+    a.wstream, a.wave_stride = ptr(wstream), int(wave_stride)
+    a.out_b, a.ln_g, a.ln_b, a.qbias_tab, a.q = ptr(out_b), ptr(ln_g), ptr(ln_b), ptr(qbias_tab), ptr(q)
+    _lib.check(_lib.lib().omp_dec_rows_mid(ctypes.byref(a), stream()), 'omp_dec_rows_mid')
+    return q
+
+
+def dec_rows_ffn(x, wstream, wave_stride, d_pos, lnt_g, lnt_b, att=None, out_b=None, ln_g=None, ln_b=None, ff1_b=None, ff2_b=None,
+                 embed=None, bias_tab=None, qkv=None, head_b=None, logits=None, vocab=0, eps=1e-5):
+    """The chain behind the cross-attention (or, embed=(seq, word_emb, pos_tab, emb_g, emb_b), the embedding of layer 0) and its tail:
+    bias_tab given -> the next layer's q | k | v (bf16 [R, 1536]); head_b=(b0, b1, b2) -> the prediction head's logits (fp32 [R, vocab])."""
+    R = x.shape[0]
+    a = _lib.DecRowsArgs()
+    a.R, a.eps, a.d_pos, a.x = R, float(eps), ptr(d_pos), ptr(_c(x, 'x'))
+    a.wstream, a.wave_stride = ptr(wstream), int(wave_stride)
+    a.lnt_g, a.lnt_b = ptr(lnt_g), ptr(lnt_b)
+    if embed is not None:
+        seq, word, pos_tab, eg, eb = embed
+        a.prologue, a.seq, a.seq_ld, a.word_emb, a.pos_tab, a.emb_g, a.emb_b = 1, ptr(seq), seq.stride(0), ptr(word), ptr(pos_tab), ptr(eg), ptr(eb)
+    else:
+        a.prologue, a.att = 0, ptr(_c(att, 'att'))
+        a.out_b, a.ln_g, a.ln_b, a.ff1_b, a.ff2_b = ptr(out_b), ptr(ln_g), ptr(ln_b), ptr(ff1_b), ptr(ff2_b)
+    if head_b is None:
+        if qkv is None:
+            qkv = torch.empty((R, 1536), dtype=torch.bfloat16, device=x.device)
+        a.tail, a.bias_tab, a.qkv = 0, ptr(bias_tab), ptr(qkv)
+        out = qkv
+    else:
+        if logits is None:
+            logits = torch.empty((R, vocab), dtype=torch.float32, device=x.device)
+        a.tail, a.h0_b, a.h1_b, a.h2_b, a.logits, a.vocab = 1, ptr(head_b[0]), ptr(head_b[1]), ptr(head_b[2]), ptr(logits), int(vocab)
+        out = logits
+    _lib.check(_lib.lib().omp_dec_rows_ffn(ctypes.byref(a), stream()), 'omp_dec_rows_ffn')
+    return out
+
+
+def swin_mlp_rows(x, ln_g, ln_b, wstream, wave_stride, b1, b2, eps=1e-5):
+    """x [M, 512] fp32 residual stream, in place: x += fc2(GELU(fc1(LN(x)))) as a row-owner chain (Swin-B stage 2; wstream from
+    model.packing.pack_rows_mlp)."""
+    if x.dtype != torch.float32 or x.shape[-1] != 512:
+        raise TypeError('swin_mlp_rows takes the fp32 residual stream [M, 512]')
+    M = x.numel() // 512
+    rc = _lib.lib().omp_swin_mlp_rows(ptr(_c(x, 'x')), M, ptr(ln_g), ptr(ln_b), float(eps), ptr(wstream), int(wave_stride), ptr(b1), ptr(b2), stream())
+    _lib.check(rc, 'omp_swin_mlp_rows')
+    return x

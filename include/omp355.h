@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 17
+#define OMP_ABI_VERSION 18
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -135,6 +135,14 @@ int omp_swin_mlp_fused(const void* x, int64_t ldx, const float* ln_gamma, const 
 int omp_swin_mlp_fused2(const void* x, int x_dtype, int64_t ldx, const float* ln_gamma, const float* ln_beta, float eps,
                         const void* wpack, const float* b2, void* y, int64_t ldy, int64_t M, int C, int hidden,
                         omp_stream_t s);
+
+/* ---- The same sub-layer at C = 512 (Swin-B stage 2) as a row-owner chain (round 5, csrc/dec_rows.hip) -------------------------------
+ * x = x + fc2(GELU(fc1(LayerNorm(x)))) in place on the fp32 residual stream [M, 512], hidden 2048, bf16 matrix-core operands (LayerNorm
+ * output and hidden activations rounded to bf16 as in the three-launch path).  A workgroup owns 80 tokens and streams the weights; wstream
+ * is written once per checkpoint by model/packing.py::pack_rows_mlp (per wave: 8 chunks of [fc1 rows of 256 hidden units, fc2 columns
+ * of the same units] as 1 KB matrix-core fragments in consumption order, see omp_dec_rows_ffn; + 8 KB slack). */
+int omp_swin_mlp_rows(float* x, int64_t M, const float* ln_gamma, const float* ln_beta, float eps, const void* wstream, int64_t wave_stride,
+                      const float* b1, const float* b2, omp_stream_t s);
 
 /* ---- Swin patch embedding: zero-pad to x4, 4x4/4 conv (as K=48 dot products), LayerNorm -----
  * Replaces PatchEmbed.forward, swin_transformer.py:427-443.  img is NCHW fp32 (as the reference
@@ -296,6 +304,9 @@ typedef struct {
   void* vcache;
   const void* crossK;          /* this layer's K slab   [B][nH][Mpad][64] */
   const void* crossVt;         /* this layer's V^T slab [B][nH][Mpad/KB][64][KB] */
+  /* row-owner chains (omp_decoder_plan.rows_fused, see omp_dec_rows_mid / omp_dec_rows_ffn): packed weight streams of this layer */
+  const void* rows_mid;        /* sa_out_w, ca_q_w */
+  const void* rows_ffn;        /* ca_out_w, ff1_w / ff2_w in 16 chunks, then the NEXT layer's sa_in_w -- the last layer: h0_w, h1_w, h2_w */
 } omp_dec_layer;
 
 typedef struct {
@@ -309,7 +320,13 @@ typedef struct {
    * blocks of [hi plane | lo plane]); q and the attention output stay fp32 (with gemm_x3 the kernels write the out-projection's
    * pair rows themselves).  kv_img_stride then counts bf16 elements: nH * Mpad * 128. */
   int32_t kv_split;
+  /* rows_fused = 1 (dtype OMP_BF16, pre_norm, d_model 512, d_ff 2048, 8 heads; the host sets it for phases of thousands of rows): the
+   * Linear layers of a step run as row-owner chains -- omp_dec_rows_ffn(embedding | q k v), then per layer self-attention,
+   * omp_dec_rows_mid, cross-attention, omp_dec_rows_ffn -- 18 launches per step instead of 50; layers[l].rows_mid / rows_ffn and
+   * rows_embed (layer 0's sa_in_w) are the packed streams (model/packing.py::pack_rows_*). */
+  int32_t rows_fused;
   float eps;
+  const void* rows_embed;
   omp_dec_layer layers[OMP_MAX_DEC_LAYERS];
   const float *word_emb, *pos_tab, *emb_g, *emb_b, *fn_g, *fn_b;
   const void *h0_w, *h1_w, *h2_w;
@@ -346,6 +363,54 @@ typedef struct {
 int omp_decoder_run(const omp_decoder_plan* plan, int first_pos, int n_steps, int graph_slot,
                     omp_stream_t s);
 int omp_decoder_graph_reset(int graph_slot);
+
+/* ---- Many-row decoder phases: the Linear chain between two attention kernels as ONE launch (round 5, csrc/dec_rows.hip) -----------
+ * Replaces, for phases of thousands of rows (polygon / recognition decoders of a large engine call), the per-Linear launches of
+ * TransformerDecoderLayer.forward_pre, transformer.py:430-454, at d_model 512 / d_ff 2048 / bf16 operands:
+ *   omp_dec_rows_mid:  x += att Wo^T + bo  (self-attention out-projection + residual, :438-440);
+ *                      q  = bf16(LayerNorm2(x) Wq^T + qbias_tab[*d_pos])  (:441-446, query side of multihead_attn)
+ *   omp_dec_rows_ffn:  prologue 0: x1 = x + att Wo^T + bo (cross-attention out-projection + residual, :442-447);
+ *                                  x  = x1 + relu(LayerNorm3(x1) W1^T + b1) W2^T + b2  (:448-453)
+ *                      prologue 1: x  = LayerNorm(word_emb[seq[r, *d_pos]] + pos_tab[*d_pos])  (DecoderEmbeddings, :302-328: layer 0)
+ *                      tail 0:     qkv = bf16(LayerNorm_t(x) Win^T + bias_tab[*d_pos])  (the NEXT layer's norm1 + in_proj, :437-440)
+ *                      tail 1:     logits = h2(relu(h1(relu(h0(LayerNorm_t(x))))))  (decoder norm :374 + prediction head, block/mlp.py:11-13)
+ * A workgroup owns omp_dec_rows_tile() consecutive rows (operand tile in LDS, residual / accumulators in registers) and streams the
+ * chain's weights; every wave w (8 per workgroup) walks its own linear stream of 1 KB matrix-core fragments starting at
+ * wstream + w * wave_stride, written once per checkpoint by model/packing.py::pack_rows_* in consumption order:
+ *   a product of N = 512 (128) output features over K: for each k-step of 32, for each of the wave's 4 (1) feature tiles of 16 --
+ *   features 64 w + 16 t .. (16 w ..) of the pass --: fragment[lane][8] = W[f0 + (lane & 15)][32 ks + 8 (lane >> 4) .. + 8];
+ *   the FFN interleaves, per chunk of 256 hidden units, linear1's pass (N = 256: features 32 w + 16 t, t = 0..1, K = 512) with linear2's
+ *   (N = 512, K = 256);
+ *   the vocabulary projection is padded with zero rows to a multiple of 128 features (512-feature passes, then 128-feature passes).
+ * The buffer carries 8 KB of slack behind the last wave's stream (the ring of 8 fragments in flight runs ahead).
+ * att: bf16 [R, 512]; x: fp32 [R, 512] in place; q: bf16 [R, 512]; qkv: bf16 [R, 1536]; logits: fp32 [R, vocab], vocab % 4 == 0. */
+typedef struct {
+  int32_t R;
+  float eps;
+  const int32_t* d_pos;
+  float* x;
+  const void* att;
+  const void* wstream;
+  int64_t wave_stride;
+  const float* out_b;
+  const float *ln_g, *ln_b;        /* mid: norm2; ffn prologue 0: norm3 */
+  const float* qbias_tab;          /* mid: [Pmax, 512] */
+  void* q;                         /* mid */
+  int32_t prologue, tail;          /* ffn */
+  const float *ff1_b, *ff2_b;
+  const int32_t* seq;
+  int32_t seq_ld;
+  const float *word_emb, *pos_tab, *emb_g, *emb_b;
+  const float *lnt_g, *lnt_b;      /* the LayerNorm in front of the tail */
+  const float* bias_tab;           /* tail 0: [Pmax, 1536] */
+  void* qkv;
+  const float *h0_b, *h1_b, *h2_b; /* tail 1 */
+  float* logits;
+  int32_t vocab;
+} omp_dec_rows_args;
+int omp_dec_rows_mid(const omp_dec_rows_args* a, omp_stream_t s);
+int omp_dec_rows_ffn(const omp_dec_rows_args* a, omp_stream_t s);
+int omp_dec_rows_tile(void);   /* rows per workgroup (80) */
 
 /* ---- MGP-STR recogniser (reference: OCR/MGP-STR; BASELINE config 5) ------------------------------------
  * The ViT-B encoder reuses omp_layernorm / omp_gemm_bias_act / omp_dec_cross_attn_step (a ViT layer's k and v

@@ -654,6 +654,153 @@ def check_decoder_fused(with_mask=True):
     return out
 
 
+def check_dec_rows():
+    """Row-owner chains of the decoders' many-row phases (csrc/dec_rows.hip, round 5) against a CPU restatement of the sub-layers they
+    replace (transformer.py:430-454 forward_pre, :302-328 embeddings, block/mlp.py head) with bf16 rounding where the kernels round
+    (LayerNorm outputs, attention outputs, hidden activations, q / k / v), fp32 elsewhere.  R = 200 rows: three workgroups of 80 rows,
+    the last one ragged (40 rows)."""
+    from advancedliteratemachinery_amd.model import packing
+    bf = torch.bfloat16
+    d, ff, V, R, P, pos = 512, 2048, 1104, 200, 12, 5
+    out = []
+    W = lambda n, k, seed: q(rnd(n, k, seed=seed) / k ** 0.5, bf)          # noqa: E731
+    vec = lambda n, seed, s=0.1: rnd(n, seed=seed, scale=s)                # noqa: E731
+    ln = lambda x, g, b: F.layer_norm(x, (d,), g, b, 1e-5)                  # noqa: E731
+    dev = lambda t, dt=None: (t.to(dt) if dt is not None else t).to(DEV).contiguous()   # noqa: E731
+    x0 = rnd(R, d, seed=1, scale=2.0)
+    att = q(rnd(R, d, seed=2), bf)
+    dpos = torch.tensor([pos, 0], dtype=torch.int32, device=DEV)
+    # ---- mid: x += att Wo^T + bo; q = bf16(LN2(x) Wq^T + qbias[pos])
+    Wo, Wq = W(d, d, 3), W(d, d, 4)
+    bo, g2, b2, qtab = vec(d, 5), 1 + vec(d, 6), vec(d, 7), rnd(P, d, seed=8, scale=0.3)
+    x1 = x0 + att @ Wo.T + bo
+    q_ref = q(q(ln(x1, g2, b2), bf) @ Wq.T + qtab[pos], bf)
+    stream, stride = packing.pack_rows_mid(dev(Wo, bf), dev(Wq, bf))
+    xd = dev(x0)
+    qd = ops.dec_rows_mid(dev(att, bf), xd, stream, stride, dev(bo), dev(g2), dev(b2), dev(qtab), dpos)
+    torch.cuda.synchronize()
+    out.append(rec('dec_rows_mid x (residual stream)', maxerr(xd, x1), 2e-4 * x1.abs().max().item()))
+    out.append(rec('dec_rows_mid q', maxerr(qd, q_ref), 0.02 * q_ref.abs().max().item(), 'bf16 output: 2^-8 of the scale + one-ulp flips of the LayerNorm output'))
+    # ---- ffn: x1 = x + att Wo^T + bo; x2 = x1 + relu(LN3(x1) W1^T + b1) W2^T + b2; tails
+    Wc, W1, W2 = W(d, d, 10), W(ff, d, 11), W(d, ff, 12)
+    bc, g3, b3, b1, bb2 = vec(d, 13), 1 + vec(d, 14), vec(d, 15), vec(ff, 16), vec(d, 17)
+    Win, gt, bt, tab = W(3 * d, d, 18), 1 + vec(d, 19), vec(d, 20), rnd(P, 3 * d, seed=21, scale=0.3)
+    H0, H1, H2 = W(d, d, 22), W(d, d, 23), W(V, d, 24)
+    hb = (vec(d, 25), vec(d, 26), vec(V, 27))
+    xa = x0 + att @ Wc.T + bc
+    hid = q(torch.relu(q(ln(xa, g3, b3), bf) @ W1.T + b1), bf)
+    x2 = xa + hid @ W2.T + bb2
+    yt = q(ln(x2, gt, bt), bf)
+    qkv_ref = q(yt @ Win.T + tab[pos], bf)
+    t0 = q(torch.relu(yt @ H0.T + hb[0]), bf)
+    t1 = q(torch.relu(t0 @ H1.T + hb[1]), bf)
+    lg_ref = t1 @ H2.T + hb[2]
+    common = dict(att=dev(att, bf), out_b=dev(bc), ln_g=dev(g3), ln_b=dev(b3), ff1_b=dev(b1), ff2_b=dev(bb2))
+    stream, stride = packing.pack_rows_ffn_qkv(dev(Wc, bf), dev(W1, bf), dev(W2, bf), dev(Win, bf))
+    xd = dev(x0)
+    qkv = ops.dec_rows_ffn(xd, stream, stride, dpos, dev(gt), dev(bt), bias_tab=dev(tab), **common)
+    torch.cuda.synchronize()
+    out.append(rec('dec_rows_ffn[qkv tail] x', maxerr(xd, x2), 5e-3 * x2.abs().max().item(), 'one-ulp flips of the bf16 hidden activations'))
+    out.append(rec('dec_rows_ffn[qkv tail] qkv', maxerr(qkv, qkv_ref), 0.03 * qkv_ref.abs().max().item()))
+    stream, stride = packing.pack_rows_ffn_head(dev(Wc, bf), dev(W1, bf), dev(W2, bf), dev(H0, bf), dev(H1, bf), dev(H2, bf))
+    xd = dev(x0)
+    lg = ops.dec_rows_ffn(xd, stream, stride, dpos, dev(gt), dev(bt), head_b=tuple(dev(b) for b in hb), vocab=V, **common)
+    torch.cuda.synchronize()
+    out.append(rec('dec_rows_ffn[head tail] x', maxerr(xd, x2), 5e-3 * x2.abs().max().item()))
+    out.append(rec('dec_rows_ffn[head tail] logits', maxerr(lg, lg_ref), 0.03 * lg_ref.abs().max().item(), 'max|logit|=%.2f' % lg_ref.abs().max().item()))
+    # ---- embedding prologue: x = LN(word[tok] + pos_tab[pos]); qkv = bf16(LN1(x) Win^T + tab[pos])
+    word, ptab = rnd(V, d, seed=30), rnd(P, d, seed=31)
+    ge, be = 1 + vec(d, 32), vec(d, 33)
+    seq = torch.randint(0, V, (R, 9), generator=torch.Generator().manual_seed(34), dtype=torch.int32)
+    xe = ln(word[seq[:, pos].long()] + ptab[pos], ge, be)
+    qkv_e = q(q(ln(xe, gt, bt), bf) @ Win.T + tab[pos], bf)
+    stream, stride = packing.pack_rows_embed_qkv(dev(Win, bf))
+    xd = torch.zeros(R, d, device=DEV)
+    qkv = ops.dec_rows_ffn(xd, stream, stride, dpos, dev(gt), dev(bt), embed=(seq.to(DEV), dev(word), dev(ptab), dev(ge), dev(be)), bias_tab=dev(tab))
+    torch.cuda.synchronize()
+    out.append(rec('dec_rows_ffn[embedding] x', maxerr(xd, xe), 1e-5 * max(1.0, xe.abs().max().item())))
+    out.append(rec('dec_rows_ffn[embedding] qkv', maxerr(qkv, qkv_e), 0.02 * qkv_e.abs().max().item()))
+    return out
+
+
+def check_swin_mlp_rows():
+    """MLP half of a Swin stage-2 block (C = 512) as a row-owner chain (omp_swin_mlp_rows) against x + fc2(GELU(fc1(LN(x)))) on the CPU with bf16
+    rounding where the kernel rounds (LayerNorm output, hidden activations), exact erf GELU, and against the three-launch path of the bf16 engine.
+    M = 1000 tokens: 13 workgroups, the last one ragged."""
+    from advancedliteratemachinery_amd.model import packing
+    bf = torch.bfloat16
+    C, Hd, M = 512, 2048, 1000
+    x = rnd(M, C, seed=1, scale=2.0)
+    g, b = 1 + rnd(C, seed=2, scale=0.1), rnd(C, seed=3, scale=0.1)
+    w1, w2 = q(rnd(Hd, C, seed=4) / C ** 0.5, bf), q(rnd(C, Hd, seed=5) / Hd ** 0.5, bf)
+    b1, b2 = rnd(Hd, seed=6, scale=0.1), rnd(C, seed=7, scale=0.1)
+    y = q(F.layer_norm(x, (C,), g, b, 1e-5), bf)
+    h = q(F.gelu(y @ w1.T + b1), bf)
+    ref = x + h @ w2.T + b2
+    dev = lambda t, dt=None: (t.to(dt) if dt is not None else t).to(DEV).contiguous()   # noqa: E731
+    stream, stride = packing.pack_rows_mlp(dev(w1, bf), dev(w2, bf))
+    xd = dev(x)
+    ops.swin_mlp_rows(xd, dev(g), dev(b), stream, stride, dev(b1), dev(b2))
+    torch.cuda.synchronize()
+    out = [rec('swin_mlp_rows vs CPU', maxerr(xd, ref), 4e-3 * ref.abs().max().item(), 'one-ulp flips of the bf16 hidden activations')]
+    # the three-launch path of the bf16 engine on the same inputs
+    x3 = dev(x)
+    yd = ops.layernorm(x3, dev(g), dev(b), out_dtype=bf)
+    hd = ops.gemm(yd, dev(w1, bf), dev(b1), act=ops.ACT_GELU)
+    ops.gemm(hd, dev(w2, bf), dev(b2), residual=x3, out=x3)
+    torch.cuda.synchronize()
+    out.append(rec('swin_mlp_rows vs LayerNorm + fc1(GELU) + fc2(residual) launches', maxerr(xd, x3), 4e-3 * ref.abs().max().item()))
+    return out
+
+
+def check_decoder_rows(with_mask=True):
+    """Many-row phases of the bf16 engine run their Linear layers as row-owner chains (plan.rows_fused; csrc/dec_rows.hip).  Teacher-forced
+    logits of every decoder kind against the oracle AND against the launch-per-op path, with the row threshold lowered so that small
+    phases take the chains: ragged groups (rows not a multiple of the 80-row tile, images with different instance counts)."""
+    dt = torch.bfloat16
+    out = []
+    args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True)
+    sd = weights.make_state_dict(args, seed=2, depths=(2, 2, 2, 2))
+    model = build_model(args, sd, (2, 2, 2, 2), dt)
+    enc, dec = model.engine()
+    d = 512
+    g = torch.Generator().manual_seed(25)
+    for counts, M, L, kinds in (([64, 37, 64], 77, 7, ('poly', 'rec')), ([30, 64], 64, 5, ('pt',))):
+        B = len(counts)
+        mem = q(rnd(B * M, d, seed=1), dt)
+        pos = q(rnd(B * M, d, seed=2), dt)
+        kmask = torch.zeros(B, M, dtype=torch.bool)
+        if with_mask:
+            kmask[B - 1, M - 17:] = True
+        mem_pos = q(mem + pos, dt)
+        kv = dec.project_memory(mem.to(DEV, dt), mem_pos.to(DEV, dt), B, M, kmask.to(torch.uint8).to(DEV) if with_mask else None)
+        R = sum(counts)
+        for kind in kinds:
+            seqs = torch.randint(0, args.num_classes - 1, (R, L), generator=g)
+            keep = dec.rows_min
+            try:
+                dec.rows_min = 1
+                lg = dec.teacher_forced_logits(kind, kv, seqs, counts, 3).cpu()
+                dec.rows_min = 1 << 30
+                lg0 = dec.teacher_forced_logits(kind, kv, seqs, counts, 3).cpu()
+            finally:
+                dec.rows_min = keep
+            worst, r0, scale = 0.0, 0, 0.0
+            for b in range(B):
+                n = counts[b]
+                mem_b = mem.reshape(B, M, d)[b].unsqueeze(1)
+                pos_b = mem_pos.reshape(B, M, d)[b].unsqueeze(1) - mem_b
+                ref = O.decode(sd, args, seqs[r0:r0 + n], mem_b, kmask[b:b + 1], pos_b, kind)
+                worst = max(worst, (lg[r0:r0 + n] - ref).abs().max().item())
+                scale = max(scale, ref.abs().max().item())
+                r0 += n
+            tag = 'decoder_rows[%s,rows=%s,L=%d]' % (kind, counts, L)
+            out.append(rec(tag + ' vs oracle', worst, 0.6, 'max|logit|=%.2f' % scale))
+            out.append(rec(tag + ' vs launch-per-op path', (lg - lg0).abs().max().item(), 0.35))
+            out.append(rec(tag + ' the chains ran (result differs in the last bits)', 0.0 if not torch.equal(lg, lg0) else 1.0, 0.0))
+    return out
+
+
 def check_sampling_block():
     """greedy sampling inside omp_decoder_run (workgroup per row + fused position advance) == the stand-alone sampling entry point:
     covered end to end by the token-identity gates; here the free-running fp32 result with the fused kernels off and on."""

@@ -20,7 +20,7 @@ def C():
 
 @pytest.mark.parametrize('name', ['check_layernorm', 'check_gemm', 'check_mlp_fused', 'check_self_attn', 'check_gemm_small', 'check_patch_embed', 'check_window_attn',
                                   'check_patch_merge', 'check_fpn', 'check_posembed', 'check_sampling', 'check_cross_attn', 'check_split_ops', 'check_gemm_x3',
-                                  'check_window_attn_split', 'check_swin_block', 'check_cross_attn_split', 'check_gemm_4w'])
+                                  'check_window_attn_split', 'check_swin_block', 'check_cross_attn_split', 'check_gemm_4w', 'check_dec_rows', 'check_swin_mlp_rows'])
 def test_op(C, name):
     _assert_all(getattr(C, name)())
 
@@ -39,6 +39,12 @@ def test_decoder_fused_few_row_kernels(C, with_mask):
 @pytest.mark.parametrize('with_mask', [True, False])
 def test_decoder_x3_many_row_phases(C, with_mask):
     _assert_all(C.check_decoder_x3(with_mask))
+
+
+@pytest.mark.parametrize('with_mask', [True, False])
+def test_decoder_row_owner_chains(C, with_mask):
+    """round 5: the many-row phases' Linear layers as two launches per layer (csrc/dec_rows.hip)"""
+    _assert_all(C.check_decoder_rows(with_mask))
 
 
 def test_sampling_block_kernel(C):

@@ -346,6 +346,102 @@ def bench_dec_gemm_rows():
             ops.force_gemm_kernel(0)
 
 
+def bench_dec_rows_fused():
+    """round 5: the decoders' many-row phases as row-owner chains (csrc/dec_rows.hip) vs the launch-per-Linear path.
+    (a) every chain kernel alone at R = KBENCH_DEC_ROWS rows; (b) the polygon || recognition phase of an engine call of
+    KBENCH_DEC_IMAGES images x 64 instances (hipGraph replay, two streams, M = 4096 memory tokens per image) with the chains on / off."""
+    from advancedliteratemachinery_amd.model import packing
+    bf = torch.bfloat16
+    R = int(os.environ.get('KBENCH_DEC_ROWS', '10240'))
+    d, ff, V, P = 512, 2048, 1104, 40
+    W = lambda n, k: (torch.randn(n, k, device=DEV) / k ** 0.5).to(bf)   # noqa: E731
+    vec = lambda n: torch.randn(n, device=DEV) * 0.1                      # noqa: E731
+    x = torch.randn(R, d, device=DEV)
+    att = torch.randn(R, d, device=DEV).to(bf)
+    dpos = torch.tensor([5, 0], dtype=torch.int32, device=DEV)
+    g, b = 1 + vec(d), vec(d)
+    tab3, tab1 = torch.randn(P, 3 * d, device=DEV), torch.randn(P, d, device=DEV)
+    Wo, Wq, Wc, W1, W2, Win, H0, H1, H2 = W(d, d), W(d, d), W(d, d), W(ff, d), W(d, ff), W(3 * d, d), W(d, d), W(d, d), W(V, d)
+    s_mid = packing.pack_rows_mid(Wo, Wq)
+    s_qkv = packing.pack_rows_ffn_qkv(Wc, W1, W2, Win)
+    s_head = packing.pack_rows_ffn_head(Wc, W1, W2, H0, H1, H2)
+    s_emb = packing.pack_rows_embed_qkv(Win)
+    q = torch.empty(R, d, device=DEV, dtype=bf)
+    qkv = torch.empty(R, 3 * d, device=DEV, dtype=bf)
+    lg = torch.empty(R, V, device=DEV)
+    seq = torch.randint(0, V, (R, 9), device=DEV, dtype=torch.int32)
+    word, ptab = torch.randn(V, d, device=DEV), torch.randn(P, d, device=DEV)
+    common = dict(att=att, out_b=vec(d), ln_g=g, ln_b=b, ff1_b=vec(ff), ff2_b=vec(d))
+    hb = (vec(d), vec(d), vec(V))
+    cases = [('mid  (out_proj + LN + ca_q)', 4.0 * R * d * d, lambda: ops.dec_rows_mid(att, x, s_mid[0], s_mid[1], hb[0], g, b, tab1, dpos, q=q)),
+             ('ffn  (out_proj + LN + FFN + LN + q k v)', 2.0 * R * d * (d + 8 * d + 3 * d), lambda: ops.dec_rows_ffn(x, s_qkv[0], s_qkv[1], dpos, g, b, bias_tab=tab3, qkv=qkv, **common)),
+             ('ffn  (out_proj + LN + FFN + LN + head)', 2.0 * R * d * (d + 8 * d + 2 * d + V), lambda: ops.dec_rows_ffn(x, s_head[0], s_head[1], dpos, g, b, head_b=hb, logits=lg, vocab=V, **common)),
+             ('embed (embedding + LN + LN + q k v)', 2.0 * R * d * 3 * d, lambda: ops.dec_rows_ffn(x, s_emb[0], s_emb[1], dpos, g, b, embed=(seq, word, ptab, g, b), bias_tab=tab3, qkv=qkv))]
+    for name, fl, fn in cases:
+        us = timeit(fn, iters=30, warm=3)
+        print('dec_rows[R=%d] %-42s : %7.1f us  %7.1f TF/s' % (R, name, us, fl / us / 1e6), flush=True)
+    # ---- (b) the phase as the engine runs it
+    sys.path.insert(0, ROOT)
+    import bench as B_
+    I = int(os.environ.get('KBENCH_DEC_IMAGES', '160'))
+    model, args, _ = B_.build_model('bf16', 1, torch.device(DEV))
+    _, dec = model.engine()
+    M = 4096
+    gen = torch.Generator(device='cpu').manual_seed(0)
+    mem = torch.randn(I * M, d, generator=gen).to(DEV, bf)
+    kv = dec.project_memory(mem, mem, I, M, None)
+    counts = [64] * I
+    pts = torch.randint(0, args.num_bins, (64 * I, 2), generator=gen, dtype=torch.int32).to(DEV)
+    dec.use_graph = True
+    st = torch.cuda.Stream()
+    sp, sr = torch.cuda.Stream(), torch.cuda.Stream()
+    for label, thr in (('row-owner chains', 1), ('launch per Linear', 1 << 30)):
+        dec.rows_min = thr
+        with torch.cuda.stream(st):
+            for streams in ((sp, sr), None):
+                def fn():
+                    dec.decode_poly_and_rec(kv, pts, counts, args.poly_sos_index, args.rec_sos_index, args.rec_length, streams=streams)
+                fn()
+                torch.cuda.synchronize()
+                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(3):
+                    fn()
+                b_.record()
+                torch.cuda.synchronize()
+                print('poly + rec phase, %d images x 64 rows, %-18s, %s : %8.2f ms per engine call'
+                      % (I, label, 'two streams' if streams else 'one stream ', a.elapsed_time(b_) / 3), flush=True)
+
+
+def bench_mlp_rows():
+    """round 5: the MLP half of a Swin stage-2 block (C = 512) at the encoder's chunk size: LayerNorm + fc1(GELU) + fc2(fp32 residual) as
+    three launches vs the row-owner chain (omp_swin_mlp_rows)."""
+    from advancedliteratemachinery_amd.model import packing
+    bf = torch.bfloat16
+    C, Hd = 512, 2048
+    for M in (int(os.environ.get('KBENCH_MLP_ROWS', '131072')), 32768):
+        x = torch.randn(M, C, device=DEV)
+        g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        w1 = (torch.randn(Hd, C, device=DEV) / C ** 0.5).to(bf)
+        w2 = (torch.randn(C, Hd, device=DEV) / Hd ** 0.5).to(bf)
+        b1, b2 = torch.randn(Hd, device=DEV) * 0.1, torch.randn(C, device=DEV) * 0.1
+        stream, stride = packing.pack_rows_mlp(w1, w2)
+        y = torch.empty(M, C, device=DEV, dtype=bf)
+        hbuf = torch.empty(M, Hd, device=DEV, dtype=bf)
+        fl = 2.0 * M * C * Hd * 2
+
+        def unfused():
+            ops.layernorm(x, g, b, out=y, out_dtype=bf)
+            ops.gemm(y, w1, b1, act=ops.ACT_GELU, out=hbuf)
+            ops.gemm(hbuf, w2, b2, residual=x, out=x)
+        us = timeit(unfused, iters=10, warm=2)
+        print('mlp_rows[C=512] M=%d LayerNorm + fc1(GELU) + fc2(fp32 residual), 3 launches : %8.1f us  %6.1f TF/s' % (M, us, fl / us / 1e6), flush=True)
+        x.normal_()
+        us = timeit(lambda: ops.swin_mlp_rows(x, g, b, stream, stride, b1, b2), iters=10, warm=2)
+        print('mlp_rows[C=512] M=%d row-owner chain (omp_swin_mlp_rows)                       : %8.1f us  %6.1f TF/s  %6.0f GB/s (x in + out)'
+              % (M, us, fl / us / 1e6, 2.0 * M * C * 4 / us / 1e3), flush=True)
+
+
 def bench_patch_embed():
     """PatchEmbed + LayerNorm of one 32-image encoder chunk at 1024x1024: the fp32 matrix-core kernel vs the thread-per-token kernel."""
     B, H, W, E = int(os.environ.get('KBENCH_PE_B', '32')), 1024, 1024, 128
@@ -415,6 +511,10 @@ if __name__ == '__main__':
         bench_cross()
     if 'dec_gemm' in what or 'all' in what:
         bench_dec_gemm()
+    if 'mlp_rows' in what:
+        bench_mlp_rows()
+    if 'dec_rows_fused' in what:
+        bench_dec_rows_fused()
     if 'patch_embed' in what:
         bench_patch_embed()
     if 'cross_split' in what:
