@@ -18,7 +18,9 @@ import torch.nn as nn
 
 from .. import _lib, ops
 
-_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32, torch.bfloat16: torch.bfloat16, torch.float32: torch.float32}
+# 'bf16x3' = the PARITY engine (round 5, as OmniParser's): fp32 storage and fp32 non-GEMM kernels, every large product as three bf16
+# matrix-core products of split operands (include/omp355.h, omp_gemm_args.a_wrap), the attention over split-plane K / V^T slabs
+_DTYPES = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'bf16x3': 'bf16x3', torch.bfloat16: torch.bfloat16, torch.float32: torch.float32}
 BASE_CFG = dict(embed=768, depth=12, heads=12, mlp_ratio=4, img=(32, 128), patch=4, max_len=27, num_class=38,
                 bpe_vocab=50257, wp_vocab=30522)
 CHARACTER = '0123456789abcdefghijklmnopqrstuvwxyz'
@@ -78,10 +80,16 @@ class _Engine(object):
     """weights packed once: matrices in the engine dtype, vectors fp32"""
 
     def __init__(self, sd, c, dtype, prefix):
+        self.x3 = dtype == 'bf16x3'
+        if self.x3:
+            dtype = torch.float32
         self.c, self.dtype = c, dtype
         E = c['embed']
         f32 = lambda k: sd[prefix + k].detach().float().contiguous()        # noqa: E731
-        mat = lambda t: t.detach().to(dtype).contiguous()                   # noqa: E731
+        if self.x3:   # [w_hi | w_hi | w_lo] images (ops.split_weight3): the W side of a bf16x3 product
+            mat = lambda t: ops.split_weight3(t)                            # noqa: E731
+        else:
+            mat = lambda t: t.detach().to(dtype).contiguous()               # noqa: E731
         self.pe_w = f32('patch_embed.proj.weight').reshape(E, -1).contiguous()
         self.pe_b = f32('patch_embed.proj.bias')
         self.cls = f32('cls_token').reshape(E).contiguous()
@@ -94,7 +102,7 @@ class _Engine(object):
                 n1=(f32(b + 'norm1.weight'), f32(b + 'norm1.bias')),
                 wq=mat(qkv_w[:E]), bq=qkv_b[:E].contiguous(),
                 wk=mat(qkv_w[E:2 * E]), bk=qkv_b[E:2 * E].contiguous(),
-                wv=mat(qkv_w[2 * E:]), bv=qkv_b[2 * E:].contiguous(),
+                wv=(ops.split_weight2(qkv_w[2 * E:]) if self.x3 else mat(qkv_w[2 * E:])), bv=qkv_b[2 * E:].contiguous(),   # V^T: swapped operands, the weight is the A side
                 wo=mat(f32(b + 'attn.proj.weight')), bo=f32(b + 'attn.proj.bias'),
                 n2=(f32(b + 'norm2.weight'), f32(b + 'norm2.bias')),
                 w1=mat(f32(b + 'mlp.fc1.weight')), b1=f32(b + 'mlp.fc1.bias'),
@@ -105,7 +113,8 @@ class _Engine(object):
             self.a3[name] = dict(
                 tn=(f32(t + 'token_norm.weight'), f32(t + 'token_norm.bias')),
                 wg=mat(_grouped_to_dense(f32(t + 'tokenLearner.0.weight'))),
-                wsel=mat(f32(t + 'tokenLearner.1.weight').reshape(c['max_len'], E)),
+                wsel=(f32(t + 'tokenLearner.1.weight').reshape(c['max_len'], E).contiguous() if self.x3   # 27 rows: stays an fp32 product
+                      else mat(f32(t + 'tokenLearner.1.weight').reshape(c['max_len'], E))),
                 wfeat=mat(_grouped_to_dense(f32(t + 'feat.weight'))),
                 n=(f32(t + 'norm.weight'), f32(t + 'norm.bias')),
                 hw=mat(f32(name + '_head.weight')), hb=f32(name + '_head.bias'))
@@ -114,7 +123,7 @@ class _Engine(object):
     def slabs(self, B, T, dev):
         """K / V^T slabs of ONE layer (reused by every layer: a layer's attention is finished before the next
         layer's projections overwrite them, all on one stream).  Zero-initialised: the padded key tail stays 0."""
-        KB = 16 if self.dtype == torch.float32 else 32
+        KB = 16 if (self.dtype == torch.float32 and not self.x3) else 32
         Mpad = (T + KB - 1) // KB * KB
         key = (B, T)
         if key not in self._slabs:
@@ -123,9 +132,13 @@ class _Engine(object):
             for b in range(B):
                 for o in range(0, T, 64):
                     groups.append((b * T + o, min(64, T - o), b))
-            self._slabs[key] = (torch.zeros(1, B, nH, Mpad, 64, dtype=self.dtype, device=dev),
-                                torch.zeros(1, B, nH, Mpad // KB, 64, KB, dtype=self.dtype, device=dev),
-                                torch.tensor(groups, dtype=torch.int32, device=dev), len(groups), Mpad, KB)
+            if self.x3:   # split-plane slabs: every 32-key block = [hi plane | lo plane] of bf16 (the bytes of the fp32 slabs)
+                slabs = (torch.zeros(1, B, nH, Mpad // 32, 2, 32, 64, dtype=torch.bfloat16, device=dev),
+                         torch.zeros(1, B, nH, Mpad // 32, 2, 64, 32, dtype=torch.bfloat16, device=dev))
+            else:
+                slabs = (torch.zeros(1, B, nH, Mpad, 64, dtype=self.dtype, device=dev),
+                         torch.zeros(1, B, nH, Mpad // KB, 64, KB, dtype=self.dtype, device=dev))
+            self._slabs[key] = slabs + (torch.tensor(groups, dtype=torch.int32, device=dev), len(groups), Mpad, KB)
         return self._slabs[key]
 
 
@@ -188,6 +201,8 @@ class MGPSTR(nn.Module):
         if (img.shape[2], img.shape[3]) != tuple(c['img']):
             raise ValueError("Input image size (%d*%d) doesn't match model (%d*%d)." % (img.shape[2], img.shape[3], c['img'][0], c['img'][1]))
         E, nH, dt = c['embed'], c['heads'], self.engine_dtype
+        if e.x3:
+            return self._encode_x3(img, e, B, T)
         x = ops.vit_patch_embed(img.float().contiguous(), e.pe_w, e.pe_b, e.cls, e.pos, dt).view(B * T, E)
         K, Vt, groups, n_groups, Mpad, KB = e.slabs(B, T, img.device)
         geom = (B, T, Mpad, nH, KB)
@@ -208,9 +223,44 @@ class MGPSTR(nn.Module):
             ops.gemm(h, blk['w2'], blk['b2'], residual=x, out=x)
         return x, B, T
 
+    def _encode_x3(self, img, e, B, T):
+        """The parity engine's encoder: fp32 residual stream, split-pair GEMM operands, split-plane K / V^T slabs, the 257-token
+        attention on the blocked cross-attention kernels (three bf16 products per score / value block)."""
+        c = self.cfg
+        E, nH, S = c['embed'], c['heads'], ops.SPLIT
+        f32 = torch.float32
+        x = ops.vit_patch_embed(img.float().contiguous(), e.pe_w, e.pe_b, e.cls, e.pos, f32).view(B * T, E)
+        K, Vt, groups, n_groups, Mpad, KB = e.slabs(B, T, img.device)
+        geom = (B, T, Mpad, nH, KB)
+        yf = torch.empty_like(x)
+        att = torch.empty_like(x)
+        ys = torch.empty((B * T, 2 * E), dtype=torch.bfloat16, device=x.device)
+        for blk in e.blocks:
+            ops.layernorm(x, blk['n1'][0], blk['n1'][1], out=ys, out_dtype=S, out_f32=yf, eps=LN_EPS_BLOCK)
+            q = ops.gemm(ys, blk['wq'], blk['bq'], out_dtype=f32, a_wrap=2 * E)
+            ops.gemm(ys, blk['wk'], blk['bk'], out=K, out_dtype=S, store_mode=_lib.STORE_KBLK, kv=geom, a_wrap=2 * E, M=B * T, N=E, K=3 * E)
+            ops.gemm(blk['wv'], ops.split_bf16(yf, triple=True), blk['bv'], out=Vt, out_dtype=S, store_mode=_lib.STORE_VBLK, kv=geom, bias_along_m=True,
+                     a_wrap=2 * E, M=E, N=B * T, K=3 * E)
+            ops.dec_cross_attn_step(q, K[0], Vt[0], nH * Mpad * 128, Mpad, None, groups, n_groups, 4, None, att, T, nH, 1)
+            ops.gemm(ops.split_bf16(att), blk['wo'], blk['bo'], residual=x, out=x, a_wrap=2 * E)
+            ops.layernorm(x, blk['n2'][0], blk['n2'][1], out=ys, out_dtype=S, eps=LN_EPS_BLOCK)
+            h = ops.gemm(ys, blk['w1'], blk['b1'], act=ops.ACT_GELU, out_dtype=S, a_wrap=2 * E)
+            ops.gemm(h, blk['w2'], blk['b2'], residual=x, out=x, a_wrap=h.shape[1])
+        return x, B, T
+
     def _a3_head(self, x, B, T, name, want_attn):
         e, c = self.engine(), self.cfg
         a, S = e.a3[name], c['max_len']
+        if e.x3:
+            E, f32 = c['embed'], torch.float32
+            ys = ops.layernorm(x, a['tn'][0], a['tn'][1], out_dtype=ops.SPLIT, eps=LN_EPS_A3)
+            t = ops.gemm(ys, a['wg'], out_dtype=f32, a_wrap=2 * E)
+            sel = ops.gemm(t, a['wsel'], out_dtype=f32)                          # [B*T, S]: a 27-row fp32 product
+            feat = ops.gemm(ys, a['wfeat'], out_dtype=f32, a_wrap=2 * E)
+            pooled, attn = ops.a3_pool(sel, feat, B, T, S, want_attn)
+            zs = ops.layernorm(pooled, a['n'][0], a['n'][1], out_dtype=ops.SPLIT, eps=LN_EPS_A3)
+            logits = ops.gemm(zs, a['hw'], a['hb'], out_dtype=f32, a_wrap=2 * E)
+            return attn, logits.view(B, S, -1)
         y = ops.layernorm(x, a['tn'][0], a['tn'][1], eps=LN_EPS_A3)
         t = ops.gemm(y, a['wg'])
         sel = ops.gemm(t, a['wsel'], out_dtype=torch.float32)                 # [B*T, S] fp32

@@ -24,12 +24,12 @@ def test_mgp_op(C, name):
     _assert_all(getattr(C, name)())
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'bf16x3'])
 def test_vit_block(C, dtype):
     _assert_all(C.check_vit_block(dtype))
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'bf16x3'])
 def test_mgp_end_to_end(C, dtype):
     _assert_all(C.check_mgp_e2e(dtype))
 
@@ -38,7 +38,12 @@ def test_mgp_golden_fp32(C):
     _assert_all(C.check_mgp_golden())
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_mgp_golden_parity_engine(C):
+    """round 5: MGP-STR's bf16x3 engine (split-bf16 products, split-plane attention) under the fp32 gates on the reference's fixture"""
+    _assert_all(C.check_mgp_golden('bf16x3'))
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'bf16x3'])
 def test_mgp_batch512_config5(C, dtype):
     """BASELINE config 5 at its stated shape (ViT-B, batch 512) against the oracle on probe rows."""
     _assert_all(C.check_mgp_b512(dtype))
