@@ -56,6 +56,13 @@ class DecRowsArgs(ctypes.Structure):
                 ('vocab', c_int32)]
 
 
+class SwinRowsArgs(ctypes.Structure):
+    """omp_swin_rows_args (include/omp355.h): a Swin stage-2 block minus its window attention core as one row-owner chain"""
+    _fields_ = [('M', c_int64), ('eps', c_float), ('mode', c_int32), ('x', c_void_p), ('att', c_void_p), ('qkv', c_void_p), ('wstream', c_void_p),
+                ('wave_stride', c_int64), ('proj_b', c_void_p), ('n2_g', c_void_p), ('n2_b', c_void_p), ('fc1_b', c_void_p), ('fc2_b', c_void_p),
+                ('n1_g', c_void_p), ('n1_b', c_void_p), ('qkv_b', c_void_p)]
+
+
 class DecoderPlan(ctypes.Structure):
     _fields_ = ([(n, c_int32) for n in ('dtype', 'n_layers', 'd_model', 'n_heads', 'd_ff', 'vocab',
                                         'pre_norm', 'R', 'Lmax', 'M', 'Mpad', 'n_tiles', 'q_tiles', 'n_split', 'n_prompt', 'gemm_x3', 'kv_split', 'rows_fused')]
@@ -105,7 +112,7 @@ _SIGS = {
     'omp_dec_rows_mid': (c_int, [ctypes.POINTER(DecRowsArgs), c_void_p]),
     'omp_dec_rows_ffn': (c_int, [ctypes.POINTER(DecRowsArgs), c_void_p]),
     'omp_dec_rows_tile': (c_int, []),
-    'omp_swin_mlp_rows': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    'omp_swin_rows_block': (c_int, [ctypes.POINTER(SwinRowsArgs), c_void_p]),
     'omp_decoder_run': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_int, c_int, c_void_p]),
     'omp_decoder_graph_reset': (c_int, [c_int]),
     'omp_decoder_step_logits': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_void_p]),

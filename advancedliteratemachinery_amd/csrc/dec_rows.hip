@@ -215,66 +215,131 @@ __device__ __forceinline__ void ln_row512(float* v, const float* __restrict__ g,
   }
 }
 
-// the attention output rows of this workgroup (bf16 [R, 512]) -> operand tile; rows beyond R repeat the last row (computed, never stored)
+// the attention output rows of this workgroup (bf16 [R, 512]) -> operand tile, by LDS DMA: a row is 1 KB = one wave instruction (64 lanes x
+// 16 bytes, LDS destination = wave-uniform base + 16 * lane), RT / 8 instructions per wave, no register staging.  Rows beyond R repeat the
+// last row (computed, never stored).  The requests count in vmcnt: the caller waits vmcnt(0) (the ring's first fragments, requested earlier,
+// have landed by then) before the barrier that opens the first product.
 template <int RTT>
-__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ att, int64_t r0, int R, char* tile, int tid) {
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ att, int64_t r0, int R, char* tile, int wave, int lane) {
   constexpr int RT = RTT * 16;
-  for (int c = tid; c < RT * 64; c += NW * 64) {   // 64 sixteen-byte pieces per row
-    const int row = c >> 6, pc = c & 63;
+#pragma unroll
+  for (int i = 0; i < RT / NW; ++i) {
+    const int row = wave * (RT / NW) + i;
     int64_t r = r0 + row;
     if (r > R - 1) r = R - 1;
-    *reinterpret_cast<u32x4*>(tile + row * A_PITCH + pc * 16) = *reinterpret_cast<const u32x4*>(att + r * D + pc * 8);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(att + r * D + lane * 8),
+                                     (__attribute__((address_space(3))) void*)(tile + row * A_PITCH), 16, 0, 0);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+
+// Epilogue helpers.  FULL = the workgroup's RT rows all exist (every workgroup but the last one of a ragged launch): no per-row predicates --
+// with them hipcc wraps every store in its own exec-mask branch and puts `s_waitcnt vmcnt(0)` in front of each (a store round trip per
+// store: the q k v tail of a chain measured 82k cycles instead of 30k, profiles/r05h_kbench_swin_rows_trace.txt).  Callers branch once on
+// nrow == RT (wave-uniform).
 
 // acc = acc + bias[f] + x[row][f]  (the residual add of an attention sub-layer); optionally the new x goes back to memory.
 // xb = x + r0 * 512 (the workgroup's first row), nrow = rows of this workgroup that exist (R - r0, >= 1)
-template <int RTT, bool STORE>
-__device__ __forceinline__ void add_bias_residual(f32x4 (&acc)[4][RTT], const float* __restrict__ bias, float* __restrict__ xb, int nrow,
-                                                  int wave, int li_, int g_) {
+template <int RTT, bool STORE, bool FULL>
+__device__ __forceinline__ void add_bias_residual_t(f32x4 (&acc)[4][RTT], const float* __restrict__ bias, float* __restrict__ xb, int nrow,
+                                                    int wave, int li_, int g_) {
   const int li = opaque(li_), g = opaque(g_);
+  // the loads of FG feature tiles at a time, all issued before the first is consumed: one memory round trip per group (all four tiles at once
+  // where the registers allow: 80 of them; the storing variant also holds its store addresses and takes two groups)
+  constexpr int FG = STORE ? 2 : 4;
 #pragma unroll
-  for (int ft = 0; ft < 4; ++ft) {
-    const int f = wave * 64 + ft * 16 + g * 4;
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + f);
+  for (int f0 = 0; f0 < 4; f0 += FG) {
+    f32x4 bb[FG], xv[FG][RTT];
 #pragma unroll
-    for (int rt = 0; rt < RTT; ++rt) {
-      const int lr = rt * 16 + li;
-      const int lc = lr < nrow ? lr : nrow - 1;
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + lc * D + f);
-      const f32x4 v = {acc[ft][rt][0] + bb[0] + xv[0], acc[ft][rt][1] + bb[1] + xv[1], acc[ft][rt][2] + bb[2] + xv[2], acc[ft][rt][3] + bb[3] + xv[3]};
-      acc[ft][rt] = v;
-      if constexpr (STORE) {
-        if (lr < nrow) *reinterpret_cast<f32x4*>(xb + lr * D + f) = v;
+    for (int u = 0; u < FG; ++u) {
+      const int f = wave * 64 + (f0 + u) * 16 + g * 4;
+      bb[u] = *reinterpret_cast<const f32x4*>(bias + f);
+#pragma unroll
+      for (int rt = 0; rt < RTT; ++rt) {
+        const int lr = rt * 16 + li;
+        const int lc = FULL ? lr : (lr < nrow ? lr : nrow - 1);
+        xv[u][rt] = *reinterpret_cast<const f32x4*>(xb + lc * D + f);
       }
     }
-    asm volatile("" ::: "memory");   // one feature tile's residual loads at a time (20 registers), not all four hoisted
+#pragma unroll
+    for (int u = 0; u < FG; ++u) {
+      const int ft = f0 + u, f = wave * 64 + ft * 16 + g * 4;
+#pragma unroll
+      for (int rt = 0; rt < RTT; ++rt) {
+        const int lr = rt * 16 + li;
+        const f32x4 v = {acc[ft][rt][0] + bb[u][0] + xv[u][rt][0], acc[ft][rt][1] + bb[u][1] + xv[u][rt][1], acc[ft][rt][2] + bb[u][2] + xv[u][rt][2],
+                         acc[ft][rt][3] + bb[u][3] + xv[u][rt][3]};
+        acc[ft][rt] = v;
+        if constexpr (STORE) {
+          if (FULL || lr < nrow) *reinterpret_cast<f32x4*>(xb + lr * D + f) = v;
+        }
+      }
+    }
+    if constexpr (FG < 4) asm volatile("" ::: "memory");   // the next group's loads stay behind this group's stores
+  }
+}
+template <int RTT, bool STORE>
+__device__ __forceinline__ void add_bias_residual(f32x4 (&acc)[4][RTT], const float* __restrict__ bias, float* __restrict__ xb, int nrow, int wave, int li, int g) {
+  if (nrow == RTT * 16) add_bias_residual_t<RTT, STORE, true>(acc, bias, xb, nrow, wave, li, g);
+  else add_bias_residual_t<RTT, STORE, false>(acc, bias, xb, nrow, wave, li, g);
+}
+
+// the bias quads of this lane's NFT feature tiles (loaded BEFORE the product whose epilogue uses them: the load hides under the product)
+template <int NFT>
+__device__ __forceinline__ void load_bias(f32x4 (&bb)[NFT], const float* __restrict__ bias, int fwave, int flimit, int g) {
+#pragma unroll
+  for (int ft = 0; ft < NFT; ++ft) {
+    const int f = fwave + ft * 16 + g * 4;
+    bb[ft] = f < flimit ? *reinterpret_cast<const f32x4*>(bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
 
-// out[row][col0 + f] = T(acc + bias[f]) (optionally ReLU): the q / q k v / logits stores.  ob = out + r0 * ld (first row of the workgroup)
-template <int NFT, int RTT, typename T, bool RELU>
-__device__ __forceinline__ void store_bias(const f32x4 (&acc)[NFT][RTT], const float* __restrict__ bias, T* __restrict__ ob, int ld, int nrow, int fwave, int flimit,
-                                           int li_, int g_) {
+// out[row][col0 + f] = T(acc + bias) (optionally ReLU): the q / q k v / logits stores.  ob = out + r0 * ld (first row of the workgroup)
+template <int NFT, int RTT, typename T, bool RELU, bool FULL>
+__device__ __forceinline__ void store_bias_t(const f32x4 (&acc)[NFT][RTT], const f32x4 (&bb)[NFT], T* __restrict__ ob, int ld, int nrow, int fwave, int flimit,
+                                             int li_, int g_) {
   const int li = opaque(li_), g = opaque(g_);
 #pragma unroll
   for (int ft = 0; ft < NFT; ++ft) {
     const int f = fwave + ft * 16 + g * 4;
-    if (f < flimit) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + f);
+    if (f < flimit) {   // wave-uniform per 16-feature tile up to the vocabulary edge (vocab % 4 == 0: a quad is live or dead as a whole)
 #pragma unroll
       for (int rt = 0; rt < RTT; ++rt) {
         const int lr = rt * 16 + li;
-        if (lr < nrow) {
+        if (FULL || lr < nrow) {
           float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { v[r] = acc[ft][rt][r] + bb[r]; if (RELU) v[r] = fmaxf(v[r], 0.f); }
+          for (int r = 0; r < 4; ++r) { v[r] = acc[ft][rt][r] + bb[ft][r]; if (RELU) v[r] = fmaxf(v[r], 0.f); }
           if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x4*>(ob + (int64_t)lr * ld + f) = f32x4{v[0], v[1], v[2], v[3]};
           else *reinterpret_cast<bf16x4*>(ob + (int64_t)lr * ld + f) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
         }
       }
     }
   }
+}
+template <int NFT, int RTT, typename T, bool RELU>
+__device__ __forceinline__ void store_bias(const f32x4 (&acc)[NFT][RTT], const f32x4 (&bb)[NFT], T* __restrict__ ob, int ld, int nrow, int fwave, int flimit, int li, int g) {
+  if (nrow == RTT * 16) store_bias_t<NFT, RTT, T, RELU, true>(acc, bb, ob, ld, nrow, fwave, flimit, li, g);
+  else store_bias_t<NFT, RTT, T, RELU, false>(acc, bb, ob, ld, nrow, fwave, flimit, li, g);
+}
+
+// x[row][f] = acc: the residual stream back to memory
+template <int RTT>
+__device__ __forceinline__ void store_x(const f32x4 (&acc)[4][RTT], float* __restrict__ xb, int nrow, int wave, int li_, int g_) {
+  const int li = opaque(li_), g = opaque(g_);
+  auto body = [&](auto FULL) {
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const int f = wave * 64 + ft * 16 + g * 4;
+#pragma unroll
+      for (int rt = 0; rt < RTT; ++rt) {
+        const int lr = rt * 16 + li;
+        if (decltype(FULL)::value || lr < nrow) *reinterpret_cast<f32x4*>(xb + lr * D + f) = acc[ft][rt];
+      }
+    }
+  };
+  if (nrow == RTT * 16) body(std::true_type());
+  else body(std::false_type());
 }
 
 struct RowsP {
@@ -299,6 +364,7 @@ struct RowsP {
   bf16_t* qkv;                     // [R, 1536]
   const float *h0_b, *h1_b, *h2_b;
   float* logits; int vocab;        // [R, vocab] fp32
+  unsigned long long* trace;       // development (omp_debug_swin_mlp_trace): [workgroup][16] cycle sums of wave 0 per phase of dec_rows_ffn_kernel
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -323,7 +389,7 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_mid_kernel(RowsP p) {
   sfor<PF>([&](auto U) { ws_issue<decltype(U)::value>(ring, st); });
   const int pos = *p.d_pos;
 
-  stage_rows<RTT>(p.att, r0, p.R, tile, tid);
+  stage_rows<RTT>(p.att, r0, p.R, tile, wave, lane);
   lds_barrier();
   const char* a_lane = tile + li * A_PITCH + g * 16;
   f32x4 acc[4][RTT];
@@ -333,9 +399,11 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_mid_kernel(RowsP p) {
   add_bias_residual<RTT, true>(acc, p.out_b, p.x + r0 * D, nrow, wave, li, g);
   ln_acc_to_tile<RTT>(acc, p.ln_g, p.ln_b, p.eps, tile, red, wave, li, g);
   zero_acc(acc);
+  f32x4 qb[4];
+  load_bias<4>(qb, p.qbias_tab + (int64_t)pos * D, wave * 64, D, g);
   gemm_pass<4, 16, RTT, A_PITCH>(acc, a_lane, ring, st);
   ws_drain(ring);
-  store_bias<4, RTT, bf16_t, false>(acc, p.qbias_tab + (int64_t)pos * D, p.q + r0 * D, D, nrow, wave * 64, D, li, g);
+  store_bias<4, RTT, bf16_t, false>(acc, qb, p.q + r0 * D, D, nrow, wave * 64, D, li, g);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's run-ahead requests (PF fragments of slack behind every stream)
 }
 
@@ -344,8 +412,10 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_mid_kernel(RowsP p) {
 // PRO 1: x' = LayerNorm(word[token] + position)                                            (layer 0: no stream)
 // TAIL 0: qkv = bf16(LayerNorm1'(x') Win^T + bias_tab[pos])                                stream: 3 x 64
 // TAIL 1: logits = h2(relu(h1(relu(h0(LayerNorm_f(x'))))))                                 stream: 64, 64, then ceil(vocab / 128) passes in 512 / 128 steps
+// PRO 2 / TAIL 2 / ACT 1 (GELU): the same chains for the blocks of Swin-B's stage 2 (C = 512), see omp_swin_rows_block below:
+// PRO 2: the tail's LayerNorm straight from the residual stream (the first block's norm1); TAIL 2: nothing behind the FFN (the last block)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int RTT, int PRO, int TAIL>
+template <int RTT, int PRO, int TAIL, int ACT>
 __global__ __launch_bounds__(NW * 64) void dec_rows_ffn_kernel(RowsP p) {
   constexpr int RT = RTT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -364,17 +434,39 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_ffn_kernel(RowsP p) {
   }
   u32x4 ring[PF];
   sfor<PF>([&](auto U) { ws_issue<decltype(U)::value>(ring, st); });
-  const int pos = *p.d_pos;
+  const int pos = p.d_pos != nullptr ? *p.d_pos : 0;
+  // development trace (p.trace): wave 0's cycles per phase -- 0 whole kernel, 1 prologue (rows staged / normalised), 2 out-projection product,
+  // 3 residual + LayerNorm + bias, 4 linear1 products, 5 barrier before the hidden tile is rewritten, 6 activation + LDS writes, 7 barrier
+  // behind them, 8 linear2 products, 9 x store, 10 the tail's LayerNorm, 11 the tail's products and stores
+  const bool tracing = p.trace != nullptr && wave == 0;
+  unsigned long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = tracing ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long t_begin = t_last;
+  auto stamp = [&](auto SLOT) {
+    if (tracing) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      tr[decltype(SLOT)::value] += t - t_last;
+      t_last = t;
+    }
+  };
+  typedef std::integral_constant<int, 1> S1; typedef std::integral_constant<int, 2> S2; typedef std::integral_constant<int, 3> S3;
+  typedef std::integral_constant<int, 4> S4; typedef std::integral_constant<int, 5> S5; typedef std::integral_constant<int, 6> S6;
+  typedef std::integral_constant<int, 7> S7; typedef std::integral_constant<int, 8> S8; typedef std::integral_constant<int, 9> S9;
+  typedef std::integral_constant<int, 10> S10; typedef std::integral_constant<int, 11> S11;
   const char* a_lane = tile + li * A_PITCH + g * 16;
   const int nrow = (int)((int64_t)p.R - r0 < RT ? (int64_t)p.R - r0 : RT);
   f32x4 acc[4][RTT];
 
   if constexpr (PRO == 0) {
-    stage_rows<RTT>(p.att, r0, p.R, tile, tid);
-    for (int i = tid; i < 4 * D / 4; i += NW * 64) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.ff1_b)[i];
+    static_assert(4 * D / 4 == NW * 64, "linear1's bias: one 16-byte piece per thread");
+    const f32x4 b1v = reinterpret_cast<const f32x4*>(p.ff1_b)[tid];   // requested before the rows: one wait covers both
+    stage_rows<RTT>(p.att, r0, p.R, tile, wave, lane);
+    reinterpret_cast<f32x4*>(b1s)[tid] = b1v;
     lds_barrier();
+    stamp(S1());
     zero_acc(acc);
     gemm_pass<4, 16, RTT, A_PITCH>(acc, a_lane, ring, st);
+    stamp(S2());
     add_bias_residual<RTT, false>(acc, p.out_b, p.x + r0 * D, nrow, wave, li, g);
     ln_acc_to_tile<RTT>(acc, p.ln_g, p.ln_b, p.eps, tile, red, wave, li, g);
     // linear2's accumulators start as x1 + b2
@@ -386,42 +478,45 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_ffn_kernel(RowsP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[ft][rt][r] += bb[r];
     }
+    stamp(S3());
 #pragma unroll 1
     for (int c = 0; c < 4 * D / HC; ++c) {
       f32x4 a1[2][RTT];
       zero_acc(a1);
       gemm_pass<2, 16, RTT, A_PITCH>(a1, a_lane, ring, st);   // hidden units c * 256 + 32 w + 16 t + 4 g + r of the rows
+      stamp(S4());
       lds_barrier();   // everybody has left linear2 of chunk c - 1: the hidden tile may be overwritten
+      stamp(S5());
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + c * HC + wave * 32 + t * 16 + g * 4);
 #pragma unroll
         for (int rt = 0; rt < RTT; ++rt) {
-          bf16x4 o;
+          float hv[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)fmaxf(a1[t][rt][r] + bb[r], 0.f);
-          *reinterpret_cast<bf16x4*>(hbuf + (rt * 16 + li) * H_PITCH + (wave * 32 + t * 16 + g * 4) * 2) = o;
+          for (int r = 0; r < 4; ++r) hv[r] = a1[t][rt][r] + bb[r];
+          if constexpr (ACT == 1) {
+            gelu_fast_n<4>(hv);   // the bf16 engine's GELU on every epilogue path (common.h): a value does not depend on the kernel that produced it
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = fmaxf(hv[r], 0.f);
+          }
+          *reinterpret_cast<bf16x4*>(hbuf + (rt * 16 + li) * H_PITCH + (wave * 32 + t * 16 + g * 4) * 2) = bf16x4{(bf16_t)hv[0], (bf16_t)hv[1], (bf16_t)hv[2], (bf16_t)hv[3]};
         }
       }
+      stamp(S6());
       lds_barrier();   // chunk c is complete in LDS
+      stamp(S7());
       gemm_pass<4, HC / 32, RTT, H_PITCH>(acc, hbuf + li * H_PITCH + g * 16, ring, st);
+      stamp(S8());
     }
+    if constexpr (TAIL == 2) ws_drain(ring);   // no product follows: the ring's run-ahead requests must land before its registers are reused
     // acc = x' : back to memory (the next attention sub-layer's residual), then the tail consumes it from registers
-    {
-      const int lo = opaque(li), go = opaque(g);
-      float* xb = p.x + r0 * D;
-#pragma unroll
-      for (int ft = 0; ft < 4; ++ft) {
-        const int f = wave * 64 + ft * 16 + go * 4;
-#pragma unroll
-        for (int rt = 0; rt < RTT; ++rt) {
-          const int lr = rt * 16 + lo;
-          if (lr < nrow) *reinterpret_cast<f32x4*>(xb + lr * D + f) = acc[ft][rt];
-        }
-      }
-    }
-    ln_acc_to_tile<RTT>(acc, p.lnt_g, p.lnt_b, p.eps, tile, red, wave, li, g);
-  } else {
+    store_x<RTT>(acc, p.x + r0 * D, nrow, wave, li, g);
+    stamp(S9());
+    if constexpr (TAIL != 2) ln_acc_to_tile<RTT>(acc, p.lnt_g, p.lnt_b, p.eps, tile, red, wave, li, g);
+    stamp(S10());
+  } else if constexpr (PRO == 1) {
     // embedding + LayerNorm -> x (fp32), then the tail's LayerNorm -> operand tile: a wave per row, RT / NW rows per wave with every
     // row's loads issued before the first row's arithmetic (one memory round trip for the lot, not one per row)
     constexpr int RPW = RT / NW;
@@ -458,19 +553,44 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_ffn_kernel(RowsP p) {
       *reinterpret_cast<bf16x8*>(tile + (wave * RPW + i) * A_PITCH + lane * 16) = o;
     }
     lds_barrier();
+  } else {
+    // PRO 2: the rows of the fp32 residual stream as they are -> the tail's LayerNorm -> operand tile (a wave per row, every row's loads first)
+    constexpr int RPW = RT / NW;
+    static_assert(RT % NW == 0, "rows per wave");
+    const float* xb = p.x + r0 * D;
+    f32x4 xv[RPW][2];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      int lr = wave * RPW + i;
+      if (lr > nrow - 1) lr = nrow - 1;
+      xv[i][0] = *reinterpret_cast<const f32x4*>(xb + lr * D + lane * 8);
+      xv[i][1] = *reinterpret_cast<const f32x4*>(xb + lr * D + lane * 8 + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      float v[8] = {xv[i][0][0], xv[i][0][1], xv[i][0][2], xv[i][0][3], xv[i][1][0], xv[i][1][1], xv[i][1][2], xv[i][1][3]};
+      ln_row512(v, p.lnt_g, p.lnt_b, lane, p.eps);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+      *reinterpret_cast<bf16x8*>(tile + (wave * RPW + i) * A_PITCH + lane * 16) = o;
+    }
+    lds_barrier();
   }
 
   if constexpr (TAIL == 0) {
     auto qkv_pass = [&](int ps, auto LAST) {
       zero_acc(acc);
+      f32x4 bb[4];
+      load_bias<4>(bb, p.bias_tab + (int64_t)pos * (3 * D) + ps * D, wave * 64, D, g);
       gemm_pass<4, 16, RTT, A_PITCH>(acc, a_lane, ring, st);
       if constexpr (decltype(LAST)::value) ws_drain(ring);
-      store_bias<4, RTT, bf16_t, false>(acc, p.bias_tab + (int64_t)pos * (3 * D) + ps * D, p.qkv + r0 * (3 * D) + ps * D, 3 * D, nrow, wave * 64, D, li, g);
+      store_bias<4, RTT, bf16_t, false>(acc, bb, p.qkv + r0 * (3 * D) + ps * D, 3 * D, nrow, wave * 64, D, li, g);
     };
 #pragma unroll 1
     for (int ps = 0; ps < 2; ++ps) qkv_pass(ps, std::false_type());
     qkv_pass(2, std::true_type());
-  } else {
+  } else if constexpr (TAIL == 1) {
     // prediction head (block/mlp.py:11-13): two hidden layers with ReLU through the operand tile, then the vocabulary projection
 #pragma unroll 1
     for (int hl = 0; hl < 2; ++hl) {
@@ -497,118 +617,29 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_ffn_kernel(RowsP p) {
 #pragma unroll 1
     for (int ps = 0; ps < n512; ++ps) {
       zero_acc(acc);
+      f32x4 bb[4];
+      load_bias<4>(bb, p.h2_b, ps * 512 + wave * 64, V, g);
       gemm_pass<4, 16, RTT, A_PITCH>(acc, a_lane, ring, st);
       ws_drain(ring);   // (after EVERY vocabulary pass: which one is the last depends on the vocabulary; once per step, ~0.5 us each)
-      // vocab % 4 == 0 (checked by the host): a quad of features is live or dead as a whole
-      store_bias<4, RTT, float, false>(acc, p.h2_b, p.logits + r0 * V, V, nrow, ps * 512 + wave * 64, V, li, g);
+      store_bias<4, RTT, float, false>(acc, bb, p.logits + r0 * V, V, nrow, ps * 512 + wave * 64, V, li, g);
     }
 #pragma unroll 1
     for (int ps = 0; ps < n128; ++ps) {
       f32x4 a1[1][RTT];
       zero_acc(a1);
+      f32x4 bb[1];
+      load_bias<1>(bb, p.h2_b, n512 * 512 + ps * 128 + wave * 16, V, g);
       gemm_pass<1, 16, RTT, A_PITCH>(a1, a_lane, ring, st);
       ws_drain(ring);
-      store_bias<1, RTT, float, false>(a1, p.h2_b, p.logits + r0 * V, V, nrow, n512 * 512 + ps * 128 + wave * 16, V, li, g);
+      store_bias<1, RTT, float, false>(a1, bb, p.logits + r0 * V, V, nrow, n512 * 512 + ps * 128 + wave * 16, V, li, g);
     }
   }
+  stamp(S11());
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The same chain for the MLP half of a Swin block at C = 512 (stage 2 of Swin-B: 18 of the 24 blocks, 60 % of the encoder):
-//     x = x + fc2(GELU(fc1(LayerNorm(x))))          swin_transformer.py:250 with Mlp.forward (:30-36) inlined
-// Round 4 ran it as LayerNorm + fc1 (GELU epilogue) + fc2 (fp32 residual epilogue): three launches, the [tokens, 2048] hidden tensor and
-// the normalised rows through HBM, 0.70 + 0.92 PFLOP/s on the two products.  Here a workgroup owns 80 tokens: LayerNorm from the fp32
-// residual stream into the operand tile (a wave per row), linear2's accumulators start as x + b2, the hidden activations of a chunk
-// of 256 units go through LDS, only x is read and written.  stream: 8 x [fc1 chunk (32 fragments per wave), fc2 chunk (32)].
-// ---------------------------------------------------------------------------------------------------------------------
-struct MlpRowsP {
-  float* x; int64_t M;
-  const float *ln_g, *ln_b; float eps;
-  const char* wstream; int64_t wave_stride;
-  const float *b1, *b2;
-};
-
-template <int RTT>
-__global__ __launch_bounds__(NW * 64) void swin_rows_mlp_kernel(MlpRowsP p) {
-  constexpr int RT = RTT * 16, RPW = RT / NW;
-  static_assert(RT % NW == 0, "rows per wave");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* tile = smem;                                                          // RT x A_PITCH
-  char* hbuf = smem + RT * A_PITCH + TILE_SLACK;                              // RT x H_PITCH
-  float* b1s = reinterpret_cast<float*>(hbuf + RT * H_PITCH + TILE_SLACK);    // 2048 floats
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t r0 = (int64_t)blockIdx.x * RT;
-  Stream st;
-  {
-    const uint64_t bs = reinterpret_cast<uint64_t>(p.wstream + (int64_t)wave * p.wave_stride);
-    st.base = reinterpret_cast<const char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bs >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bs));
-    st.voff = lane * 16;
-  }
-  u32x4 ring[PF];
-  sfor<PF>([&](auto U) { ws_issue<decltype(U)::value>(ring, st); });
-  const int nrow = (int)(p.M - r0 < RT ? p.M - r0 : RT);
-  float* xb = p.x + r0 * D;
-  {
-    // LayerNorm: a wave per row, every row's loads first
-    f32x4 xv[RPW][2];
+  if (tracing && lane == 0) {
+    tr[0] = __builtin_amdgcn_s_memtime() - t_begin;
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      int lr = wave * RPW + i;
-      if (lr > nrow - 1) lr = nrow - 1;
-      xv[i][0] = *reinterpret_cast<const f32x4*>(xb + lr * D + lane * 8);
-      xv[i][1] = *reinterpret_cast<const f32x4*>(xb + lr * D + lane * 8 + 4);
-    }
-    for (int i = tid; i < 4 * D / 4; i += NW * 64) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      float v[8] = {xv[i][0][0], xv[i][0][1], xv[i][0][2], xv[i][0][3], xv[i][1][0], xv[i][1][1], xv[i][1][2], xv[i][1][3]};
-      ln_row512(v, p.ln_g, p.ln_b, lane, p.eps);
-      bf16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
-      *reinterpret_cast<bf16x8*>(tile + (wave * RPW + i) * A_PITCH + lane * 16) = o;
-    }
-  }
-  lds_barrier();
-  const char* a_lane = tile + li * A_PITCH + g * 16;
-  f32x4 acc[4][RTT];
-  zero_acc(acc);
-  add_bias_residual<RTT, false>(acc, p.b2, xb, nrow, wave, li, g);   // fc2's accumulators start as x + b2 (the rows are L2 hits now)
-#pragma unroll 1
-  for (int c = 0; c < 4 * D / HC; ++c) {
-    f32x4 a1[2][RTT];
-    zero_acc(a1);
-    gemm_pass<2, 16, RTT, A_PITCH>(a1, a_lane, ring, st);
-    lds_barrier();
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + c * HC + wave * 32 + t * 16 + g * 4);
-#pragma unroll
-      for (int rt = 0; rt < RTT; ++rt) {
-        float hv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hv[r] = a1[t][rt][r] + bb[r];
-        gelu_fast_n<4>(hv);   // the bf16 engine's GELU on every epilogue path (common.h): a value does not depend on the kernel that produced it
-        *reinterpret_cast<bf16x4*>(hbuf + (rt * 16 + li) * H_PITCH + (wave * 32 + t * 16 + g * 4) * 2) = bf16x4{(bf16_t)hv[0], (bf16_t)hv[1], (bf16_t)hv[2], (bf16_t)hv[3]};
-      }
-    }
-    lds_barrier();
-    gemm_pass<4, HC / 32, RTT, H_PITCH>(acc, hbuf + li * H_PITCH + g * 16, ring, st);
-  }
-  ws_drain(ring);
-  {
-    const int lo = opaque(li), go = opaque(g);
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
-      const int f = wave * 64 + ft * 16 + go * 4;
-#pragma unroll
-      for (int rt = 0; rt < RTT; ++rt) {
-        const int lr = rt * 16 + lo;
-        if (lr < nrow) *reinterpret_cast<f32x4*>(xb + lr * D + f) = acc[ft][rt];
-      }
-    }
+    for (int i = 0; i < 12; ++i) p.trace[(int64_t)blockIdx.x * 16 + i] = tr[i];
   }
 }
 
@@ -623,18 +654,18 @@ int raise_lds(K kern, const char* what) {
   return OMP_OK;
 }
 
-template <int PRO, int TAIL>
+template <int PRO, int TAIL, int ACT = 0>
 int launch_ffn(const RowsP& p, hipStream_t st) {
   constexpr int RTT = RTT_DEFAULT, RT = RTT * 16;
   const size_t smem = (size_t)RT * A_PITCH + TILE_SLACK + RT * H_PITCH + TILE_SLACK + 2 * NW * RT * 4 + 4 * D * 4;
-  auto kern = dec_rows_ffn_kernel<RTT, PRO, TAIL>;
+  auto kern = dec_rows_ffn_kernel<RTT, PRO, TAIL, ACT>;
   static bool done = false;   // per instantiation
   if (!done) {
     const int rc = raise_lds(kern, "omp_dec_rows_ffn");
     if (rc != OMP_OK) return rc;
     done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((p.R + RT - 1) / RT), dim3(NW * 64), smem, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(((int64_t)p.R + RT - 1) / RT)), dim3(NW * 64), smem, st, p);
   OMP_CHECK_LAUNCH("omp_dec_rows_ffn");
   return OMP_OK;
 }
@@ -698,27 +729,38 @@ extern "C" int omp_dec_rows_ffn(const omp_dec_rows_args* a, omp_stream_t s) {
 
 extern "C" int omp_dec_rows_tile(void) { return omp_rows_tile(); }
 
-extern "C" int omp_swin_mlp_rows(float* x, int64_t M, const float* ln_gamma, const float* ln_beta, float eps, const void* wstream, int64_t wave_stride,
-                                 const float* b1, const float* b2, omp_stream_t s) {
-  OMP_CHECK_ARG(x && ln_gamma && ln_beta && wstream && b1 && b2, "omp_swin_mlp_rows: null pointer");
-  OMP_CHECK_ARG(M > 0 && M < (1ll << 31), "omp_swin_mlp_rows: bad M=%lld", (long long)M);
-  OMP_CHECK_ARG(wave_stride >= 512 * 1024 && wave_stride % 16 == 0 && ((uintptr_t)wstream % 16) == 0 && ((uintptr_t)x % 16) == 0, "omp_swin_mlp_rows: a wave's stream holds 512 fragments of 1 KB; 16-byte aligned pointers");
-  MlpRowsP p{};
-  p.x = x; p.M = M; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.eps = eps; p.wstream = reinterpret_cast<const char*>(wstream); p.wave_stride = wave_stride;
-  p.b1 = b1; p.b2 = b2;
-  constexpr int RTT = RTT_DEFAULT, RT = RTT * 16;
-  const size_t smem = (size_t)RT * A_PITCH + TILE_SLACK + RT * H_PITCH + TILE_SLACK + 4 * D * 4;
-  auto kern = swin_rows_mlp_kernel<RTT>;
-  static bool done = false;
-  if (!done) {
-    const int rc = raise_lds(kern, "omp_swin_mlp_rows");
-    if (rc != OMP_OK) return rc;
-    done = true;
-  }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Swin-B stage 2 (C = 512, 16 heads: 18 of the 24 blocks, 60 % of the encoder) on the same chains.  Everything of a block except the
+// window attention core is row-local:
+//     x = x + proj(attn(norm1(x)));  x = x + fc2(GELU(fc1(norm2(x))))                  swin_transformer.py:196-253
+// so a block is TWO launches -- the window attention kernel on q | k | v, then ONE chain: proj + residual, norm2, fc1 + GELU, fc2 + residual,
+// and already the NEXT block's norm1 + qkv Linear -- instead of seven (LayerNorm, qkv, attention, proj, LayerNorm, fc1, fc2); the
+// normalised rows, the hidden activations and the residual stream between the sub-layers never reach HBM.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int omp_swin_rows_block(const omp_swin_rows_args* a, omp_stream_t s) {
+  OMP_CHECK_ARG(a != nullptr, "omp_swin_rows_block: null argument block");
+  OMP_CHECK_ARG(a->M > 0 && a->M < (1ll << 31) && a->x && a->wstream, "omp_swin_rows_block: bad M / null pointer");
+  OMP_CHECK_ARG(a->mode == 0 || a->mode == 1, "omp_swin_rows_block: mode 0 (norm1 + qkv) or 1 (proj + MLP [+ next norm1 + qkv])");
+  const bool tail_qkv = a->n1_g != nullptr;
+  if (a->mode == 0) OMP_CHECK_ARG(tail_qkv && a->n1_b && a->qkv_b && a->qkv, "omp_swin_rows_block: mode 0 needs norm1, the qkv bias and the qkv destination");
+  else OMP_CHECK_ARG(a->att && a->proj_b && a->n2_g && a->n2_b && a->fc1_b && a->fc2_b && (!tail_qkv || (a->n1_b && a->qkv_b && a->qkv)), "omp_swin_rows_block: null pointer");
+  const int64_t frags = (a->mode == 1 ? 64 + 8 * 64 : 0) + (tail_qkv ? 192 : 0);
+  OMP_CHECK_ARG(a->wave_stride >= frags * 1024 && a->wave_stride % 16 == 0 && ((uintptr_t)a->wstream % 16) == 0 && ((uintptr_t)a->x % 16) == 0,
+                "omp_swin_rows_block: a wave's stream holds %lld fragments of 1 KB here; 16-byte aligned pointers", (long long)frags);
+  RowsP p{};
+  p.R = (int)a->M; p.eps = a->eps; p.d_pos = nullptr; p.x = a->x; p.att = reinterpret_cast<const bf16_t*>(a->att);
+  p.wstream = reinterpret_cast<const char*>(a->wstream); p.wave_stride = a->wave_stride;
+  p.out_b = a->proj_b; p.ln_g = a->n2_g; p.ln_b = a->n2_b; p.ff1_b = a->fc1_b; p.ff2_b = a->fc2_b;
+  p.lnt_g = a->n1_g; p.lnt_b = a->n1_b; p.bias_tab = a->qkv_b; p.qkv = reinterpret_cast<bf16_t*>(a->qkv);
+  p.trace = omp_cur().mlp_trace;   // omp_debug_swin_mlp_trace: the development buffer also takes this kernel's phase sums ([workgroup][16])
   hipStream_t st = (hipStream_t)s;
-  const int slot = omp_prof_active(OMP_PROF_MLP) ? omp_prof_begin(OMP_PROF_MLP, st, 4.0 * (double)M * D * 4 * D, 8.0 * (double)M * D + 4.0 * D * 4 * D) : -1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((M + RT - 1) / RT)), dim3(NW * 64), smem, st, p);
+  const double fl = 2.0 * (double)a->M * D * ((a->mode == 1 ? D + 8.0 * D : 0.0) + (tail_qkv ? 3.0 * D : 0.0));
+  const double by = (double)a->M * D * (a->mode == 1 ? 2 + 4 + 4 : 4) + (tail_qkv ? (double)a->M * 3 * D * 2 : 0.0) + (double)frags * 8192;
+  const int slot = omp_prof_active(OMP_PROF_MLP) ? omp_prof_begin(OMP_PROF_MLP, st, fl, by) : -1;
+  int rc;
+  if (a->mode == 0) rc = launch_ffn<2, 0, 1>(p, st);
+  else rc = tail_qkv ? launch_ffn<0, 0, 1>(p, st) : launch_ffn<0, 2, 1>(p, st);
   if (slot >= 0) omp_prof_end(OMP_PROF_MLP, slot, st);
-  OMP_CHECK_LAUNCH("omp_swin_mlp_rows");
-  return OMP_OK;
+  return rc;
 }

@@ -788,7 +788,34 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
       if ((which == 9 || which == 10 || which == 20) && gemm4wx3_ok(p, true, std::is_same<TOut, bf16_t>::value)) which = 22;
     }
   }
-  if (cx.gemm_choice_only) { cx.gemm_last_choice = which; return OMP_OK; }   // omp_debug_gemm_choice: the dispatch table is host logic, testable without a GPU
+  if (cx.gemm_choice_only) {
+    // omp_debug_gemm_choice: the dispatch table is host logic, testable without a GPU.  It reports a selector only for arguments the
+    // launch path below accepts -- a forced selector that does not take the product (no second destination, a shape its tiles do not
+    // cover, non-bf16 operands) is the launch path's OMP_ERR_UNSUPPORTED here too
+    bool ok = true;
+    constexpr bool BO = std::is_same<TOut, bf16_t>::value;
+    if (p.C2 != nullptr && which != 5 && which != 6 && which != 9 && which != 10 && which != 11 && which != 15 && which != 16 && which != 18 && which != 20 && which != 21 && which != 22) ok = false;
+    else if (which == 9 || (which >= 10 && which <= 14) || (which >= 16 && which <= 18) || (which >= 20 && which <= 22)) {
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        if (which == 9) ok = gemm256_ok(p, true, BO);
+        else if (which == 10 || which == 11) ok = gemm4w_ok(p, true, BO);
+        else if (which >= 12 && which <= 14) ok = BO && gemm4w_ok(p, true, true) && p.store_mode == OMP_STORE_PLAIN && !p.split_out;
+        else if (which >= 16 && which <= 18) ok = gemm4wr_ok(p, true, BO) && (which != 17 || (BO && !p.split_out));
+        else if (which == 20 || which == 21) ok = gemm4wp_ok(p, true, BO) && (which != 21 || !BO);
+        else ok = gemm4wx3_ok(p, true, BO);
+      } else {
+        ok = false;
+      }
+    } else if (which != 3 && which != 5 && which != 6 && which != 15) {
+      ok = false;
+    }
+    if (!ok) {
+      omp_set_error("omp_gemm_bias_act: kernel selector %d does not take this product", which);
+      return OMP_ERR_UNSUPPORTED;
+    }
+    cx.gemm_last_choice = which;
+    return OMP_OK;
+  }
   if (p.C2 != nullptr && which != 5 && which != 6 && which != 9 && which != 10 && which != 11 && which != 15 && which != 16 && which != 18 && which != 20 && which != 21 && which != 22) {
     omp_set_error("omp_gemm_bias_act: kernel selector %d has no second destination (C2)", which);
     return OMP_ERR_UNSUPPORTED;

@@ -13,7 +13,7 @@ extern "C" {
 #endif
 
 int omp_debug_swin_mlp_variant(int v); /* alternative (rows per wave, waves, ring depth) instantiations of the fused MLP; 100 = traced default */
-int omp_debug_swin_mlp_trace(void* buffer); /* uint64 [workgroups][8] cycle sums written by variant 100 (csrc/mlp.hip); while set, omp_swin_attn_block launches its traced instantiation into the same buffer (csrc/swin_block.hip) */
+int omp_debug_swin_mlp_trace(void* buffer); /* uint64 [workgroups][8] cycle sums written by variant 100 (csrc/mlp.hip); while set, omp_swin_attn_block launches its traced instantiation into the same buffer (csrc/swin_block.hip) and omp_swin_rows_block writes uint64 [workgroups][16] phase sums of wave 0 (csrc/dec_rows.hip: 0 whole, 1 prologue, 2 out-projection, 3 residual + LayerNorm, 4 linear1, 5 / 7 the two barriers of a chunk, 6 activation + LDS writes, 8 linear2, 9 x store, 10 tail LayerNorm, 11 tail products) */
 
 /* ---- streams on a subset of the compute units (engine/pipeline.py: HBM-bound decoder phases of one engine call
  * next to the matrix-core-bound encoder of another) ---------------------------------------------------------------

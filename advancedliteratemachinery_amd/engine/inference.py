@@ -127,6 +127,59 @@ def _meta(t):
     return {'file_name': t['file_name'], 'orig_size': (float(h), float(w)), 'dataset_name': t.get('dataset_name', 'results')}
 
 
+def plan_eos_balance(pred, world, batch_size):
+    """Straggler balance for EOS-honouring inference ("expected scaling loss comes from ragged decode length (straggler
+    rank), not bandwidth -> balance by sorting / bucketing images by predicted N").  An image's decode time grows with its instance count
+    (2 N point steps, then N polygon and N recognition rows); images of one engine call are decoded in lock-step, so a call costs its
+    DENSEST image, and a rank costs the sum of its calls -- contiguous shards of a dataset whose dense pages sit together make one rank
+    the straggler of every all-gather.
+      pred: predicted instance count (any cost proxy) per image, dataset order -- annotation counts of a validation set, the previous
+            epoch's decoded counts, a detector's proposals;
+      -> plan[rank] = list of batches, each a list of GLOBAL image indices.
+    (1) across ranks: longest-processing-time-first -- images by predicted cost, descending, each to the least-loaded rank that still has
+        room; shard SIZES stay those of utils/dist.py::shard_range, so every rank makes the same number of engine calls (+-1) and the
+        padded all-gather is unchanged;
+    (2) inside a rank: by predicted cost, descending, cut into batches of `batch_size`: images that finish together are decoded together.
+    Deterministic (ties by index): every rank computes the same plan without communicating."""
+    n = len(pred)
+    cap = [udist.shard_range(n, r, world)[1] - udist.shard_range(n, r, world)[0] for r in range(world)]
+    load = [0.0] * world
+    mine = [[] for _ in range(world)]
+    for i in sorted(range(n), key=lambda i: (-float(pred[i]), i)):
+        r = min((r for r in range(world) if len(mine[r]) < cap[r]), key=lambda r: (load[r], r))
+        mine[r].append(i)
+        load[r] += float(pred[i])
+    bs = max(1, int(batch_size))
+    plan = []
+    for r in range(world):
+        order = sorted(mine[r], key=lambda i: (-float(pred[i]), i))
+        plan.append([order[o:o + bs] for o in range(0, len(order), bs)])
+    return plan
+
+
+def plan_cost(plan, pred):
+    """lock-step cost model of a plan: per rank, the sum over its engine calls of the call's densest image -> list per rank"""
+    return [sum(max(float(pred[i]) for i in b) for b in batches if b) for batches in plan]
+
+
+def _items_by_index(dataloader, order):
+    """the items of `dataloader` with the given GLOBAL indices, in that order, without touching the others (map-style DataLoader that walks
+    its dataset in order: re-pointed at Subset(dataset, order); a sequence: indexed)."""
+    ds = getattr(dataloader, 'dataset', None)
+    if isinstance(dataloader, torch.utils.data.DataLoader) and ds is not None and hasattr(ds, '__getitem__') and \
+            (dataloader.batch_size in (1, None)) and len(ds) == len(dataloader) and \
+            isinstance(getattr(dataloader, 'sampler', None), torch.utils.data.SequentialSampler):
+        kw = {}
+        if dataloader.num_workers > 0:
+            kw = dict(prefetch_factor=dataloader.prefetch_factor, persistent_workers=dataloader.persistent_workers)
+        return torch.utils.data.DataLoader(torch.utils.data.Subset(ds, list(order)), batch_size=dataloader.batch_size, shuffle=False,
+                                           num_workers=dataloader.num_workers, collate_fn=dataloader.collate_fn, pin_memory=dataloader.pin_memory,
+                                           worker_init_fn=dataloader.worker_init_fn, **kw)
+    if isinstance(dataloader, (list, tuple)):
+        return [dataloader[i] for i in order]
+    raise TypeError('EOS balancing (args.eos_pred_counts) needs a sized, index-addressable loader: a sequence or a DataLoader over a map-style dataset in order')
+
+
 def _rank_items(dataloader, rank, ws, sharded):
     """This rank's part of the validation set WITHOUT decoding the other ranks' images (every rank used to iterate the
     whole loader and discard what was not its own).  A torch DataLoader with a map-style dataset is re-pointed at
@@ -169,22 +222,44 @@ def validate(model, dataloader, epoch, args, batch_size=1):
     `batch_size` consecutive items are merged into one engine call (different sizes are padded and masked exactly as the
     reference's collate would), decoded token tensors are packed to fixed size and all-gathered ONCE at the end, and
     rank 0 formats and writes <output_folder>/results/epXXX/<dataset>.json (text spotting) or one <file_name>.json per
-    image (KIE).  Returns the records on rank 0 (a list; per-image lists for KIE) and [] elsewhere."""
+    image (KIE).  Returns the records on rank 0 (a list; per-image lists for KIE) and [] elsewhere.
+    args.eos_pred_counts (optional: one predicted instance count per dataloader item) switches the contiguous shards for plan_eos_balance's:
+    cost-balanced across ranks, homogeneous inside an engine call; the output is the same, in dataset order."""
     model.eval()
     rank, ws = udist.world()
     dev = next(model.parameters()).device
     sharded = bool(getattr(args, 'dataloader_is_sharded', False))
-    items, lo, hi = _rank_items(dataloader, rank, ws, sharded)
+    pred = getattr(args, 'eos_pred_counts', None)
     kie = args.vie_categories > 0
     local_raw, local_meta = [], []
     pend_imgs, pend_tg = [], []
+    if pred is not None and not sharded:
+        # balanced shards + homogeneous batches (plan_eos_balance): this rank's images in plan order, engine calls cut where the plan cuts;
+        # every meta carries its dataset index so that rank 0 restores dataset order before formatting (the JSON is the unbalanced run's)
+        if len(pred) != len(dataloader):
+            raise ValueError('args.eos_pred_counts holds %d entries for %d dataloader items' % (len(pred), len(dataloader)))
+        my = plan_eos_balance(pred, ws, batch_size)[rank]
+        order = [i for b in my for i in b]
+        cuts = set()
+        acc = 0
+        for b in my:
+            acc += len(b)
+            cuts.add(acc)
+        items, lo = _items_by_index(dataloader, order), 0
+    else:
+        items, lo, hi = _rank_items(dataloader, rank, ws, sharded)
+        order, cuts = None, None
+    seen = [0]
 
     def flush():
         if not pend_imgs:
             return
         raw, _ = predict_raw(model, list(pend_imgs), args, [t['orig_size'] for t in pend_tg] if args.infer_vie else None)
         local_raw.extend(raw)
-        local_meta.extend(_meta(t) for t in pend_tg)
+        for t in pend_tg:
+            m = _meta(t)
+            m['_idx'] = order[len(local_meta)] if order is not None else lo + len(local_meta)
+            local_meta.append(m)
         del pend_imgs[:], pend_tg[:]
 
     for samples, targets in items:
@@ -192,7 +267,8 @@ def validate(model, dataloader, epoch, args, batch_size=1):
         for img, t in zip(nt.unpad_tensors(), targets):
             pend_imgs.append(img)
             pend_tg.append(t)
-            if len(pend_imgs) >= max(1, int(batch_size)):
+            seen[0] += 1
+            if (cuts is not None and seen[0] in cuts) or (cuts is None and len(pend_imgs) >= max(1, int(batch_size))):
                 flush()
     flush()
 
@@ -206,6 +282,7 @@ def validate(model, dataloader, epoch, args, batch_size=1):
             pairs = [p for part in allp for p in part]
         if rank != 0:
             return []
+        pairs.sort(key=lambda mr: mr[0]['_idx'])
         if folder is not None:
             for m, r in pairs:
                 path = os.path.join(folder, m['file_name'] + '.json')
@@ -231,14 +308,17 @@ def validate(model, dataloader, epoch, args, batch_size=1):
         return []
     results, last = [], None
     per_rank = [metas] if ws == 1 else metas
+    every = []
     for r_, ms in enumerate(per_rank):
         outs = udist.unpack_results(ids[r_ * n_max:r_ * n_max + len(ms)].cpu(), probs[r_ * n_max:r_ * n_max + len(ms)].cpu(),
                                     n_inst[r_ * n_max:r_ * n_max + len(ms)].cpu())
-        for m, o in zip(ms, outs):
-            last = m
-            if o is None:       # the reference skips empty outputs (val.py:36-37)
-                continue
-            results.extend(decode_pred_seq([t[0] for t in o[0]], o[1][0], m, args))
+        every.extend(zip(ms, outs))
+    every.sort(key=lambda mo: mo[0]['_idx'])     # dataset order, whatever the sharding was
+    for m, o in every:
+        last = m
+        if o is None:       # the reference skips empty outputs (val.py:36-37)
+            continue
+        results.extend(decode_pred_seq([t[0] for t in o[0]], o[1][0], m, args))
     if folder is not None and last is not None:
         os.makedirs(folder, exist_ok=True)
         with open(os.path.join(folder, last['dataset_name'] + '.json'), 'w') as f:

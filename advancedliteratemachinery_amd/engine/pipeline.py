@@ -19,6 +19,8 @@ from concurrent.futures import Future
 
 import torch
 
+from ..utils.env import env_flag
+
 
 class Lane(object):
     def __init__(self, device, index, dec_priority=False, side_streams=True):
@@ -58,7 +60,7 @@ class LanePool(object):
         if self.device.index is None:   # torch.cuda.set_device() in the lane threads needs an explicit index
             self.device = torch.device(self.device.type, torch.cuda.current_device())
         if dec_priority is None:
-            dec_priority = os.environ.get('OMP355_DEC_PRIORITY', '0') == '1'
+            dec_priority = env_flag('OMP355_DEC_PRIORITY', False)
         from .. import ops
         self._ctx = ops.current_context_handle()   # lane threads work on the omp_ctx of the thread that built the pool
         self.lanes = [Lane(self.device, i, dec_priority, side_streams) for i in range(max(1, n_lanes))]

@@ -21,27 +21,27 @@ Engine precisions (model/omniparser.py `engine_dtype`):
 import torch
 
 from .. import ops
-import os
-
-from .packing import pack_attn_block, pack_mlp, pack_rows_mlp
+from ..utils.env import env_int
+from .packing import pack_attn_block, pack_mlp, pack_rows_embed_qkv, pack_rows_ffn, pack_rows_ffn_qkv
 
 LN_EPS = 1e-5
 # stages whose MLP runs as ONE fused launch in the bf16 engine (csrc/mlp.hip); at C >= 512 the row-stationary kernel is
 # bound by its weight stream and the two GEMMs win (profiles/r02c_kbench_mlp.txt)
 FUSED_MLP_WIDTHS = (128, 256)
-# C = 512 (stage 2 of Swin-B: 18 of the 24 blocks): the MLP half as a ROW-OWNER chain (csrc/dec_rows.hip::swin_rows_mlp_kernel, round 5) once a
-# launch has at least this many tokens -- 899 -> 646 us per block at the encoder's 131 072-token chunks, equal at 32 768, slower below
-# (a workgroup streams the block's 4 MB of weights for its 80 tokens: it needs several workgroups per compute unit to pay)
-ROWS_MLP_MIN_TOKENS = int(os.environ.get('OMP355_MLP_ROWS_MIN', '32768'))
+# C = 512 (stage 2 of Swin-B: 18 of the 24 blocks, 60 % of the encoder): everything of a block except the window attention core as ONE row-owner
+# chain (csrc/dec_rows.hip, omp_swin_rows_block, round 5) -- proj + residual, norm2, fc1 + GELU, fc2 + residual and the NEXT block's norm1 + qkv
+# -- once a launch has at least this many tokens (a workgroup streams the chain's 6 MB of weights for its 80 tokens: it needs several
+# workgroups per compute unit to pay; below, the launch-per-Linear path)
+ROWS_BLOCK_MIN_TOKENS = env_int('OMP355_MLP_ROWS_MIN', 32768, 1, 1 << 30)
 
 
 class _Block(object):
     __slots__ = ('n1g', 'n1b', 'qkv_w', 'qkv_b', 'table', 'proj_w', 'proj_b', 'n2g', 'n2b', 'fc1_w',
-                 'fc1_b', 'fc2_w', 'fc2_b', 'shift', 'mlp_pack', 'bias_exp', 'attn_fused', 'attn_pack', 'mlp_rows')
+                 'fc1_b', 'fc2_w', 'fc2_b', 'shift', 'mlp_pack', 'bias_exp', 'attn_fused', 'attn_pack', 'rows')
 
 
 class _Stage(object):
-    __slots__ = ('C', 'nH', 'blocks', 'down_g', 'down_b', 'down_w', 'out_g', 'out_b')
+    __slots__ = ('C', 'nH', 'blocks', 'down_g', 'down_b', 'down_w', 'out_g', 'out_b', 'rows_qkv0')
 
 
 class Encoder(object):
@@ -100,8 +100,7 @@ class Encoder(object):
                 fuse = (dtype == torch.bfloat16 and st.C in FUSED_MLP_WIDTHS and blk.fc1_w.shape[0] % 32 == 0
                         and getattr(args, 'fused_mlp', True))
                 blk.mlp_pack = pack_mlp(blk.fc1_w, blk.fc1_b, blk.fc2_w) if fuse else None
-                blk.mlp_rows = (pack_rows_mlp(blk.fc1_w, blk.fc2_w) if (dtype == torch.bfloat16 and not self.x3 and st.C == 512 and blk.fc1_w.shape == (2048, 512)
-                                                                     and getattr(args, 'fused_mlp', True)) else None)
+                blk.rows = None
                 # norm1 + qkv + (S)W-MSA + proj + residual in one launch where the kernel is built (C = 128 with 4 heads: Swin-B stage 0)
                 blk.attn_fused = (dtype == torch.bfloat16 and not self.x3 and st.C == 128 and nh == 4 and self.window == 7
                                   and getattr(args, 'fused_attn', True))
@@ -116,6 +115,14 @@ class Encoder(object):
             else:
                 st.down_g = st.down_b = st.down_w = None
             st.out_g, st.out_b = f32('%snorm%d.weight' % (bb, s)), f32('%snorm%d.bias' % (bb, s))
+            # row-owner chains of a C = 512 stage: packed weight streams per block (its proj + MLP + the next block's qkv) and the first block's qkv
+            st.rows_qkv0 = None
+            if (dtype == torch.bfloat16 and not self.x3 and st.C == 512 and all(b_.fc1_w.shape == (2048, 512) for b_ in st.blocks)
+                    and getattr(args, 'fused_mlp', True) and getattr(args, 'fused_attn', True)):
+                st.rows_qkv0 = pack_rows_embed_qkv(st.blocks[0].qkv_w)
+                for i, b_ in enumerate(st.blocks):
+                    nxt = st.blocks[i + 1] if i + 1 < len(st.blocks) else None
+                    b_.rows = (pack_rows_ffn_qkv(b_.proj_w, b_.fc1_w, b_.fc2_w, nxt.qkv_w) if nxt is not None else pack_rows_ffn(b_.proj_w, b_.fc1_w, b_.fc2_w))
             self.stages.append(st)
         self.use_fpn = bool(args.use_fpn)
         if self.use_fpn:
@@ -187,7 +194,21 @@ class Encoder(object):
         for si, st in enumerate(self.stages):
             C = st.C
             y = None   # LayerNorm operand buffer of the unfused halves (a block whose attention half is fused never made one)
-            for blk in st.blocks:
+            if st.rows_qkv0 is not None and x.shape[0] >= ROWS_BLOCK_MIN_TOKENS:
+                # two launches per block: window attention on q | k | v, then everything else of the block (and the next block's qkv) as a chain
+                blks = st.blocks
+                qkv = ops.swin_rows_qkv(x, (blks[0].n1g, blks[0].n1b), blks[0].qkv_b, st.rows_qkv0[0], st.rows_qkv0[1], eps=LN_EPS)
+                att = torch.empty((x.shape[0], C), dtype=T, device=x.device)
+                for i, blk in enumerate(blks):
+                    ops.swin_window_attn(qkv, blk.qkv_b, blk.table, B, H, W, C, st.nH, blk.shift, out=att, window=self.window, bias_expanded=blk.bias_exp)
+                    nxt = blks[i + 1] if i + 1 < len(blks) else None
+                    ops.swin_rows_block(x, att, blk.rows[0], blk.rows[1], blk.proj_b, (blk.n2g, blk.n2b), blk.fc1_b, blk.fc2_b,
+                                        next_n1=(nxt.n1g, nxt.n1b) if nxt is not None else None, next_qkv_b=nxt.qkv_b if nxt is not None else None,
+                                        qkv=qkv, eps=LN_EPS)
+                blks = ()
+            else:
+                blks = st.blocks
+            for blk in blks:
                 if blk.attn_fused:
                     ops.swin_attn_block(x, blk.n1g, blk.n1b, blk.qkv_w, blk.qkv_b, blk.bias_exp, blk.proj_w, blk.proj_b, B, H, W, C, st.nH,
                                         blk.shift, window=self.window, eps=LN_EPS)
@@ -204,8 +225,6 @@ class Encoder(object):
                     self._gemm(att, blk.proj_w, blk.proj_b, residual=x, out=x)
                 if blk.mlp_pack is not None:   # norm2 + fc1 + GELU + fc2 + residual in one launch, in place
                     ops.swin_mlp_fused(x, blk.n2g, blk.n2b, blk.mlp_pack, blk.fc2_b, out=x, eps=LN_EPS)
-                elif blk.mlp_rows is not None and x.shape[0] >= ROWS_MLP_MIN_TOKENS:   # the same sub-layer as a row-owner chain (C = 512)
-                    ops.swin_mlp_rows(x, blk.n2g, blk.n2b, blk.mlp_rows[0], blk.mlp_rows[1], blk.fc1_b, blk.fc2_b, eps=LN_EPS)
                 else:
                     if y is None:
                         y = self._rows(x.shape[0], C, T, x.device)

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..utils.env import env_flag, env_int
 from ..utils.nested_tensor import NestedTensor
 from . import params
 from .backbone import Encoder
@@ -57,7 +58,7 @@ class OmniParser(nn.Module):
         self.use_graph = True          # decoder steps replay as hipGraphs when run on a non-default stream
         self.overlap_decoders = True   # polygon || recognition decoders on two streams
         # images per encoder pass inside one engine call (see _encode_chunked); OMP355_ENC_CHUNK is the A/B knob of the sweep
-        self.enc_chunk = int(os.environ.get('OMP355_ENC_CHUNK', '32'))
+        self.enc_chunk = env_int('OMP355_ENC_CHUNK', 32, 1, 4096)
         self._streams = None
         self.phase_events = None       # set to [] to collect (name, torch.cuda.Event) marks per infer()
         self.eval()
@@ -65,7 +66,8 @@ class OmniParser(nn.Module):
     # -- engine lifecycle -------------------------------------------------------------------------
     def _key(self):
         ps = list(self.parameters())
-        return (ps[0].device, self.engine_dtype, sum(p._version for p in ps), id(ps[0]))
+        # OMP355_KV_SPLIT changes the layout of the K / V^T slabs the decoder is built around: part of the key
+        return (ps[0].device, self.engine_dtype, sum(p._version for p in ps), id(ps[0]), env_flag('OMP355_KV_SPLIT', True))
 
     def engine(self):
         """(Encoder, Decoder) packed from the CURRENT parameters; rebuilt after load_state_dict/.to()."""

@@ -186,14 +186,6 @@ def pack_rows_embed_qkv(sa_in_w):
     return _rows_finish(_rows_product(sa_in_w))
 
 
-def pack_rows_mlp(fc1_w, fc2_w, chunk=256):
-    """omp_swin_mlp_rows: fc1 [2048, 512] / fc2 [512, 2048] of a Swin stage-2 block, per chunk of 256 hidden units fc1's pass then fc2's."""
-    _bf16(fc1_w, fc2_w)
-    Hd, C = fc1_w.shape
-    if fc2_w.shape != (C, Hd) or Hd != 4 * C or C != 512:
-        raise ValueError('pack_rows_mlp: the row-owner MLP chain is built for C = 512, hidden 2048 (got %s / %s)' % (tuple(fc1_w.shape), tuple(fc2_w.shape)))
-    pieces = []
-    for c in range(Hd // chunk):
-        pieces.append(_rows_pass(fc1_w[c * chunk:(c + 1) * chunk], chunk // (16 * ROWS_WAVES)))
-        pieces += _rows_product(fc2_w[:, c * chunk:(c + 1) * chunk].contiguous())
-    return _rows_finish(pieces)
+def pack_rows_ffn(out_w, ff1_w, ff2_w):
+    """an attention out-projection and the FFN behind it with nothing after it (omp_swin_rows_block mode 1 for the last block of a stage)."""
+    return _rows_finish(_rows_ffn_pieces(out_w, ff1_w, ff2_w))

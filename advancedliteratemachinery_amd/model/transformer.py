@@ -20,6 +20,7 @@ import torch
 
 from .. import _lib, ops
 from . import packing
+from ..utils.env import env_flag, env_int
 
 KINDS = ('pt', 'poly', 'rec')
 KIND_ID = {'pt': _lib.DEC_PT, 'poly': _lib.DEC_POLY, 'rec': _lib.DEC_REC}
@@ -135,7 +136,7 @@ class Decoder(object):
         self.x3 = bool(x3)   # bf16x3 engine: the K / V^T projection of the memory runs as split-bf16 products (decoder steps stay fp32)
         # ... and (round 4) writes SPLIT-PLANE slabs: 32-key blocks of [hi plane | lo plane] bf16 -- the bytes of the fp32 slabs, streamed
         # by cross-attention kernels that run three bf16 matrix-core products per block instead of fp32 ones (csrc/decoder.hip, bf16s_t)
-        self.kv_split = self.x3 and os.environ.get('OMP355_KV_SPLIT', '1') != '0'
+        self.kv_split = self.x3 and env_flag('OMP355_KV_SPLIT', True)
         self.d, self.nH, self.L = args.tfm_hidden_dim, args.tfm_nheads, args.tfm_dec_layers
         self.ff, self.V = args.tfm_dim_feedforward, args.num_classes
         if self.d != self.nH * 64:
@@ -143,7 +144,7 @@ class Decoder(object):
         if self.L > _lib.MAX_DEC_LAYERS:
             raise ValueError('too many decoder layers')
         self.use_graph = False
-        self.n_split_override = int(os.environ.get('OMP355_CROSS_SPLIT', '0'))
+        self.n_split_override = env_int('OMP355_CROSS_SPLIT', 0, 0, 16, allowed=(0, 1, 2, 4, 8, 16))
         self._phases = OrderedDict()
         self._kv = OrderedDict()
         d = self.d
@@ -199,7 +200,7 @@ class Decoder(object):
     X3_MIN_ROWS = 65    # phases with more rows run their products as split-bf16 products (csrc/decoder.hip: step_launch_x3)
     # bf16 engine: phases with at least this many rows run their Linear layers as row-owner chains (csrc/dec_rows.hip: 80 rows per
     # workgroup, weights streamed from L2): from ~50 workgroups on they beat the launch-per-Linear path (profiles/r05*_kbench_dec_rows*)
-    ROWS_MIN_ROWS = int(os.environ.get('OMP355_ROWS_MIN', '4096'))
+    ROWS_MIN_ROWS = env_int('OMP355_ROWS_MIN', 4096, 1, 1 << 30)
 
     def _rows_streams(self, kind):
         """Packed weight streams of decoder `kind` for the row-owner chains, built on first use (model/packing.py::pack_rows_*):

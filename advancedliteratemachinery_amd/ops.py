@@ -519,12 +519,34 @@ def dec_rows_ffn(x, wstream, wave_stride, d_pos, lnt_g, lnt_b, att=None, out_b=N
     return out
 
 
-def swin_mlp_rows(x, ln_g, ln_b, wstream, wave_stride, b1, b2, eps=1e-5):
-    """x [M, 512] fp32 residual stream, in place: x += fc2(GELU(fc1(LN(x)))) as a row-owner chain (Swin-B stage 2; wstream from
-    model.packing.pack_rows_mlp)."""
-    if x.dtype != torch.float32 or x.shape[-1] != 512:
-        raise TypeError('swin_mlp_rows takes the fp32 residual stream [M, 512]')
+def swin_rows_qkv(x, n1, qkv_b, wstream, wave_stride, qkv=None, eps=1e-5):
+    """qkv = bf16(LayerNorm(x; n1) Wqkv^T + bqkv) for x [M, 512] fp32 (Swin-B stage 2, the stage's first block): omp_swin_rows_block mode 0."""
     M = x.numel() // 512
-    rc = _lib.lib().omp_swin_mlp_rows(ptr(_c(x, 'x')), M, ptr(ln_g), ptr(ln_b), float(eps), ptr(wstream), int(wave_stride), ptr(b1), ptr(b2), stream())
-    _lib.check(rc, 'omp_swin_mlp_rows')
-    return x
+    if qkv is None:
+        qkv = torch.empty((M, 1536), dtype=torch.bfloat16, device=x.device)
+    a = _lib.SwinRowsArgs()
+    a.M, a.eps, a.mode, a.x, a.qkv = M, float(eps), 0, ptr(_c(x, 'x')), ptr(qkv)
+    a.wstream, a.wave_stride = ptr(wstream), int(wave_stride)
+    a.n1_g, a.n1_b, a.qkv_b = ptr(n1[0]), ptr(n1[1]), ptr(qkv_b)
+    _lib.check(_lib.lib().omp_swin_rows_block(ctypes.byref(a), stream()), 'omp_swin_rows_block')
+    return qkv
+
+
+def swin_rows_block(x, att, wstream, wave_stride, proj_b, n2, fc1_b, fc2_b, next_n1=None, next_qkv_b=None, qkv=None, eps=1e-5):
+    """x += att Wproj^T + bproj; x += fc2(GELU(fc1(LN(x; n2)))) in place on the fp32 residual stream [M, 512]; with next_n1 / next_qkv_b also
+    the next block's qkv = bf16(LN(x; next_n1) Wqkv'^T + b') -> returned (else None).  omp_swin_rows_block mode 1."""
+    if x.dtype != torch.float32 or x.shape[-1] != 512:
+        raise TypeError('swin_rows_block takes the fp32 residual stream [M, 512]')
+    M = x.numel() // 512
+    a = _lib.SwinRowsArgs()
+    a.M, a.eps, a.mode, a.x, a.att = M, float(eps), 1, ptr(_c(x, 'x')), ptr(_c(att, 'att'))
+    a.wstream, a.wave_stride = ptr(wstream), int(wave_stride)
+    a.proj_b, a.n2_g, a.n2_b, a.fc1_b, a.fc2_b = ptr(proj_b), ptr(n2[0]), ptr(n2[1]), ptr(fc1_b), ptr(fc2_b)
+    if next_n1 is not None:
+        if qkv is None:
+            qkv = torch.empty((M, 1536), dtype=torch.bfloat16, device=x.device)
+        a.n1_g, a.n1_b, a.qkv_b, a.qkv = ptr(next_n1[0]), ptr(next_n1[1]), ptr(next_qkv_b), ptr(qkv)
+    else:
+        qkv = None
+    _lib.check(_lib.lib().omp_swin_rows_block(ctypes.byref(a), stream()), 'omp_swin_rows_block')
+    return qkv

@@ -1,0 +1,33 @@
+"""The OMP355_* environment knobs (A/B switches of the sweeps under tools/ and profiles/): read through these helpers so that a typo is an
+error message, not a silently different engine.  Knobs that change an engine's LAYOUT (OMP355_KV_SPLIT) are part of the engine key
+(model/omniparser.py::_key); the others change scheduling only.
+
+  OMP355_ENC_CHUNK     images per encoder pass inside one engine call (1..4096, default 32)
+  OMP355_KV_SPLIT      bf16x3 engine: split-plane K / V^T slabs (1, default) or fp32 slabs (0)
+  OMP355_CROSS_SPLIT   override of the cross-attention key split (0 = automatic; a power of two <= 16)
+  OMP355_ROWS_MIN      rows from which a decoder phase of the bf16 engine runs its Linear layers as row-owner chains (default 4096)
+  OMP355_MLP_ROWS_MIN  tokens from which the blocks of Swin-B's stage 2 run as row-owner chains (default 32768)
+  OMP355_DEC_PRIORITY  pipeline lanes: decoder streams at high priority (0 / 1, default 0)"""
+import os
+
+
+def env_int(name, default, lo, hi, allowed=None):
+    raw = os.environ.get(name)
+    if raw is None or raw == '':
+        return default
+    try:
+        v = int(raw)
+    except ValueError:
+        raise ValueError('%s=%r is not an integer' % (name, raw))
+    if v < lo or v > hi or (allowed is not None and v not in allowed):
+        raise ValueError('%s=%d is outside %s' % (name, v, sorted(allowed) if allowed is not None else '[%d, %d]' % (lo, hi)))
+    return v
+
+
+def env_flag(name, default):
+    raw = os.environ.get(name)
+    if raw is None or raw == '':
+        return bool(default)
+    if raw not in ('0', '1'):
+        raise ValueError('%s=%r must be 0 or 1' % (name, raw))
+    return raw == '1'

@@ -170,6 +170,17 @@ def pmc_gemm_traffic(size, dtype):
         return None
 
 
+def pmc_rows_traffic():
+    """Measured HBM bytes per launch of the row-owner chain kernels from the rocprofv3 PMC passes over the polygon / recognition phase of a
+    160-image engine call (tools/dec_rows_pmc.py -> profiles/pmc_dec_rows.json): (bytes per launch, measured / algorithmic, scope)."""
+    try:
+        with open(os.environ.get('OMP355_PMC_ROWS_JSON', os.path.join(ROOT, 'profiles', 'pmc_dec_rows.json'))) as f:
+            s_ = json.load(f)['summary']
+        return float(s_['measured_bytes_per_launch']), float(s_['measured_over_alg']), s_.get('scope', '')
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-run this script under torch.distributed.run, one rank per GPU."""
     import socket
@@ -217,35 +228,23 @@ def host_cores():
 
 
 def cpu_baseline(args, sd, size, instances, pt_steps, budget_s=32.0):
-    """Reference algorithm (oracle restatement: no KV cache, full prefix re-decoded every step, memory
-    broadcast per instance) on the host cores.  Two parts:
-      * `measured_small`: ONE complete run of the path, measured end to end at a reduced size (512x512 image, 2 instances);
-      * `value`: an ESTIMATE of the full workload (1024x1024, 64 instances would take ~15 minutes per image) composed from a
-        bounded sample: backbone+FPN+projection of one image at (size/2)^2 (x4: Swin cost is linear in pixels), then single
-        decoder calls against a full-size (size/16)^2 memory: point decoder at a short and a mid prefix, polygon /
-        recognition at N=2 instances (reference decode cost is linear in instances and ~affine in prefix length).
-    Every leg of the estimate is skipped (and the number marked partial) once `budget_s` is spent."""
+    """Reference algorithm (oracle restatement: no KV cache, full prefix re-decoded every step, memory broadcast per instance) on the
+    host cores -- `kind: port`: the oracle is pinned to the reference's own classes (tests/test_oracle_vs_reference.py) but it is
+    the oracle, not /root/reference, that is timed: the reference does not exist on the GPU box.
+      * `value`: ONE complete run of the path at the benchmark's image size with 8 instances per image (pt_seq_length 16: 8 points,
+        8 x 32 polygon and 8 x rec_length recognition steps, every step the full reference recomputation), extrapolated x8 to the
+        benchmark's 64 instances: t = t_encode + (t_total - t_encode) x (instances / 8)   (the reference's decode cost
+        is linear in the instance count -- memory is replicated per instance -- and its point sequence grows with it);
+      * `measured_c1`: BASELINE config 1 run COMPLETE (one 640x640 image, Swin-T widths, 16 instances).
+    Hosts with fewer than 8 usable cores run the 8-instance leg at half the image size (and say so)."""
     import copy
     from oracle import omniparser_ref as O
     cores = host_cores()
     torch.set_num_threads(min(cores, 64))
     sd = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
-    # -- measured: the whole reference path once, 512x512, pt_seq_length 4 -> 2 instances x (32 polygon + rec_length steps)
-    small = copy.copy(args)
-    small.pt_seq_length = 4
-    gs = torch.Generator().manual_seed(4321)
-    with torch.no_grad():
-        img_s = torch.randn(1, 3, 512, 512, generator=gs)
-        t0 = time.time()
-        out_s = O.forward(sd, small, img_s, torch.zeros(1, 512, 512, dtype=torch.bool), O.default_prompts(small))
-        t_small = time.time() - t0
-    n_small = 0 if out_s is None else int(out_s[0][0].numel()) // 2
-    measured_small = dict(value=1.0 / t_small, unit='images/s', seconds=t_small, image_size=512, instances=n_small,
-                          chars_per_sec=n_small * args.rec_length / t_small,
-                          sample='oracle.forward end to end: 512x512 image, pt_seq_length 4 (%d instances), %d threads' % (n_small, min(cores, 64)))
-    print('[cpu_baseline] measured end to end: 512x512, %d instances: %.2fs' % (n_small, t_small), file=sys.stderr, flush=True)
-    # -- measured: BASELINE config 1 COMPLETE (Swin-T widths, one 640x640 image, pt_seq_length 32 -> 16 instances with their 32-token
-    #    polygons and 25-token transcriptions; the case of tools/cpu_full_c1.py): ~10 s on 16 threads, skipped on small hosts
+    log = lambda m: print('[cpu_baseline] ' + m, file=sys.stderr, flush=True)  # noqa: E731
+    # -- BASELINE config 1 COMPLETE (Swin-T widths, one 640x640 image, pt_seq_length 32 -> 16 instances with their 32-token polygons and
+    #    25-token transcriptions; the case of tools/cpu_full_c1.py): ~10 s on 16 threads, skipped on small hosts
     measured_c1 = None
     if cores >= 8:
         from oracle import gen_golden as G_
@@ -260,65 +259,40 @@ def cpu_baseline(args, sd, size, instances, pt_steps, budget_s=32.0):
         measured_c1 = dict(value=1.0 / t_c1, unit='images/s', seconds=t_c1, image_size=640, instances=n1, chars_per_sec=n1 * a1.rec_length / t_c1,
                            sample='BASELINE config 1 run COMPLETE, not extrapolated: oracle.forward on one 640x640 image, Swin-T widths (embed 96, depths 2-2-6-2, '
                                   'no FPN), pt_seq_length 32 (%d instances), %d threads' % (n1, min(cores, 64)))
-        print('[cpu_baseline] config 1 complete: 640x640, %d instances: %.2fs' % (n1, t_c1), file=sys.stderr, flush=True)
+        log('config 1 complete: 640x640, %d instances: %.2fs' % (n1, t_c1))
         del sd1, img1
-    t_start = time.time()
-    left = lambda: budget_s - (time.time() - t_start)   # noqa: E731
-    log = lambda m: print('[cpu_baseline] ' + m, file=sys.stderr, flush=True)  # noqa: E731
+    # -- the benchmark's own configuration, 8 instances, complete
+    n_s = 8
+    side = size if cores >= 8 else max(64, size // 2)
+    small = copy.copy(args)
+    small.pt_seq_length = 2 * n_s
     g = torch.Generator().manual_seed(1234)
-    half = max(64, size // 2)
-    d = args.tfm_hidden_dim
-    M = (size // 16) ** 2
-    notes = []
     with torch.no_grad():
-        img = torch.randn(1, 3, half, half, generator=g)
+        img = torch.randn(1, 3, side, side, generator=g)
+        msk = torch.zeros(1, side, side, dtype=torch.bool)
         t0 = time.time()
-        O.encode(sd, args, img, torch.zeros(1, half, half, dtype=torch.bool))
-        t_enc = (time.time() - t0) * (size / float(half)) ** 2
-        log('encode %dx%d: %.2fs -> %.2fs at %dx%d (cores=%d)' % (half, half, time.time() - t0, t_enc, size, size, cores))
-        mem = torch.randn(M, 1, d, generator=g)
-        pos = torch.randn(M, 1, d, generator=g)
-        m = torch.zeros(1, M, dtype=torch.bool)
-
-        def step_time(kind, n, L):
-            if left() <= 0:
-                return None
-            seq = torch.randint(0, args.num_bins, (n, L), generator=g)
-            ts = []
-            for _ in range(3):   # median of 3 while the budget lasts
-                t = time.time()
-                O.decode(sd, args, seq, mem, m, pos, kind)
-                ts.append(time.time() - t)
-                if left() <= 0:
-                    break
-            dt_ = sorted(ts)[len(ts) // 2]
-            log('%s decode call n=%d L=%d: %.3fs' % (kind, n, L, dt_))
-            return dt_
-
-        n_s = 2
-        t_pt_a = step_time('pt', 1, 7)
-        t_poly = step_time('poly', n_s, 3 + 16)
-        t_rec = step_time('rec', n_s, 3 + 12)
-        t_pt_b = step_time('pt', 1, 7 + pt_steps // 2)
-    if t_pt_a is None:
-        raise RuntimeError('cpu_baseline: budget too small for a single decoder call')
-    if t_pt_b is None:
-        t_pt_b = t_pt_a
-        notes.append('mid-prefix point step not measured (budget)')
-    if t_poly is None or t_rec is None:
-        t_poly = t_rec = t_pt_a * n_s
-        notes.append('polygon/recognition steps estimated from the point step (budget)')
-    t_pt = pt_steps * 0.5 * (t_pt_a + t_pt_b)
-    t_total = t_enc + t_pt + (32 * t_poly + args.rec_length * t_rec) * (instances / n_s)
-    return dict(value=1.0 / t_total, unit='images/s', cores=cores, kind='port', estimated=True, measured_small=measured_small, measured_c1=measured_c1,
-                sample=('ESTIMATE from a bounded sample (the measured end-to-end run is `measured_small`) -- oracle (CPU restatement of the reference path, fp32, %d threads): encode of one %dx%d image '
-                        'measured and scaled x%.0f to %dx%d = %.2fs; point-decoder call %.3fs (L=7) / %.3fs (L=%d) '
-                        'measured against a %d-token memory, x%d steps; polygon / recognition call %.3fs / %.3fs '
-                        'measured at N=%d instances, scaled linearly to N=%d (x32 / x%d steps); estimated '
-                        'full-workload time %.1fs per image%s'
-                        % (min(cores, 64), half, half, (size / float(half)) ** 2, size, size, t_enc, t_pt_a, t_pt_b,
-                           7 + pt_steps // 2, M, pt_steps, t_poly, t_rec, n_s, instances, args.rec_length, t_total,
-                           ('; ' + '; '.join(notes)) if notes else '')),
+        O.encode(sd, args, img, msk)
+        t_enc = time.time() - t0
+        log('encode %dx%d: %.2fs (cores=%d)' % (side, side, t_enc, cores))
+        t0 = time.time()
+        out_s = O.forward(sd, small, img, msk, O.default_prompts(small))
+        t_all = time.time() - t0
+    n_got = 0 if out_s is None else int(out_s[0][0].numel()) // 2
+    log('complete run %dx%d, %d instances: %.2fs' % (side, side, n_got, t_all))
+    if n_got <= 0:
+        raise RuntimeError('cpu_baseline: the oracle decoded no instance')
+    px = (size / float(side)) ** 2            # 1.0 unless the host is small
+    t_dec = max(t_all - t_enc, 0.0)
+    t_total = t_enc * px + t_dec * (instances / float(n_got)) * px   # the decoders' memory has (side/16)^2 tokens: linear in pixels too
+    measured = dict(value=1.0 / t_all, unit='images/s', seconds=t_all, encode_seconds=t_enc, image_size=side, instances=n_got,
+                    chars_per_sec=n_got * args.rec_length / t_all)
+    return dict(value=1.0 / t_total, unit='images/s', cores=cores, kind='port', estimated=True, measured_n8=measured, measured_c1=measured_c1,
+                sample=('oracle (CPU restatement of the reference path, pinned to the reference classes; fp32, %d threads): ONE COMPLETE run of the path on a '
+                        '%dx%d image with %d instances (pt_seq_length %d: %d point tokens, %d x 32 polygon and %d x %d recognition steps) measured '
+                        '%.1fs (encode %.2fs of it); `value` extrapolates the decode part x%.1f to the benchmark\'s %d instances%s: %.1fs per image'
+                        % (min(cores, 64), side, side, n_got, small.pt_seq_length, 2 * n_got, n_got, n_got, args.rec_length, t_all, t_enc,
+                           instances / float(n_got), instances, (' and everything x%.0f to %dx%d pixels (fewer than 8 host cores)' % (px, size, size)) if px != 1.0 else '',
+                           t_total)),
                 chars_per_sec=instances * args.rec_length / t_total)
 
 
@@ -471,6 +445,113 @@ def run_kie(a, device, world, rank):
                 roofline=roof)
 
 
+class StepLoop(object):
+    """The part of the bench line that must be right on N GPUs, as an object (tests/test_bench_loop.py drives it over world-2 gloo with a stub
+    engine): K steps in groups of `group` consecutive steps per engine call, ONE all-gather of the packed payload per engine call issued in
+    step order from the calling thread, a barrier + synchronize pair on both sides of EXACTLY K steps, the MAX over ranks of the elapsed
+    time, the stop decision of the repetition loop all-reduced so that every rank takes the same one, every rank's own ms per step gathered.
+    run_group(first_step, n_steps, lane, forced) -> (ids int32 [b, N, T], probs fp32 [b, N, L]) is the engine call; on a CPU device
+    (the tests) the stream / event calls are skipped, the protocol is the same."""
+
+    def __init__(self, run_group, world, rank, device, group, pools=None):
+        self.run_group, self.world, self.rank, self.device, self.G = run_group, world, rank, device, group
+        self.cuda = device.type == 'cuda'
+        self.pools = pools if pools is not None else {'active': None}
+        self.gather_ev = []   # (start, end) events around every all-gather of the timed region (cuda)
+        self.local_s = []     # this rank's own time of every repetition (before the max over ranks)
+        self.n_gathers = 0
+
+    def sync(self):
+        if self.cuda:
+            torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def exchange(self, ids, probs):
+        if self.world == 1:
+            return ids, probs
+        e0 = e1 = None
+        if self.cuda:
+            # results were produced on a lane stream and are consumed by RCCL on this one: tell the caching allocator
+            ids.record_stream(torch.cuda.current_stream())
+            probs.record_stream(torch.cuda.current_stream())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        # ONE collective per engine call: ids and probability bit patterns in one int32 payload (utils/dist.py::pack_payload)
+        payload = pack_payload(ids, probs)
+        buf = torch.empty(self.world * payload.shape[0], payload.shape[1], dtype=torch.int32, device=self.device)
+        dist.all_gather_into_tensor(buf, payload)
+        all_ids, all_pr, _ = unpack_payload(buf, ids.shape[1:], probs.shape[1:], with_n=False)
+        self.n_gathers += 1
+        if self.cuda:
+            e1.record()
+            self.gather_ev.append((e0, e1))
+        return all_ids, all_pr
+
+    def run_steps(self, k, group=None, forced=None):
+        """k steps = k batches through the whole hot path, in groups of `group` consecutive steps per engine call.
+        With lanes > 1 consecutive groups are in flight on different HIP streams (lane threads enqueue them); the
+        all-gather of the decoded sequences (one per group) is issued from THIS thread in step order, after the
+        lane's completion event, so every rank calls the collectives in the same order."""
+        group = group or self.G
+        sizes = [group] * (k // group) + ([k % group] if k % group else [])
+        firsts = [sum(sizes[:i]) for i in range(len(sizes))]
+        out = None
+        pl = self.pools['active']
+        if pl is None:
+            for f0, g_ in zip(firsts, sizes):
+                ids, probs = self.run_group(f0, g_, None, forced)
+                out = self.exchange(ids, probs)
+            return out
+        futs = [pl.submit(lambda lane, f0=f0, g_=g_: self.run_group(f0, g_, lane, forced)) for f0, g_ in zip(firsts, sizes)]
+        for f in futs:
+            (ids, probs), ev = f.result()
+            torch.cuda.current_stream().wait_event(ev)
+            out = self.exchange(ids, probs)
+        return out
+
+    def timed(self, k, group=None, forced=None):
+        """EXACTLY k steps between barrier + synchronize pairs; MAX over ranks."""
+        self.sync()
+        self.barrier()
+        t0 = time.perf_counter()
+        out = self.run_steps(k, group, forced)
+        self.sync()
+        self.barrier()
+        el = time.perf_counter() - t0
+        self.local_s.append(el)
+        if self.world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    def repeat(self, k, min_seconds, max_reps=64, group=None, forced=None):
+        """timed(k) until min_seconds are measured (or max_reps): every rank takes the SAME stop decision (all-reduced).  -> (reps, last out)"""
+        reps, out = [], None
+        while True:
+            el, out = self.timed(k, group, forced)
+            reps.append(el)
+            stop = sum(reps) >= min_seconds or len(reps) >= max_reps
+            if self.world > 1:
+                t = torch.tensor([1.0 if stop else 0.0], device=self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                stop = bool(t.item() > 0)
+            if stop:
+                return reps, out
+
+    def per_rank_ms(self, steps):
+        """every rank's own median ms per step (before the max over ranks), gathered on all ranks"""
+        if self.world == 1:
+            return None
+        mine = torch.tensor([pct(self.local_s, 0.5) / steps * 1e3], dtype=torch.float64, device=self.device)
+        allr = torch.empty(self.world, dtype=torch.float64, device=self.device)
+        dist.all_gather_into_tensor(allr, mine)
+        return [float(v) for v in allr.tolist()]
+
+
 def main():
     a = parse()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -540,7 +621,7 @@ def main():
     mask1 = torch.zeros(B, a.size, a.size, dtype=torch.bool, device=device)
     calls = []   # (start event, end event, images) of every engine call, recorded on its lane stream
 
-    def run_group(first_step, g_, lane=None, forced=N, model=model):
+    def run_group(first_step, g_, lane=None, forced=N, model=model):   # StepLoop's engine call
         """steps first_step .. first_step+g_-1 as ONE engine call: their batches arrive as separate tensors and are
         concatenated here, inside the timed region, as a serving engine would have to."""
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -560,69 +641,13 @@ def main():
         calls.append((ev0, ev1, B * g_))
         return out
 
-    gather_ev = []   # (start, end) events around every all-gather pair of the timed region
     inst_log = []
+    loop = StepLoop(lambda f0, g_, lane, forced: run_group(f0, g_, lane, N if forced == 'N' else forced), world, rank, device, G, pools)
+    # (forced: 'N' = the benchmark's forced instance count, None = EOS honoured)
+    run_steps = lambda k, group=None, forced='N': loop.run_steps(k, group, forced)     # noqa: E731
+    timed = lambda k, group=None, forced='N': loop.timed(k, group, forced)             # noqa: E731
+    gather_ev, local_s = loop.gather_ev, loop.local_s
 
-    def exchange(ids, probs, g_):
-        if world == 1:
-            return ids, probs
-        # results were produced on a lane stream and are consumed by RCCL on this one: tell the caching allocator
-        ids.record_stream(torch.cuda.current_stream())
-        probs.record_stream(torch.cuda.current_stream())
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        # ONE collective per engine call: ids and probability bit patterns in one int32 payload (utils/dist.py::pack_payload)
-        payload = pack_payload(ids, probs)
-        buf = torch.empty(world * payload.shape[0], payload.shape[1], dtype=torch.int32, device=device)
-        dist.all_gather_into_tensor(buf, payload)
-        all_ids, all_pr, _ = unpack_payload(buf, ids.shape[1:], probs.shape[1:], with_n=False)
-        e1.record()
-        gather_ev.append((e0, e1))
-        return all_ids, all_pr
-
-    def run_steps(k, group=None, forced=N):
-        """k steps = k batches through the whole hot path, in groups of `group` consecutive steps per engine call.
-        With lanes > 1 consecutive groups are in flight on different HIP streams (lane threads enqueue them); the
-        all-gather of the decoded sequences (one per group) is issued from THIS thread in step order, after the
-        lane's completion event, so every rank calls the collectives in the same order."""
-        group = group or G
-        sizes = [group] * (k // group) + ([k % group] if k % group else [])
-        firsts = [sum(sizes[:i]) for i in range(len(sizes))]
-        out = None
-        pl = pools['active']
-        if pl is None:
-            for f0, g_ in zip(firsts, sizes):
-                ids, probs = run_group(f0, g_, forced=forced)
-                out = exchange(ids, probs, g_)
-            return out
-        futs = [pl.submit(lambda lane, f0=f0, g_=g_: run_group(f0, g_, lane, forced)) for f0, g_ in zip(firsts, sizes)]
-        for f, g_ in zip(futs, sizes):
-            (ids, probs), ev = f.result()
-            torch.cuda.current_stream().wait_event(ev)
-            out = exchange(ids, probs, g_)
-        return out
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    def timed(k, group=None, forced=N):
-        """EXACTLY k steps between barrier + synchronize pairs; MAX over ranks."""
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        out = run_steps(k, group, forced)
-        torch.cuda.synchronize()
-        barrier()
-        el = time.perf_counter() - t0
-        local_s.append(el)
-        if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el, out
-
-    local_s = []   # this rank's own time of every repetition (before the max over ranks)
     with torch.cuda.stream(stream):
         # untimed set-up: every lane (or the model itself) allocates its buffers and captures its graphs for
         # both group sizes the timed region will use (full groups and the remainder group)
@@ -634,30 +659,13 @@ def main():
         del calls[:]
         del gather_ev[:]
         del local_s[:]
-        reps = []
-        budget_reps = 64
-        while True:
-            el, out = timed(a.steps)
-            reps.append(el)
-            spent = sum(reps)
-            stop = spent >= a.min_seconds or len(reps) >= budget_reps
-            if world > 1:   # every rank must take the same decision
-                t = torch.tensor([1.0 if stop else 0.0], device=device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                stop = bool(t.item() > 0)
-            if stop:
-                break
+        reps, out = loop.repeat(a.steps, a.min_seconds, 64, forced='N')
         torch.cuda.synchronize()
         call_ms = [e0.elapsed_time(e1) for e0, e1, _ in calls]
         call_imgs = calls[0][2] if calls else B * G
     elapsed = pct(reps, 0.5)
-    per_rank_ms = gather_ms = None
-    if world > 1:
-        mine = torch.tensor([pct(local_s, 0.5) / a.steps * 1e3], dtype=torch.float64, device=device)
-        allr = torch.empty(world, dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(allr, mine)
-        per_rank_ms = [float(v) for v in allr.tolist()]
-        gather_ms = [e0.elapsed_time(e1) for e0, e1 in gather_ev]
+    per_rank_ms = loop.per_rank_ms(a.steps)
+    gather_ms = [e0.elapsed_time(e1) for e0, e1 in gather_ev] if world > 1 else None
     total_images = world * B * a.steps
     ips = total_images / elapsed
     # sanity: the forced workload really produced N instances x rec_length chars per image
@@ -737,7 +745,7 @@ def main():
         with torch.cuda.stream(stream):
             run_group(0, G, model=mdl)
             torch.cuda.synchronize()
-            h.omp_prof_enable(15)
+            h.omp_prof_enable(31)
             for i in range(n_groups):
                 run_group(i * G, G, model=mdl)
             torch.cuda.synchronize()
@@ -754,7 +762,8 @@ def main():
         t_gemm, n_gemm, f_gemm = read(1)
         t_mlp, n_mlp, f_mlp = read(2)
         t_gd, n_gd, f_gd = read(3)   # the same GEMM kernels on decoder-phase rows (M < 32768: the 10240-row polygon / recognition products)
-        (b_gemm, r_gemm), (b_mlp, r_mlp), (b_gd, r_gd) = read_roof(1), read_roof(2), read_roof(3)
+        t_rw, n_rw, f_rw = read(4)   # round 5: the decoders' many-row Linear layers as row-owner chains (csrc/dec_rows.hip)
+        (b_gemm, r_gemm), (b_mlp, r_mlp), (b_gd, r_gd), (b_rw, r_rw) = read_roof(1), read_roof(2), read_roof(3), read_roof(4)
         h.omp_prof_enable(0)
         mdl.use_graph = was
         M = (a.size // 16) ** 2
@@ -784,9 +793,18 @@ def main():
                                     achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None, launches=int(n_gd),
                                     avg_us=t_gd / n_gd * 1e3, flops_per_launch=f_gd / n_gd, alg_bytes_per_launch=b_gd / n_gd,
                                     frac_of_launch_rooflines=r_gd / (t_gd / 1e3), gpu_ms_per_image=t_gd / (n_groups * BI))))
+        if n_rw:
+            tf = f_rw / (t_rw / 1e3) / 1e12
+            rt_ = pmc_rows_traffic()
+            recs.append((t_rw, dict(bound='mfma', kernel='dec_rows_mid_kernel / dec_rows_ffn_kernel (row-owner chains: the Linear layers of the many-row polygon / recognition '
+                                                        'steps, two launches per decoder layer; on gemm_256 / gemm_dma launches until round 5)',
+                                    achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=rt_[0] if rt_ else None, launches=int(n_rw),
+                                    avg_us=t_rw / n_rw * 1e3, flops_per_launch=f_rw / n_rw, alg_bytes_per_launch=b_rw / n_rw,
+                                    frac_of_launch_rooflines=r_rw / (t_rw / 1e3), gpu_ms_per_image=t_rw / (n_groups * BI),
+                                    **(dict(traffic_over_algorithmic=rt_[1], traffic_scope=rt_[2]) if rt_ else {}))))
         if n_mlp:
             tf = f_mlp / (t_mlp / 1e3) / 1e12
-            recs.append((t_mlp, dict(bound='mfma', kernel='mlp_fused_kernel (Swin stages 0/1: LayerNorm + fc1 + GELU + fc2 + residual)',
+            recs.append((t_mlp, dict(bound='mfma', kernel='mlp_fused_kernel (Swin stages 0/1) + swin_rows_mlp_kernel (stage 2, round 5): LayerNorm + fc1 + GELU + fc2 + residual in one launch',
                                      achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None,
                                      launches=int(n_mlp), avg_us=t_mlp / n_mlp * 1e3, flops_per_launch=f_mlp / n_mlp,
                                      alg_bytes_per_launch=b_mlp / n_mlp, frac_of_launch_rooflines=r_mlp / (t_mlp / 1e3),
@@ -802,12 +820,30 @@ def main():
                                        unit='GB/s', frac=ach / HBM_PEAK_GBS, traffic=pmc_traffic(BI, 'x3_' if dtype_name == 'bf16x3' else ''), launches=int(n_cross),
                                        avg_us=avg_s * 1e6, alg_bytes_per_launch=alg, images_per_launch=BI,
                                        gpu_ms_per_image=t_cross / (n_groups * BI))))
-        recs.sort(key=lambda r: -r[0])
-        note = ('hipEvent-bracketed eager launches of %d engine calls of %d images on one stream (graph replay cannot be bracketed); '
-                'ordered by GPU time; traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch from the committed '
-                'PMC passes (profiles/pmc_cross_attn.json, profiles/pmc_gemm.json), null for classes / sizes without a pass' % (n_groups, BI))
-        if recs:
-            return dict(recs[0][1], note=note), [r for _, r in recs[1:]]
+        # FAMILIES: everything that runs on the matrix cores is one family -- the encoder-sized GEMMs, the same kernels on
+        # decoder-phase rows, the fused MLPs and the row-owner chains -- so that `roofline` names the family that bounds the engine, with its
+        # classes beneath it; the HBM-bound cross-attention kernels are the other family.
+        note = ('hipEvent-bracketed eager launches of %d engine calls of %d images on one stream (graph replay cannot be bracketed); families ordered '
+                'by GPU time, their classes beneath them; traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch from the committed '
+                'PMC passes (profiles/pmc_cross_attn.json, pmc_gemm.json, pmc_dec_rows.json), null for classes / sizes without a pass' % (n_groups, BI))
+        mm = sorted([r for r in recs if r[1]['bound'] == 'mfma'], key=lambda r: -r[0])
+        fams = []
+        if mm:
+            t_f = sum(t for t, _ in mm)
+            fl_f = sum(r['flops_per_launch'] * r['launches'] for _, r in mm)
+            roof_f = sum(r['frac_of_launch_rooflines'] * t for t, r in mm)
+            tf = fl_f / (t_f / 1e3) / 1e12
+            fams.append((t_f, dict(bound='mfma', kernel='matrix-core family: ' + ' | '.join(r['kernel'].split(' (')[0].split(' at M')[0] for _, r in mm),
+                                   achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None,
+                                   launches=sum(r['launches'] for _, r in mm), avg_us=t_f / sum(r['launches'] for _, r in mm) * 1e3,
+                                   frac_of_launch_rooflines=roof_f / t_f, gpu_ms_per_image=t_f / (n_groups * BI), classes=[r for _, r in mm],
+                                   traffic_note='per-launch HBM traffic is a per-class figure: see `classes`')))
+        for t, r in recs:
+            if r['bound'] == 'hbm':
+                fams.append((t, r))
+        fams.sort(key=lambda r: -r[0])
+        if fams:
+            return dict(fams[0][1], note=note), [r for _, r in fams[1:]]
         return None, []
 
 
@@ -854,6 +890,17 @@ def main():
         return dict(words_per_sec=r_['value'], ms_per_step=r_['ms_per_step'], workload=r_['config']['workload'],
                     model_tflops=r_['config']['tflops_model'])
 
+    def kie_parity_leg():   # the same config-3 leg on the engine that meets the parity gates (bf16x3)
+        r_ = run_kie(side_args(dtype='bf16x3'), device, 1, 0)
+        return dict(engine='bf16x3', images_per_sec=r_['value'], ms_per_step=r_['ms_per_step'], workload=r_['config']['workload'],
+                    words_per_image=r_['config']['words_per_image'], entities_per_image=r_['config']['entities_per_image'],
+                    note='tests/test_gpu_e2e.py: kie fixtures identical to the reference on this engine')
+
+    def mgp_parity_leg():   # config 5 on MGP-STR's parity engine (round 5: split-bf16 products, split-plane attention; logits <= 1.6e-4 at batch 512)
+        r_ = run_mgp_str(side_args(steps=4, warmup=1, dtype='bf16x3'), device, 1, 0)
+        return dict(engine='bf16x3', words_per_sec=r_['value'], ms_per_step=r_['ms_per_step'], workload=r_['config']['workload'],
+                    note='tests/test_gpu_mgp.py::test_mgp_golden_parity_engine / test_mgp_batch512_config5[bf16x3]: fp32 gates')
+
     def long_pt_leg():
         # BASELINE config 4 as far as the reference allows: the released code has no table-recognition head and its
         # position tables hold 1024 entries (transformer.py:475), so the long structured-sequence decode is the point decoder at
@@ -889,6 +936,9 @@ def main():
         leg('kie', kie_leg)
         leg('mgp_str', mgp_leg)
         leg('long_pt', long_pt_leg)
+        if not a.no_parity_leg and a.dtype == 'bf16':
+            leg('kie_parity', kie_parity_leg)
+            leg('mgp_str_parity', mgp_parity_leg)
 
     if a.phase_times and rank == 0:
         def one_step():

@@ -136,13 +136,30 @@ int omp_swin_mlp_fused2(const void* x, int x_dtype, int64_t ldx, const float* ln
                         const void* wpack, const float* b2, void* y, int64_t ldy, int64_t M, int C, int hidden,
                         omp_stream_t s);
 
-/* ---- The same sub-layer at C = 512 (Swin-B stage 2) as a row-owner chain (round 5, csrc/dec_rows.hip) -------------------------------
- * x = x + fc2(GELU(fc1(LayerNorm(x)))) in place on the fp32 residual stream [M, 512], hidden 2048, bf16 matrix-core operands (LayerNorm
- * output and hidden activations rounded to bf16 as in the three-launch path).  A workgroup owns 80 tokens and streams the weights; wstream
- * is written once per checkpoint by model/packing.py::pack_rows_mlp (per wave: 8 chunks of [fc1 rows of 256 hidden units, fc2 columns
- * of the same units] as 1 KB matrix-core fragments in consumption order, see omp_dec_rows_ffn; + 8 KB slack). */
-int omp_swin_mlp_rows(float* x, int64_t M, const float* ln_gamma, const float* ln_beta, float eps, const void* wstream, int64_t wave_stride,
-                      const float* b1, const float* b2, omp_stream_t s);
+/* ---- Swin-B stage 2 (C = 512, hidden 2048) as row-owner chains (round 5, csrc/dec_rows.hip) ------------------------------------------
+ * Everything of a SwinTransformerBlock (swin_transformer.py:196-253) except the window attention core is row-local, so a block is the
+ * window attention kernel (omp_swin_window_attn2 on bf16 q | k | v) plus ONE launch of this entry point:
+ *   mode 0: qkv = bf16(LayerNorm(x; n1) Wqkv^T + bqkv)                                          (:208 + :127, the stage's first block)
+ *   mode 1: x += att Wproj^T + bproj  (:148, :246);  x += fc2(GELU(fc1(LayerNorm(x; n2))))     (:250 with Mlp.forward :30-36 inlined);
+ *           and, when n1_g != NULL, the NEXT block's qkv = bf16(LayerNorm(x; n1) Wqkv'^T + bqkv')
+ * x: fp32 residual stream [M, 512], in place; att: bf16 [M, 512] (attention output in token order); qkv: bf16 [M, 1536].  A workgroup owns
+ * omp_dec_rows_tile() tokens and streams the weights: wstream is written once per checkpoint by model/packing.py (pack_rows_embed_qkv for
+ * mode 0, pack_rows_ffn_qkv / pack_rows_ffn for mode 1: proj, 8 chunks of [fc1 rows of 256 hidden units, fc2 columns of the same units],
+ * then the next block's qkv; fragment format as omp_dec_rows_ffn).  bf16 matrix-core operands (LayerNorm outputs and hidden activations
+ * are rounded to bf16 exactly where the launch-per-Linear path rounds), fp32 accumulation, the bf16 engine's GELU. */
+typedef struct {
+  int64_t M;
+  float eps;
+  int32_t mode;
+  float* x;
+  const void* att;
+  void* qkv;
+  const void* wstream;
+  int64_t wave_stride;
+  const float *proj_b, *n2_g, *n2_b, *fc1_b, *fc2_b;   /* mode 1 */
+  const float *n1_g, *n1_b, *qkv_b;                    /* the LayerNorm + qkv Linear behind the chain (mode 0: the chain itself) */
+} omp_swin_rows_args;
+int omp_swin_rows_block(const omp_swin_rows_args* a, omp_stream_t s);
 
 /* ---- Swin patch embedding: zero-pad to x4, 4x4/4 conv (as K=48 dot products), LayerNorm -----
  * Replaces PatchEmbed.forward, swin_transformer.py:427-443.  img is NCHW fp32 (as the reference

@@ -723,33 +723,57 @@ def check_dec_rows():
     return out
 
 
-def check_swin_mlp_rows():
-    """MLP half of a Swin stage-2 block (C = 512) as a row-owner chain (omp_swin_mlp_rows) against x + fc2(GELU(fc1(LN(x)))) on the CPU with bf16
-    rounding where the kernel rounds (LayerNorm output, hidden activations), exact erf GELU, and against the three-launch path of the bf16 engine.
-    M = 1000 tokens: 13 workgroups, the last one ragged."""
+def check_swin_rows_block():
+    """A Swin stage-2 block (C = 512) minus its window attention core as row-owner chains (omp_swin_rows_block, round 5): mode 0 (norm1 + qkv) and
+    mode 1 (proj + residual, norm2, fc1 + GELU, fc2 + residual, with and without the next block's norm1 + qkv) against the CPU with bf16 rounding
+    where the kernel rounds and the exact erf GELU, and against the launch-per-Linear path of the bf16 engine.  M = 1000 tokens: 13 workgroups, the
+    last one ragged."""
     from advancedliteratemachinery_amd.model import packing
     bf = torch.bfloat16
     C, Hd, M = 512, 2048, 1000
-    x = rnd(M, C, seed=1, scale=2.0)
-    g, b = 1 + rnd(C, seed=2, scale=0.1), rnd(C, seed=3, scale=0.1)
-    w1, w2 = q(rnd(Hd, C, seed=4) / C ** 0.5, bf), q(rnd(C, Hd, seed=5) / Hd ** 0.5, bf)
-    b1, b2 = rnd(Hd, seed=6, scale=0.1), rnd(C, seed=7, scale=0.1)
-    y = q(F.layer_norm(x, (C,), g, b, 1e-5), bf)
-    h = q(F.gelu(y @ w1.T + b1), bf)
-    ref = x + h @ w2.T + b2
+    ln = lambda t, g_, b_: F.layer_norm(t, (C,), g_, b_, 1e-5)            # noqa: E731
     dev = lambda t, dt=None: (t.to(dt) if dt is not None else t).to(DEV).contiguous()   # noqa: E731
-    stream, stride = packing.pack_rows_mlp(dev(w1, bf), dev(w2, bf))
+    W = lambda n, k, seed: q(rnd(n, k, seed=seed) / k ** 0.5, bf)          # noqa: E731
+    vec = lambda n, seed: rnd(n, seed=seed, scale=0.1)                      # noqa: E731
+    x = rnd(M, C, seed=1, scale=2.0)
+    att = q(rnd(M, C, seed=2), bf)
+    g1, b1_, g2, b2_ = 1 + vec(C, 3), vec(C, 4), 1 + vec(C, 5), vec(C, 6)
+    Wqkv, bqkv = W(3 * C, C, 7), vec(3 * C, 8)
+    Wp, bp = W(C, C, 9), vec(C, 10)
+    W1, bb1, W2, bb2 = W(Hd, C, 11), vec(Hd, 12), W(C, Hd, 13), vec(C, 14)
+    out = []
+    # mode 0
+    qkv_ref = q(q(ln(x, g1, b1_), bf) @ Wqkv.T + bqkv, bf)
+    s0 = packing.pack_rows_embed_qkv(dev(Wqkv, bf))
     xd = dev(x)
-    ops.swin_mlp_rows(xd, dev(g), dev(b), stream, stride, dev(b1), dev(b2))
+    qkv = ops.swin_rows_qkv(xd, (dev(g1), dev(b1_)), dev(bqkv), s0[0], s0[1])
     torch.cuda.synchronize()
-    out = [rec('swin_mlp_rows vs CPU', maxerr(xd, ref), 4e-3 * ref.abs().max().item(), 'one-ulp flips of the bf16 hidden activations')]
-    # the three-launch path of the bf16 engine on the same inputs
+    out.append(rec('swin_rows_block[mode 0] qkv', maxerr(qkv, qkv_ref), 0.02 * qkv_ref.abs().max().item()))
+    out.append(rec('swin_rows_block[mode 0] leaves x alone', maxerr(xd, x), 0.0))
+    # mode 1, with and without the next block's qkv
+    x1 = x + att @ Wp.T + bp
+    h = q(F.gelu(q(ln(x1, g2, b2_), bf) @ W1.T + bb1), bf)
+    x2 = x1 + h @ W2.T + bb2
+    qkv2_ref = q(q(ln(x2, g1, b1_), bf) @ Wqkv.T + bqkv, bf)
+    for tail in (True, False):
+        st = (packing.pack_rows_ffn_qkv(dev(Wp, bf), dev(W1, bf), dev(W2, bf), dev(Wqkv, bf)) if tail
+              else packing.pack_rows_ffn(dev(Wp, bf), dev(W1, bf), dev(W2, bf)))
+        xd = dev(x)
+        got = ops.swin_rows_block(xd, dev(att, bf), st[0], st[1], dev(bp), (dev(g2), dev(b2_)), dev(bb1), dev(bb2),
+                                  next_n1=(dev(g1), dev(b1_)) if tail else None, next_qkv_b=dev(bqkv) if tail else None)
+        torch.cuda.synchronize()
+        tag = 'swin_rows_block[mode 1%s]' % (', + next qkv' if tail else '')
+        out.append(rec(tag + ' x vs CPU', maxerr(xd, x2), 4e-3 * x2.abs().max().item(), 'one-ulp flips of the bf16 hidden activations'))
+        if tail:
+            out.append(rec(tag + ' qkv vs CPU', maxerr(got, qkv2_ref), 0.03 * qkv2_ref.abs().max().item()))
+    # the launch-per-Linear path of the bf16 engine on the same inputs
     x3 = dev(x)
-    yd = ops.layernorm(x3, dev(g), dev(b), out_dtype=bf)
-    hd = ops.gemm(yd, dev(w1, bf), dev(b1), act=ops.ACT_GELU)
-    ops.gemm(hd, dev(w2, bf), dev(b2), residual=x3, out=x3)
+    ops.gemm(dev(att, bf), dev(Wp, bf), dev(bp), residual=x3, out=x3)
+    yd = ops.layernorm(x3, dev(g2), dev(b2_), out_dtype=bf)
+    hd = ops.gemm(yd, dev(W1, bf), dev(bb1), act=ops.ACT_GELU)
+    ops.gemm(hd, dev(W2, bf), dev(bb2), residual=x3, out=x3)
     torch.cuda.synchronize()
-    out.append(rec('swin_mlp_rows vs LayerNorm + fc1(GELU) + fc2(residual) launches', maxerr(xd, x3), 4e-3 * ref.abs().max().item()))
+    out.append(rec('swin_rows_block[mode 1] x vs proj + LayerNorm + fc1(GELU) + fc2 launches', maxerr(xd, x3), 4e-3 * x2.abs().max().item()))
     return out
 
 

@@ -617,3 +617,45 @@ def test_gemm_dispatch_table():
     # argument errors surface as errors, not as a selector
     with pytest.raises(RuntimeError):
         G(128, 512, 100)
+
+
+def test_gemm_choice_refuses_what_the_launch_path_refuses():
+    """omp_debug_gemm_choice used to return BEFORE the selector / argument compatibility checks of launch_gemm, so the host-logic
+    test of the dispatch table could report a selector for arguments the real call rejects.  A forced selector that does not take the
+    product is now OMP_ERR_UNSUPPORTED in the host-logic call as well."""
+    import pytest
+    from advancedliteratemachinery_amd import ops
+    try:
+        ops.force_gemm_kernel(3)      # the row-streaming kernel has no second destination
+        with pytest.raises(RuntimeError):
+            ops.gemm_choice(131072, 512, 1024, out_dtype=ops.OMP_BF16, residual=True, two_destinations=True)
+        assert ops.gemm_choice(16, 512, 512) == 3
+        ops.force_gemm_kernel(20)     # the persistent four-wave kernel needs M, N, K multiples of 256
+        with pytest.raises(RuntimeError):
+            ops.gemm_choice(10240, 1104, 512)
+        assert ops.gemm_choice(131072, 2048, 512, act=ops.ACT_GELU) == 20
+        ops.force_gemm_kernel(22)     # the fused bf16x3 kernel takes bf16x3 operands only
+        with pytest.raises(RuntimeError):
+            ops.gemm_choice(131072, 1536, 512)
+    finally:
+        ops.force_gemm_kernel(0)
+
+
+def test_env_knobs_are_validated(monkeypatch):
+    """OMP355_* knobs were read with bare int() / string compares"""
+    import pytest
+    from advancedliteratemachinery_amd.utils.env import env_flag, env_int
+    monkeypatch.setenv('OMP355_ENC_CHUNK', '64')
+    assert env_int('OMP355_ENC_CHUNK', 32, 1, 4096) == 64
+    for bad in ('0', 'x', '99999'):
+        monkeypatch.setenv('OMP355_ENC_CHUNK', bad)
+        with pytest.raises(ValueError):
+            env_int('OMP355_ENC_CHUNK', 32, 1, 4096)
+    monkeypatch.setenv('OMP355_CROSS_SPLIT', '3')
+    with pytest.raises(ValueError):
+        env_int('OMP355_CROSS_SPLIT', 0, 0, 16, allowed=(0, 1, 2, 4, 8, 16))
+    monkeypatch.setenv('OMP355_KV_SPLIT', 'yes')
+    with pytest.raises(ValueError):
+        env_flag('OMP355_KV_SPLIT', True)
+    monkeypatch.delenv('OMP355_KV_SPLIT')
+    assert env_flag('OMP355_KV_SPLIT', True) is True

@@ -194,3 +194,60 @@ def test_rank_items_reads_only_the_ranks_own_shard():
     mark = lambda _: None   # noqa: E731
     dl3 = torch.utils.data.DataLoader(Counting(10), batch_size=1, shuffle=False, num_workers=0, collate_fn=lambda b: b[0], worker_init_fn=mark)
     assert inf._rank_items(dl3, 0, 2, False)[0].worker_init_fn is mark
+
+
+def test_plan_eos_balance_is_a_balanced_partition_with_homogeneous_batches():
+    """dense pages sit together in a dataset -> contiguous shards make one rank the straggler; the plan spreads predicted cost over
+    the ranks (LPT, shard sizes as shard_range) and batches images of similar predicted count."""
+    g = torch.Generator().manual_seed(7)
+    n, world, bs = 203, 8, 4
+    pred = [int(v) for v in torch.randint(1, 8, (n,), generator=g)]
+    for i in range(40):            # a run of dense images at the front of the dataset
+        pred[i] = 40 + (i % 25)
+    plan = inf.plan_eos_balance(pred, world, bs)
+    flat = [i for batches in plan for b in batches for i in b]
+    assert sorted(flat) == list(range(n))                                                      # a partition
+    sizes = [sum(len(b) for b in batches) for batches in plan]
+    assert sizes == [udist.shard_range(n, r, world)[1] - udist.shard_range(n, r, world)[0] for r in range(world)]
+    assert all(len(b) <= bs for batches in plan for b in batches)
+    contiguous = [[list(range(lo, hi))[o:o + bs] for o in range(0, hi - lo, bs)] for lo, hi in (udist.shard_range(n, r, world) for r in range(world))]
+    c_new, c_old = inf.plan_cost(plan, pred), inf.plan_cost(contiguous, pred)
+    assert max(c_new) < 0.5 * max(c_old)                                                       # the straggler is gone
+    assert max(c_new) <= 1.25 * (sum(c_new) / world)                                           # ranks within 25 % of the mean
+    for batches in plan:                                                                       # descending, homogeneous batches
+        tops = [max(pred[i] for i in b) for b in batches]
+        assert tops == sorted(tops, reverse=True)
+    assert inf.plan_eos_balance(pred, world, bs) == plan                                       # deterministic: no communication needed
+
+
+def _worker_balanced(rank, world, port, folder, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    assert udist.init_distributed_mode(backend='gloo')
+    args = make_args(use_char_window_prompt=True, output_folder=folder)
+    loader = _loader(9)
+    args.eos_pred_counts = [_key(s.tensors[0], s.mask[0]) % 4 for s, _ in loader]   # the stub's true instance counts as the prediction
+    model = StubModel()
+    got = inf.validate(model, loader, 2, args, batch_size=2)
+    plan = inf.plan_eos_balance(args.eos_pred_counts, world, 2)
+    q.put((rank, len(got), [b for (b, _, _, _), _ in model.calls], [len(b) for b in plan[rank]]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_validate_world2_eos_balanced_shards_give_the_same_json(tmp_path):
+    """args.eos_pred_counts: balanced, non-contiguous shards and plan-cut engine calls -- the JSON is the contiguous run's, in dataset order"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_balanced, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    args = make_args(use_char_window_prompt=True)
+    exp = _expected(9, args)
+    assert got[0][1] == len(exp) and got[1][1] == 0
+    for _, _, calls, planned in got:
+        assert calls == planned                                  # every rank made exactly the engine calls of its plan
+    _same(json.load(open(os.path.join(str(tmp_path), 'results', 'ep002', 'unit_val.json'))), exp)

@@ -413,33 +413,65 @@ def bench_dec_rows_fused():
                       % (I, label, 'two streams' if streams else 'one stream ', a.elapsed_time(b_) / 3), flush=True)
 
 
-def bench_mlp_rows():
-    """round 5: the MLP half of a Swin stage-2 block (C = 512) at the encoder's chunk size: LayerNorm + fc1(GELU) + fc2(fp32 residual) as
-    three launches vs the row-owner chain (omp_swin_mlp_rows)."""
+def bench_swin_rows():
+    """round 5: a Swin stage-2 block (C = 512, 16 heads) at the encoder's chunk size (32 images of 1024 x 1024: 131 072 tokens): LayerNorm, qkv,
+    window attention, proj, LayerNorm, fc1 + GELU, fc2 as seven launches vs window attention + ONE row-owner chain (omp_swin_rows_block)."""
     from advancedliteratemachinery_amd.model import packing
     bf = torch.bfloat16
-    C, Hd = 512, 2048
-    for M in (int(os.environ.get('KBENCH_MLP_ROWS', '131072')), 32768):
-        x = torch.randn(M, C, device=DEV)
-        g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
-        w1 = (torch.randn(Hd, C, device=DEV) / C ** 0.5).to(bf)
-        w2 = (torch.randn(C, Hd, device=DEV) / Hd ** 0.5).to(bf)
-        b1, b2 = torch.randn(Hd, device=DEV) * 0.1, torch.randn(C, device=DEV) * 0.1
-        stream, stride = packing.pack_rows_mlp(w1, w2)
-        y = torch.empty(M, C, device=DEV, dtype=bf)
-        hbuf = torch.empty(M, Hd, device=DEV, dtype=bf)
-        fl = 2.0 * M * C * Hd * 2
+    C, Hd, nH = 512, 2048, 16
+    B = int(os.environ.get('KBENCH_SWIN_B', '32'))
+    H = W = 64
+    M = B * H * W
+    x = torch.randn(M, C, device=DEV)
+    g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    Wm = lambda n, k: (torch.randn(n, k, device=DEV) / k ** 0.5).to(bf)   # noqa: E731
+    wqkv, wp, w1, w2 = Wm(3 * C, C), Wm(C, C), Wm(Hd, C), Wm(C, Hd)
+    bqkv, bp, b1, b2 = (torch.randn(n, device=DEV) * 0.1 for n in (3 * C, C, Hd, C))
+    table = torch.randn(169, nH, device=DEV) * 0.2
+    bexp = ops.swin_expand_bias(table)
+    y = torch.empty(M, C, device=DEV, dtype=bf)
+    att = torch.empty(M, C, device=DEV, dtype=bf)
+    hbuf = torch.empty(M, Hd, device=DEV, dtype=bf)
+    qkv = torch.empty(M, 3 * C, device=DEV, dtype=bf)
+    fl = 2.0 * M * C * (3 * C + C + 2 * Hd)
 
-        def unfused():
-            ops.layernorm(x, g, b, out=y, out_dtype=bf)
-            ops.gemm(y, w1, b1, act=ops.ACT_GELU, out=hbuf)
-            ops.gemm(hbuf, w2, b2, residual=x, out=x)
-        us = timeit(unfused, iters=10, warm=2)
-        print('mlp_rows[C=512] M=%d LayerNorm + fc1(GELU) + fc2(fp32 residual), 3 launches : %8.1f us  %6.1f TF/s' % (M, us, fl / us / 1e6), flush=True)
-        x.normal_()
-        us = timeit(lambda: ops.swin_mlp_rows(x, g, b, stream, stride, b1, b2), iters=10, warm=2)
-        print('mlp_rows[C=512] M=%d row-owner chain (omp_swin_mlp_rows)                       : %8.1f us  %6.1f TF/s  %6.0f GB/s (x in + out)'
-              % (M, us, fl / us / 1e6, 2.0 * M * C * 4 / us / 1e3), flush=True)
+    def seven():
+        ops.layernorm(x, g, b, out=y, out_dtype=bf)
+        ops.gemm(y, wqkv, bqkv, out=qkv)
+        ops.swin_window_attn(qkv, bqkv, table, B, H, W, C, nH, 3, out=att, bias_expanded=bexp)
+        ops.gemm(att, wp, bp, residual=x, out=x)
+        ops.layernorm(x, g, b, out=y, out_dtype=bf)
+        ops.gemm(y, w1, b1, act=ops.ACT_GELU, out=hbuf)
+        ops.gemm(hbuf, w2, b2, residual=x, out=x)
+    us7 = timeit(seven, iters=10, warm=2)
+    print('swin_rows[C=512] %d tokens: LayerNorm, qkv, window attention, proj, LayerNorm, fc1 + GELU, fc2 (7 launches) : %8.1f us  %6.1f TF/s' % (M, us7, fl / us7 / 1e6), flush=True)
+    x.normal_()
+    st = packing.pack_rows_ffn_qkv(wp, w1, w2, wqkv)
+
+    def two():
+        ops.swin_window_attn(qkv, bqkv, table, B, H, W, C, nH, 3, out=att, bias_expanded=bexp)
+        ops.swin_rows_block(x, att, st[0], st[1], bp, (g, b), b1, b2, next_n1=(g, b), next_qkv_b=bqkv, qkv=qkv)
+    us2 = timeit(two, iters=10, warm=2)
+    print('swin_rows[C=512] %d tokens: window attention + ONE chain (proj, norm2, fc1 + GELU, fc2, next norm1 + qkv)    : %8.1f us  %6.1f TF/s' % (M, us2, fl / us2 / 1e6), flush=True)
+    if os.environ.get('KBENCH_ROWS_TRACE', '1') == '1':   # wave 0's cycles per phase, median over the workgroups
+        h = _lib.lib()
+        nwg = (M + 79) // 80
+        trace = torch.zeros(nwg, 16, dtype=torch.int64, device=DEV)
+        h.omp_debug_swin_mlp_trace(ops.ptr(trace))
+        ops.swin_rows_block(x, att, st[0], st[1], bp, (g, b), b1, b2, next_n1=(g, b), next_qkv_b=bqkv, qkv=qkv)
+        torch.cuda.synchronize()
+        h.omp_debug_swin_mlp_trace(None)
+        t = trace.cpu().double()
+        t = t[t[:, 0] > 0]
+        med = t.median(dim=0).values
+        names = ['whole workgroup (wave 0)', 'prologue: attention rows -> LDS', 'proj product', 'residual + LayerNorm2 + bias', 'fc1 products (8 chunks)',
+                 'barrier before the hidden tile is rewritten', 'GELU + LDS writes', 'barrier behind them', 'fc2 products (8 chunks)', 'x store',
+                 'next norm1 (LayerNorm over accumulators)', 'next qkv products + stores']
+        for i, n in enumerate(names):
+            print('    %-46s %9.0f cycles (%5.1f%%)' % (n, med[i].item(), 100 * med[i].item() / med[0].item()), flush=True)
+        print('    workgroups %d, sum of phases / whole = %.3f' % (t.shape[0], float(med[1:12].sum() / med[0])), flush=True)
+    usa = timeit(lambda: ops.swin_window_attn(qkv, bqkv, table, B, H, W, C, nH, 3, out=att, bias_expanded=bexp), iters=10, warm=2)
+    print('swin_rows[C=512]   of which the window attention kernel : %8.1f us; the chain : %8.1f us = %6.1f TF/s' % (usa, us2 - usa, fl / (us2 - usa) / 1e6), flush=True)
 
 
 def bench_patch_embed():
@@ -511,8 +543,8 @@ if __name__ == '__main__':
         bench_cross()
     if 'dec_gemm' in what or 'all' in what:
         bench_dec_gemm()
-    if 'mlp_rows' in what:
-        bench_mlp_rows()
+    if 'swin_rows' in what:
+        bench_swin_rows()
     if 'dec_rows_fused' in what:
         bench_dec_rows_fused()
     if 'patch_embed' in what:
