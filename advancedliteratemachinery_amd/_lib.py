@@ -53,14 +53,14 @@ class DecRowsArgs(ctypes.Structure):
                 ('prologue', c_int32), ('tail', c_int32), ('ff1_b', c_void_p), ('ff2_b', c_void_p), ('seq', c_void_p), ('seq_ld', c_int32),
                 ('word_emb', c_void_p), ('pos_tab', c_void_p), ('emb_g', c_void_p), ('emb_b', c_void_p), ('lnt_g', c_void_p), ('lnt_b', c_void_p),
                 ('bias_tab', c_void_p), ('qkv', c_void_p), ('h0_b', c_void_p), ('h1_b', c_void_p), ('h2_b', c_void_p), ('logits', c_void_p),
-                ('vocab', c_int32)]
+                ('vocab', c_int32), ('x3', c_int32)]
 
 
 class SwinRowsArgs(ctypes.Structure):
     """omp_swin_rows_args (include/omp355.h): a Swin stage-2 block minus its window attention core as one row-owner chain"""
     _fields_ = [('M', c_int64), ('eps', c_float), ('mode', c_int32), ('x', c_void_p), ('att', c_void_p), ('qkv', c_void_p), ('wstream', c_void_p),
                 ('wave_stride', c_int64), ('proj_b', c_void_p), ('n2_g', c_void_p), ('n2_b', c_void_p), ('fc1_b', c_void_p), ('fc2_b', c_void_p),
-                ('n1_g', c_void_p), ('n1_b', c_void_p), ('qkv_b', c_void_p)]
+                ('n1_g', c_void_p), ('n1_b', c_void_p), ('qkv_b', c_void_p), ('x3', c_int32)]
 
 
 class DecoderPlan(ctypes.Structure):

@@ -41,53 +41,20 @@
 
 #include "common.h"
 
+// the parity engine's chains (csrc/dec_rows_x3.hip)
+int omp_rows_x3_mid(const omp_dec_rows_args* a, hipStream_t st);
+int omp_rows_x3_ffn(const omp_dec_rows_args* a, hipStream_t st);
+int omp_rows_x3_swin(const omp_swin_rows_args* a, hipStream_t st);
+
 namespace {
 
-constexpr int NW = 8;                  // waves per workgroup
+#include "rows_common.inc"
+
 constexpr int PF = 8;                  // weight fragments in flight per wave
-constexpr int D = 512;                 // d_model
 constexpr int HC = 256;                // hidden units per FFN chunk
 constexpr int A_PITCH = D * 2 + 32;    // operand tile row pitch, bytes: 264 dwords = 8 mod 64 -> the b128 fragment reads are conflict-free
 constexpr int H_PITCH = HC * 2 + 32;   // hidden chunk tile row pitch: 136 dwords = 8 mod 64
 constexpr int TILE_SLACK = 64;         // behind each tile: the operand prefetch of gemm_pass reads one k-step past the last row
-
-template <int... I, class F>
-__device__ __forceinline__ void sfor_seq(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>()), ...); }
-template <int N, class F>
-__device__ __forceinline__ void sfor(F&& f) { sfor_seq(std::make_integer_sequence<int, N>(), f); }
-
-struct Stream {
-  const char* base;   // wave-uniform: the next fragment to REQUEST (kept in scalar registers)
-  unsigned voff;      // lane * 16
-};
-
-template <int U>
-__device__ __forceinline__ void ws_issue(u32x4 (&ring)[PF], Stream& st) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 ; ring-load" : "=v"(ring[U]) : "v"(st.voff), "s"(st.base) : "memory");
-  st.base += 1024;
-}
-template <int U>
-__device__ __forceinline__ bf16x8 ws_take(u32x4 (&ring)[PF]) {
-  asm volatile("s_waitcnt vmcnt(%1) ; ring-take %0" : "+v"(ring[U]) : "n"(PF - 1) : "memory");
-  bf16x8 f;
-  __builtin_memcpy(&f, &ring[U], 16);
-  return f;
-}
-// The ring runs PF fragments ahead of the stream's end.  The compiler sees no further use of those registers and would hand them to the
-// code that follows -- where the requests still in flight would land on live values (the build audit caught exactly that).  After a
-// kernel's last product: wait for everything, with the ring registers as operands so that they stay allocated until then.
-__device__ __forceinline__ void ws_drain(u32x4 (&ring)[PF]) {
-  asm volatile("s_waitcnt vmcnt(0) ; ring-drain" : "+v"(ring[0]), "+v"(ring[1]), "+v"(ring[2]), "+v"(ring[3]), "+v"(ring[4]), "+v"(ring[5]), "+v"(ring[6]), "+v"(ring[7])::"memory");
-}
-// A value the optimiser cannot trace back: epilogues index with opaque copies of the lane coordinates so that their address arithmetic is
-// redone where it is used instead of being kept live (as 64-bit pointers, 40+ registers) across the product loops -- the kernels sit at
-// the 256-register budget of two waves per SIMD.
-__device__ __forceinline__ int opaque(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-// LDS-only barrier: the weight ring stays in flight across it (a __syncthreads() would drain vmcnt(0))
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // acc[ft][rt] += W[feature tile ft of this wave][:] . a[row tile rt][:] over KS k-steps of 32; the wave's next NFT * KS stream fragments,
 // ordered (k-step, feature tile).  a_lane = operand tile + (lane & 15) * PITCH + (lane >> 4) * 16.
@@ -121,14 +88,6 @@ __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NFT][RTT], const char* a_
 #pragma unroll 1
     for (int gi = 0; gi < NG; ++gi) group(gi);
   }
-}
-
-template <int NFT, int RTT>
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[NFT][RTT]) {
-#pragma unroll
-  for (int ft = 0; ft < NFT; ++ft)
-#pragma unroll
-    for (int rt = 0; rt < RTT; ++rt) acc[ft][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // LayerNorm of the RT rows held in accumulator layout (v[ft][rt][r]: row rt * 16 + li, feature 64 w + 16 ft + 4 g + r), written as the
@@ -192,27 +151,6 @@ __device__ __forceinline__ void ln_acc_to_tile(const f32x4 (&v)[4][RTT], const f
     }
   }
   lds_barrier();
-}
-
-// two-pass LayerNorm of one 512-wide row held 8 values per lane (the embedding prologue: a wave per row)
-__device__ __forceinline__ void ln_row512(float* v, const float* __restrict__ g, const float* __restrict__ b, int lane, float eps) {
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s += v[i];
-  s = wave_sum(s);
-  const float mean = s * (1.0f / D);
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; q += d * d; }
-  q = wave_sum(q);
-  const float rstd = 1.0f / sqrtf(q * (1.0f / D) + eps);
-  const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + lane * 8), g1 = *reinterpret_cast<const f32x4*>(g + lane * 8 + 4);
-  const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + lane * 8), b1 = *reinterpret_cast<const f32x4*>(b + lane * 8 + 4);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    v[i] = (v[i] - mean) * rstd * g0[i] + b0[i];
-    v[i + 4] = (v[i + 4] - mean) * rstd * g1[i] + b1[i];
-  }
 }
 
 // the attention output rows of this workgroup (bf16 [R, 512]) -> operand tile, by LDS DMA: a row is 1 KB = one wave instruction (64 lanes x
@@ -282,16 +220,6 @@ template <int RTT, bool STORE>
 __device__ __forceinline__ void add_bias_residual(f32x4 (&acc)[4][RTT], const float* __restrict__ bias, float* __restrict__ xb, int nrow, int wave, int li, int g) {
   if (nrow == RTT * 16) add_bias_residual_t<RTT, STORE, true>(acc, bias, xb, nrow, wave, li, g);
   else add_bias_residual_t<RTT, STORE, false>(acc, bias, xb, nrow, wave, li, g);
-}
-
-// the bias quads of this lane's NFT feature tiles (loaded BEFORE the product whose epilogue uses them: the load hides under the product)
-template <int NFT>
-__device__ __forceinline__ void load_bias(f32x4 (&bb)[NFT], const float* __restrict__ bias, int fwave, int flimit, int g) {
-#pragma unroll
-  for (int ft = 0; ft < NFT; ++ft) {
-    const int f = fwave + ft * 16 + g * 4;
-    bb[ft] = f < flimit ? *reinterpret_cast<const f32x4*>(bias + f) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
 }
 
 // out[row][col0 + f] = T(acc + bias) (optionally ReLU): the q / q k v / logits stores.  ob = out + r0 * ld (first row of the workgroup)
@@ -379,12 +307,7 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_mid_kernel(RowsP p) {
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t r0 = (int64_t)blockIdx.x * RT;
-  Stream st;
-  {
-    const uint64_t bs = reinterpret_cast<uint64_t>(p.wstream + (int64_t)wave * p.wave_stride);
-    st.base = reinterpret_cast<const char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bs >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bs));
-    st.voff = lane * 16;
-  }
+  Stream st = stream_of_wave(p.wstream, p.wave_stride, wave, lane);
   u32x4 ring[PF];
   sfor<PF>([&](auto U) { ws_issue<decltype(U)::value>(ring, st); });
   const int pos = *p.d_pos;
@@ -426,12 +349,7 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_ffn_kernel(RowsP p) {
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t r0 = (int64_t)blockIdx.x * RT;
-  Stream st;
-  {
-    const uint64_t bs = reinterpret_cast<uint64_t>(p.wstream + (int64_t)wave * p.wave_stride);
-    st.base = reinterpret_cast<const char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bs >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bs));
-    st.voff = lane * 16;
-  }
+  Stream st = stream_of_wave(p.wstream, p.wave_stride, wave, lane);
   u32x4 ring[PF];
   sfor<PF>([&](auto U) { ws_issue<decltype(U)::value>(ring, st); });
   const int pos = p.d_pos != nullptr ? *p.d_pos : 0;
@@ -677,7 +595,14 @@ int omp_rows_tile() { return RTT_DEFAULT * 16; }
 extern "C" int omp_dec_rows_mid(const omp_dec_rows_args* a, omp_stream_t s) {
   OMP_CHECK_ARG(a != nullptr, "omp_dec_rows_mid: null argument block");
   OMP_CHECK_ARG(a->R > 0 && a->d_pos && a->x && a->att && a->wstream && a->out_b && a->ln_g && a->ln_b && a->qbias_tab && a->q, "omp_dec_rows_mid: null pointer");
-  OMP_CHECK_ARG(a->wave_stride >= 128 * 1024 && a->wave_stride % 16 == 0 && ((uintptr_t)a->wstream % 16) == 0, "omp_dec_rows_mid: a wave's stream holds 128 fragments of 1 KB");
+  const int mul = a->x3 ? 2 : 1;
+  OMP_CHECK_ARG(a->wave_stride >= mul * 128 * 1024 && a->wave_stride % 16 == 0 && ((uintptr_t)a->wstream % 16) == 0, "omp_dec_rows_mid: a wave's stream holds %d fragments of 1 KB", mul * 128);
+  if (a->x3) {
+    const int slot3 = omp_prof_active(OMP_PROF_ROWS) ? omp_prof_begin(OMP_PROF_ROWS, (hipStream_t)s, 3 * 4.0 * (double)a->R * D * D, (double)a->R * D * (4 + 4 + 4 + 4) + 2.0 * D * D * 4) : -1;
+    const int rc3 = omp_rows_x3_mid(a, (hipStream_t)s);
+    if (slot3 >= 0) omp_prof_end(OMP_PROF_ROWS, slot3, (hipStream_t)s);
+    return rc3;
+  }
   RowsP p{};
   p.R = a->R; p.eps = a->eps; p.d_pos = a->d_pos; p.x = a->x; p.att = reinterpret_cast<const bf16_t*>(a->att);
   p.wstream = reinterpret_cast<const char*>(a->wstream); p.wave_stride = a->wave_stride;
@@ -709,7 +634,15 @@ extern "C" int omp_dec_rows_ffn(const omp_dec_rows_args* a, omp_stream_t s) {
   else OMP_CHECK_ARG(a->h0_b && a->h1_b && a->h2_b && a->logits && a->vocab > 0 && a->vocab % 4 == 0, "omp_dec_rows_ffn: prediction-head tail needs its biases, logits and vocab %% 4 == 0");
   const int vpad = (a->vocab + 127) / 128 * 128;
   const int64_t frags = (a->prologue == 0 ? 64 + 16 * 32 : 0) + (a->tail == 0 ? 192 : 128 + (vpad / 512) * 64 + ((vpad % 512) / 128) * 16);
-  OMP_CHECK_ARG(a->wave_stride >= frags * 1024 && a->wave_stride % 16 == 0 && ((uintptr_t)a->wstream % 16) == 0, "omp_dec_rows_ffn: a wave's stream holds %lld fragments of 1 KB here", (long long)frags);
+  const int mul = a->x3 ? 2 : 1;
+  OMP_CHECK_ARG(a->wave_stride >= mul * frags * 1024 && a->wave_stride % 16 == 0 && ((uintptr_t)a->wstream % 16) == 0, "omp_dec_rows_ffn: a wave's stream holds %lld fragments of 1 KB here", (long long)(mul * frags));
+  if (a->x3) {
+    const double fl3 = 3 * 2.0 * (double)a->R * D * ((a->prologue == 0 ? D + 8.0 * D : 0.0) + (a->tail == 0 ? 3.0 * D : 2.0 * D + a->vocab));
+    const int slot3 = omp_prof_active(OMP_PROF_ROWS) ? omp_prof_begin(OMP_PROF_ROWS, (hipStream_t)s, fl3, (double)a->R * D * (4 + 4 + 4) + (double)a->R * (a->tail == 0 ? 3 * D * 4 : a->vocab * 4) + (double)frags * 2 * 8192) : -1;
+    const int rc3 = omp_rows_x3_ffn(a, (hipStream_t)s);
+    if (slot3 >= 0) omp_prof_end(OMP_PROF_ROWS, slot3, (hipStream_t)s);
+    return rc3;
+  }
   RowsP p{};
   p.R = a->R; p.eps = a->eps; p.d_pos = a->d_pos; p.x = a->x; p.att = reinterpret_cast<const bf16_t*>(a->att);
   p.wstream = reinterpret_cast<const char*>(a->wstream); p.wave_stride = a->wave_stride;
@@ -746,8 +679,17 @@ extern "C" int omp_swin_rows_block(const omp_swin_rows_args* a, omp_stream_t s) 
   if (a->mode == 0) OMP_CHECK_ARG(tail_qkv && a->n1_b && a->qkv_b && a->qkv, "omp_swin_rows_block: mode 0 needs norm1, the qkv bias and the qkv destination");
   else OMP_CHECK_ARG(a->att && a->proj_b && a->n2_g && a->n2_b && a->fc1_b && a->fc2_b && (!tail_qkv || (a->n1_b && a->qkv_b && a->qkv)), "omp_swin_rows_block: null pointer");
   const int64_t frags = (a->mode == 1 ? 64 + 8 * 64 : 0) + (tail_qkv ? 192 : 0);
-  OMP_CHECK_ARG(a->wave_stride >= frags * 1024 && a->wave_stride % 16 == 0 && ((uintptr_t)a->wstream % 16) == 0 && ((uintptr_t)a->x % 16) == 0,
-                "omp_swin_rows_block: a wave's stream holds %lld fragments of 1 KB here; 16-byte aligned pointers", (long long)frags);
+  const int mul = a->x3 ? 2 : 1;
+  OMP_CHECK_ARG(a->wave_stride >= mul * frags * 1024 && a->wave_stride % 16 == 0 && ((uintptr_t)a->wstream % 16) == 0 && ((uintptr_t)a->x % 16) == 0,
+                "omp_swin_rows_block: a wave's stream holds %lld fragments of 1 KB here; 16-byte aligned pointers", (long long)(mul * frags));
+  if (a->x3) {
+    const double fl3 = 3 * 2.0 * (double)a->M * D * ((a->mode == 1 ? D + 8.0 * D : 0.0) + (tail_qkv ? 3.0 * D : 0.0));
+    const double by3 = (double)a->M * D * (a->mode == 1 ? 4 + 4 + 4 : 4) + (tail_qkv ? (double)a->M * 3 * D * 4 : 0.0) + (double)frags * 2 * 8192;
+    const int slot3 = omp_prof_active(OMP_PROF_MLP) ? omp_prof_begin(OMP_PROF_MLP, (hipStream_t)s, fl3, by3) : -1;
+    const int rc3 = omp_rows_x3_swin(a, (hipStream_t)s);
+    if (slot3 >= 0) omp_prof_end(OMP_PROF_MLP, slot3, (hipStream_t)s);
+    return rc3;
+  }
   RowsP p{};
   p.R = (int)a->M; p.eps = a->eps; p.d_pos = nullptr; p.x = a->x; p.att = reinterpret_cast<const bf16_t*>(a->att);
   p.wstream = reinterpret_cast<const char*>(a->wstream); p.wave_stride = a->wave_stride;

@@ -1657,11 +1657,66 @@ int step_launch_rows(const omp_decoder_plan* P, hipStream_t st) {
   return OMP_OK;
 }
 
+// The same step for the parity engine (plan->gemm_x3 with rows_fused): the chains of csrc/dec_rows_x3.hip -- three bf16 matrix-core products per
+// Linear over split operands -- between the fp32 self-attention kernel and the split-plane cross-attention kernel.  The attention outputs reach
+// the chains as split pairs: the cross-attention kernels write them themselves (kv_split), the self-attention output goes through omp_split_bf16.
+int step_launch_rows_x3(const omp_decoder_plan* P, hipStream_t st) {
+  const int d = P->d_model, R = P->R, nL = P->n_layers, F = OMP_F32;
+  const int vpad = (P->vocab + 127) / 128 * 128;
+  void* as = P->ffh;   // attention outputs as split pairs [R, 2 d] bf16 (the FFN hidden buffer is unused on this path)
+  omp_dec_rows_args a{};
+  a.x3 = 1;
+  a.R = R; a.eps = P->eps; a.d_pos = P->d_pos; a.x = P->x; a.att = as;
+  a.seq = P->seq; a.seq_ld = P->seq_ld; a.word_emb = P->word_emb; a.pos_tab = P->pos_tab; a.emb_g = P->emb_g; a.emb_b = P->emb_b;
+  a.qkv = P->qkv; a.q = P->q; a.logits = P->logits; a.vocab = P->vocab; a.h0_b = P->h0_b; a.h1_b = P->h1_b; a.h2_b = P->h2_b;
+  a.prologue = 1; a.tail = 0; a.wstream = P->rows_embed; a.wave_stride = 2 * 192 * 1024;
+  a.lnt_g = P->layers[0].n1_g; a.lnt_b = P->layers[0].n1_b; a.bias_tab = P->layers[0].sa_bias_tab;
+  RUN(omp_dec_rows_ffn(&a, st));
+  CrossP cp;
+  cp.q = P->q; cp.ldq = d; cp.img_stride = P->kv_img_stride; cp.Mpad = P->Mpad;
+  cp.kmask = P->key_mask; cp.groups = P->tiles; cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R; cp.kpw = 0;
+  if (P->kv_split) { cp.out = as; cp.ldo = 2 * (int64_t)d; cp.lo_off = d; }
+  else { cp.out = P->att; cp.ldo = d; cp.lo_off = 0; }
+  for (int li = 0; li < nL; ++li) {
+    const omp_dec_layer& L = P->layers[li];
+    cp.K = L.crossK; cp.V = L.crossVt;
+    RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, F, R, P->n_heads, d, P->Lmax, st));
+    RUN(omp_split_bf16(reinterpret_cast<const float*>(P->att), d, as, 2 * d, R, d, 0, st));
+    a.wstream = L.rows_mid; a.wave_stride = 2 * 128 * 1024;
+    a.out_b = L.sa_out_b; a.ln_g = L.n2_g; a.ln_b = L.n2_b; a.qbias_tab = L.ca_qbias_tab;
+    RUN(omp_dec_rows_mid(&a, st));
+    if (P->kv_split) {
+      RUN(launch_cross(cp, P->n_tiles, OMP_BF16X2, P->n_split, P->q_tiles, st));
+    } else {
+      RUN(launch_cross(cp, P->n_tiles, F, P->n_split, P->q_tiles, st));
+      RUN(omp_split_bf16(reinterpret_cast<const float*>(P->att), d, as, 2 * d, R, d, 0, st));
+    }
+    a.prologue = 0; a.wstream = L.rows_ffn;
+    a.out_b = L.ca_out_b; a.ln_g = L.n3_g; a.ln_b = L.n3_b; a.ff1_b = L.ff1_b; a.ff2_b = L.ff2_b;
+    if (li + 1 < nL) {
+      a.tail = 0; a.wave_stride = 2 * (64 + 16 * 32 + 192) * 1024;
+      a.lnt_g = P->layers[li + 1].n1_g; a.lnt_b = P->layers[li + 1].n1_b; a.bias_tab = P->layers[li + 1].sa_bias_tab;
+    } else {
+      a.tail = 1; a.wave_stride = 2 * (int64_t)(64 + 16 * 32 + 128 + (vpad / 512) * 64 + ((vpad % 512) / 128) * 16) * 1024;
+      a.lnt_g = P->fn_g; a.lnt_b = P->fn_b;
+    }
+    RUN(omp_dec_rows_ffn(&a, st));
+  }
+  return OMP_OK;
+}
+
 int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
   const int d = P->d_model, R = P->R, T = P->dtype;
   if (P->gemm_x3) {
     OMP_CHECK_ARG(T == OMP_F32 && P->pre_norm && R > 64 && d % 64 == 0 && P->d_ff % 64 == 0,
                   "omp_decoder_run: gemm_x3 plans are fp32, pre-norm, more than 64 rows, widths multiples of 64");
+    if (P->rows_fused) {
+      OMP_CHECK_ARG(d == 512 && P->d_ff == 2048 && P->n_heads == 8 && P->vocab % 4 == 0 && P->rows_embed != nullptr,
+                    "omp_decoder_run: rows_fused plans are d_model 512 / d_ff 2048 / 8 heads, vocab %% 4 == 0, with packed streams bound");
+      for (int li = 0; li < P->n_layers; ++li)
+        OMP_CHECK_ARG(P->layers[li].rows_mid && P->layers[li].rows_ffn, "omp_decoder_run: rows_fused plan without the packed streams of layer %d", li);
+      return step_launch_rows_x3(P, st);
+    }
     return step_launch_x3(P, do_head, st);
   }
   if (P->rows_fused) {

@@ -115,14 +115,20 @@ class Encoder(object):
             else:
                 st.down_g = st.down_b = st.down_w = None
             st.out_g, st.out_b = f32('%snorm%d.weight' % (bb, s)), f32('%snorm%d.bias' % (bb, s))
-            # row-owner chains of a C = 512 stage: packed weight streams per block (its proj + MLP + the next block's qkv) and the first block's qkv
+            # row-owner chains of a C = 512 stage: packed weight streams per block (its proj + MLP + the next block's qkv) and the first block's
+            # qkv; the bf16 engine packs its bf16 matrices (csrc/dec_rows.hip), the parity engine the fp32 masters as (hi, lo) fragment pairs
+            # (csrc/dec_rows_x3.hip)
             st.rows_qkv0 = None
-            if (dtype == torch.bfloat16 and not self.x3 and st.C == 512 and all(b_.fc1_w.shape == (2048, 512) for b_ in st.blocks)
+            if ((dtype == torch.bfloat16 or self.x3) and st.C == 512 and all(tuple(sd['%slayers.%d.blocks.%d.mlp.fc1.weight' % (bb, s, i)].shape) == (2048, 512) for i in range(dep))
                     and getattr(args, 'fused_mlp', True) and getattr(args, 'fused_attn', True)):
-                st.rows_qkv0 = pack_rows_embed_qkv(st.blocks[0].qkv_w)
+                if self.x3:
+                    rw = lambda i, leaf: f32('%slayers.%d.blocks.%d.%s' % (bb, s, i, leaf))                 # noqa: E731
+                else:
+                    rw = lambda i, leaf: sd['%slayers.%d.blocks.%d.%s' % (bb, s, i, leaf)].detach().to(dtype).contiguous()   # noqa: E731
+                st.rows_qkv0 = pack_rows_embed_qkv(rw(0, 'attn.qkv.weight'))
                 for i, b_ in enumerate(st.blocks):
-                    nxt = st.blocks[i + 1] if i + 1 < len(st.blocks) else None
-                    b_.rows = (pack_rows_ffn_qkv(b_.proj_w, b_.fc1_w, b_.fc2_w, nxt.qkv_w) if nxt is not None else pack_rows_ffn(b_.proj_w, b_.fc1_w, b_.fc2_w))
+                    args_ = (rw(i, 'attn.proj.weight'), rw(i, 'mlp.fc1.weight'), rw(i, 'mlp.fc2.weight'))
+                    b_.rows = pack_rows_ffn_qkv(*args_, rw(i + 1, 'attn.qkv.weight')) if i + 1 < dep else pack_rows_ffn(*args_)
             self.stages.append(st)
         self.use_fpn = bool(args.use_fpn)
         if self.use_fpn:
@@ -162,7 +168,21 @@ class Encoder(object):
         outs = []
         for st in self.stages:
             C = st.C
-            for blk in st.blocks:
+            blks = st.blocks
+            if st.rows_qkv0 is not None and x.shape[0] >= ROWS_BLOCK_MIN_TOKENS:
+                # stage 2 as row-owner chains over split operands (csrc/dec_rows_x3.hip): per block the split-product window attention on fp32
+                # q | k | v, then ONE launch for proj, norm2, fc1 + GELU, fc2 and the next block's norm1 + qkv
+                qkv = ops.swin_rows_qkv(x, (blks[0].n1g, blks[0].n1b), blks[0].qkv_b, st.rows_qkv0[0], st.rows_qkv0[1], eps=LN_EPS, x3=True)
+                att = torch.empty((x.shape[0], 2 * C), dtype=torch.bfloat16, device=x.device)
+                for i, blk in enumerate(blks):
+                    ops.swin_window_attn(qkv, blk.qkv_b, blk.table, B, H, W, C, st.nH, blk.shift, out=att, window=self.window,
+                                         bias_expanded=blk.bias_exp, out_split=True)
+                    nxt = blks[i + 1] if i + 1 < len(blks) else None
+                    ops.swin_rows_block(x, att, blk.rows[0], blk.rows[1], blk.proj_b, (blk.n2g, blk.n2b), blk.fc1_b, blk.fc2_b,
+                                        next_n1=(nxt.n1g, nxt.n1b) if nxt is not None else None, next_qkv_b=nxt.qkv_b if nxt is not None else None,
+                                        qkv=qkv, eps=LN_EPS, x3=True)
+                blks = ()
+            for blk in blks:
                 y = ops.layernorm(x, blk.n1g, blk.n1b, out_dtype=S, eps=LN_EPS)
                 qkv = ops.gemm(y, blk.qkv_w, blk.qkv_b, out_dtype=torch.float32, a_wrap=2 * C)
                 att = ops.swin_window_attn(qkv, blk.qkv_b, blk.table, B, H, W, C, st.nH, blk.shift, out=y, window=self.window,

@@ -94,7 +94,7 @@ def pack_attn_block(qkv_w, proj_w, n_heads):
 # wave w owns features 64 w + 16 t (t = 0..3) of every 512-feature pass (16 w of a 128-feature pass) and consumes, k-step by
 # k-step, the fragment of each of its feature tiles:  fragment[lane = 16 g + li][8] = W[f0 + li][32 ks + 8 g .. + 8].
 # The packers below write those fragments in consumption order, wave-major: buffer = [8 waves][fragments of the chain][64 lanes][8]
-# bf16 + 8 KB of slack (the kernels' register ring of 8 fragments in flight runs ahead of the stream's end).  Pure index permutation.
+# bf16 + 16 KB of slack (the kernels' register ring of 8 fragments in flight runs ahead of the stream's end).  Pure index permutation.
 # ---------------------------------------------------------------------------------------------------------------------
 ROWS_WAVES = 8
 ROWS_SLACK = 8 * 1024
@@ -102,11 +102,16 @@ ROWS_SLACK = 8 * 1024
 
 def _rows_pass(w, per_wave_tiles):
     """w [16 * 8 * per_wave_tiles, K] (one pass: the features of wave 0's tiles first, then wave 1's ...) -> [8 waves][K / 32 k-steps]
-    [tiles][64 lanes][8]: the pass's fragments in the order every wave consumes its own."""
+    [tiles][64 lanes][8]: the pass's fragments in the order every wave consumes its own.  fp32 w (the parity engine, x3): every fragment
+    becomes a PAIR, the fragment of w_hi = bf16(w) followed by the fragment of w_lo = bf16(w - w_hi)."""
     n, K = w.shape
     t = per_wave_tiles
     if n != 16 * ROWS_WAVES * t or K % 32:
         raise ValueError('_rows_pass: %d features x %d are not %d waves x %d tiles of 16 x k-steps of 32' % (n, K, ROWS_WAVES, t))
+    if w.dtype == torch.float32:
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.float()).to(torch.bfloat16)
+        return torch.stack([_rows_pass(hi, t), _rows_pass(lo, t)], dim=2).reshape(ROWS_WAVES, 2 * (K // 32) * t, 512)
     # w[wave][tile][li][ks][g][e] -> [wave][ks][tile][g][li][e]
     return w.reshape(ROWS_WAVES, t, 16, K // 32, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(ROWS_WAVES, (K // 32) * t, 512)
 
@@ -131,30 +136,33 @@ def _rows_finish(pieces):
     """[8][n_i][512] pieces -> (uint8 buffer, bytes per wave)."""
     s = torch.cat(pieces, dim=1).contiguous()            # [8 waves][fragments][512 bf16]
     per_wave = s.shape[1] * 1024
-    buf = torch.zeros(ROWS_WAVES * per_wave + ROWS_SLACK, dtype=torch.uint8, device=s.device)
+    buf = torch.zeros(ROWS_WAVES * per_wave + 2 * ROWS_SLACK, dtype=torch.uint8, device=s.device)   # slack: 16 fragments in flight (x3 ring)
     buf[:ROWS_WAVES * per_wave] = s.view(torch.uint8).reshape(-1)
     return buf, per_wave
 
 
-def _bf16(*ws):
-    for w in ws:
-        if w.dtype != torch.bfloat16:
-            raise TypeError('the row-owner chains take bf16 matrices')
+def _same_kind(*ws):
+    """the bf16 engine packs bf16 matrices, the parity engine (x3) the fp32 masters: no mixing"""
+    kinds = set(w.dtype for w in ws)
+    if kinds not in ({torch.bfloat16}, {torch.float32}):
+        raise TypeError('the row-owner chains take bf16 matrices (bf16 engine) or fp32 matrices (bf16x3 engine), not %s' % sorted(str(k) for k in kinds))
+    return ws[0].dtype == torch.float32
 
 
 def pack_rows_mid(sa_out_w, ca_q_w):
     """omp_dec_rows_mid: self_attn.out_proj [512, 512], then the query rows of multihead_attn.in_proj [512, 512]."""
-    _bf16(sa_out_w, ca_q_w)
+    _same_kind(sa_out_w, ca_q_w)
     return _rows_finish(_rows_product(sa_out_w) + _rows_product(ca_q_w))
 
 
-def _rows_ffn_pieces(ca_out_w, ff1_w, ff2_w, chunk=256):
-    _bf16(ca_out_w, ff1_w, ff2_w)
+def _rows_ffn_pieces(ca_out_w, ff1_w, ff2_w):
+    x3 = _same_kind(ca_out_w, ff1_w, ff2_w)
+    chunk = 128 if x3 else 256      # hidden units per chunk (csrc/dec_rows_x3.hip: HC3; csrc/dec_rows.hip: HC)
     Hd, C = ff1_w.shape
     if ff2_w.shape != (C, Hd) or Hd % chunk or C != 512:
         raise ValueError('pack_rows_ffn: unsupported shapes %s / %s' % (tuple(ff1_w.shape), tuple(ff2_w.shape)))
     pieces = _rows_product(ca_out_w)
-    for c in range(Hd // chunk):      # per chunk of 256 hidden units: linear1's pass (N = 256: TWO tiles per wave, K = 512), then linear2's (N = 512, K = 256)
+    for c in range(Hd // chunk):      # per chunk of hidden units: linear1's pass (N = chunk: chunk / 128 tiles per wave, K = 512), then linear2's (N = 512, K = chunk)
         pieces.append(_rows_pass(ff1_w[c * chunk:(c + 1) * chunk], chunk // (16 * ROWS_WAVES)))
         pieces += _rows_product(ff2_w[:, c * chunk:(c + 1) * chunk].contiguous())
     return pieces
@@ -162,12 +170,12 @@ def _rows_ffn_pieces(ca_out_w, ff1_w, ff2_w, chunk=256):
 
 def pack_rows_ffn_qkv(ca_out_w, ff1_w, ff2_w, next_sa_in_w):
     """omp_dec_rows_ffn(prologue 0, tail 0): multihead_attn.out_proj, linear1 / linear2 in chunks, then the NEXT layer's self_attn.in_proj [1536, 512]."""
-    _bf16(next_sa_in_w)
+    _same_kind(ca_out_w, next_sa_in_w)
     return _rows_finish(_rows_ffn_pieces(ca_out_w, ff1_w, ff2_w) + _rows_product(next_sa_in_w))
 
 
 def _rows_head_pieces(h0_w, h1_w, h2_w):
-    _bf16(h0_w, h1_w, h2_w)
+    _same_kind(h0_w, h1_w, h2_w)
     V = h2_w.shape[0]
     vpad = (V + 127) // 128 * 128
     if vpad != V:
@@ -177,12 +185,13 @@ def _rows_head_pieces(h0_w, h1_w, h2_w):
 
 def pack_rows_ffn_head(ca_out_w, ff1_w, ff2_w, h0_w, h1_w, h2_w):
     """omp_dec_rows_ffn(prologue 0, tail 1): the last layer's chain, then the 3-layer prediction head (vocabulary rows zero-padded to x128)."""
+    _same_kind(ca_out_w, h0_w)
     return _rows_finish(_rows_ffn_pieces(ca_out_w, ff1_w, ff2_w) + _rows_head_pieces(h0_w, h1_w, h2_w))
 
 
 def pack_rows_embed_qkv(sa_in_w):
     """omp_dec_rows_ffn(prologue 1, tail 0): layer 0's self_attn.in_proj behind the embedding."""
-    _bf16(sa_in_w)
+    _same_kind(sa_in_w)
     return _rows_finish(_rows_product(sa_in_w))
 
 

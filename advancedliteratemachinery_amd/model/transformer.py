@@ -303,8 +303,9 @@ class Decoder(object):
         use_x3 = bool(self.x3 and a.tfm_pre_norm and ph.R >= self.X3_MIN_ROWS and d % 64 == 0 and self.ff % 64 == 0)
         P.gemm_x3 = 1 if use_x3 else 0
         P.kv_split = 1 if self.kv_split else 0
-        use_rows = bool(self.dtype == torch.bfloat16 and a.tfm_pre_norm and ph.R >= self.rows_min and d == 512 and self.ff == 2048 and self.nH == 8
-                        and self.V % 4 == 0)
+        # row-owner chains: the bf16 engine's (csrc/dec_rows.hip) or, on a gemm_x3 plan, the parity engine's (csrc/dec_rows_x3.hip)
+        use_rows = bool((self.dtype == torch.bfloat16 or use_x3) and a.tfm_pre_norm and ph.R >= self.rows_min and d == 512 and self.ff == 2048
+                        and self.nH == 8 and self.V % 4 == 0)
         P.rows_fused = 1 if use_rows else 0
         if use_rows:
             r_embed, r_layers = self._rows_streams(ph.kind)

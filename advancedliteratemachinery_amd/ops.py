@@ -477,12 +477,14 @@ def swin_mlp_variant(v):
     _lib.check(_lib.lib().omp_debug_swin_mlp_variant(int(v)), 'omp_debug_swin_mlp_variant')
 
 
-def dec_rows_mid(att, x, wstream, wave_stride, out_b, ln_g, ln_b, qbias_tab, d_pos, q=None, eps=1e-5):
-    """x += att Wo^T + bo;  q = bf16(LayerNorm(x) Wq^T + qbias_tab[*d_pos])  -- one launch, a workgroup owns 80 rows (include/omp355.h)."""
+def dec_rows_mid(att, x, wstream, wave_stride, out_b, ln_g, ln_b, qbias_tab, d_pos, q=None, eps=1e-5, x3=False):
+    """x += att Wo^T + bo;  q = bf16(LayerNorm(x) Wq^T + qbias_tab[*d_pos])  -- one launch, a workgroup owns 80 rows (include/omp355.h).
+    x3: the parity engine's chain -- att as split pairs bf16 [R, 1024], q fp32, split weight stream, 48 rows per workgroup."""
     R = x.shape[0]
     if q is None:
-        q = torch.empty((R, 512), dtype=torch.bfloat16, device=x.device)
+        q = torch.empty((R, 512), dtype=torch.float32 if x3 else torch.bfloat16, device=x.device)
     a = _lib.DecRowsArgs()
+    a.x3 = 1 if x3 else 0
     a.R, a.eps, a.d_pos, a.x, a.att = R, float(eps), ptr(d_pos), ptr(_c(x, 'x')), ptr(_c(att, 'att'))
     a.wstream, a.wave_stride = ptr(wstream), int(wave_stride)
     a.out_b, a.ln_g, a.ln_b, a.qbias_tab, a.q = ptr(out_b), ptr(ln_g), ptr(ln_b), ptr(qbias_tab), ptr(q)
@@ -491,11 +493,12 @@ def dec_rows_mid(att, x, wstream, wave_stride, out_b, ln_g, ln_b, qbias_tab, d_p
 
 
 def dec_rows_ffn(x, wstream, wave_stride, d_pos, lnt_g, lnt_b, att=None, out_b=None, ln_g=None, ln_b=None, ff1_b=None, ff2_b=None,
-                 embed=None, bias_tab=None, qkv=None, head_b=None, logits=None, vocab=0, eps=1e-5):
+                 embed=None, bias_tab=None, qkv=None, head_b=None, logits=None, vocab=0, eps=1e-5, x3=False):
     """The chain behind the cross-attention (or, embed=(seq, word_emb, pos_tab, emb_g, emb_b), the embedding of layer 0) and its tail:
     bias_tab given -> the next layer's q | k | v (bf16 [R, 1536]); head_b=(b0, b1, b2) -> the prediction head's logits (fp32 [R, vocab])."""
     R = x.shape[0]
     a = _lib.DecRowsArgs()
+    a.x3 = 1 if x3 else 0
     a.R, a.eps, a.d_pos, a.x = R, float(eps), ptr(d_pos), ptr(_c(x, 'x'))
     a.wstream, a.wave_stride = ptr(wstream), int(wave_stride)
     a.lnt_g, a.lnt_b = ptr(lnt_g), ptr(lnt_b)
@@ -507,7 +510,7 @@ def dec_rows_ffn(x, wstream, wave_stride, d_pos, lnt_g, lnt_b, att=None, out_b=N
         a.out_b, a.ln_g, a.ln_b, a.ff1_b, a.ff2_b = ptr(out_b), ptr(ln_g), ptr(ln_b), ptr(ff1_b), ptr(ff2_b)
     if head_b is None:
         if qkv is None:
-            qkv = torch.empty((R, 1536), dtype=torch.bfloat16, device=x.device)
+            qkv = torch.empty((R, 1536), dtype=torch.float32 if x3 else torch.bfloat16, device=x.device)
         a.tail, a.bias_tab, a.qkv = 0, ptr(bias_tab), ptr(qkv)
         out = qkv
     else:
@@ -519,12 +522,14 @@ def dec_rows_ffn(x, wstream, wave_stride, d_pos, lnt_g, lnt_b, att=None, out_b=N
     return out
 
 
-def swin_rows_qkv(x, n1, qkv_b, wstream, wave_stride, qkv=None, eps=1e-5):
-    """qkv = bf16(LayerNorm(x; n1) Wqkv^T + bqkv) for x [M, 512] fp32 (Swin-B stage 2, the stage's first block): omp_swin_rows_block mode 0."""
+def swin_rows_qkv(x, n1, qkv_b, wstream, wave_stride, qkv=None, eps=1e-5, x3=False):
+    """qkv = bf16(LayerNorm(x; n1) Wqkv^T + bqkv) for x [M, 512] fp32 (Swin-B stage 2, the stage's first block): omp_swin_rows_block mode 0.
+    x3: the parity engine's chain (fp32 qkv)."""
     M = x.numel() // 512
     if qkv is None:
-        qkv = torch.empty((M, 1536), dtype=torch.bfloat16, device=x.device)
+        qkv = torch.empty((M, 1536), dtype=torch.float32 if x3 else torch.bfloat16, device=x.device)
     a = _lib.SwinRowsArgs()
+    a.x3 = 1 if x3 else 0
     a.M, a.eps, a.mode, a.x, a.qkv = M, float(eps), 0, ptr(_c(x, 'x')), ptr(qkv)
     a.wstream, a.wave_stride = ptr(wstream), int(wave_stride)
     a.n1_g, a.n1_b, a.qkv_b = ptr(n1[0]), ptr(n1[1]), ptr(qkv_b)
@@ -532,19 +537,20 @@ def swin_rows_qkv(x, n1, qkv_b, wstream, wave_stride, qkv=None, eps=1e-5):
     return qkv
 
 
-def swin_rows_block(x, att, wstream, wave_stride, proj_b, n2, fc1_b, fc2_b, next_n1=None, next_qkv_b=None, qkv=None, eps=1e-5):
+def swin_rows_block(x, att, wstream, wave_stride, proj_b, n2, fc1_b, fc2_b, next_n1=None, next_qkv_b=None, qkv=None, eps=1e-5, x3=False):
     """x += att Wproj^T + bproj; x += fc2(GELU(fc1(LN(x; n2)))) in place on the fp32 residual stream [M, 512]; with next_n1 / next_qkv_b also
     the next block's qkv = bf16(LN(x; next_n1) Wqkv'^T + b') -> returned (else None).  omp_swin_rows_block mode 1."""
     if x.dtype != torch.float32 or x.shape[-1] != 512:
         raise TypeError('swin_rows_block takes the fp32 residual stream [M, 512]')
     M = x.numel() // 512
     a = _lib.SwinRowsArgs()
+    a.x3 = 1 if x3 else 0
     a.M, a.eps, a.mode, a.x, a.att = M, float(eps), 1, ptr(_c(x, 'x')), ptr(_c(att, 'att'))
     a.wstream, a.wave_stride = ptr(wstream), int(wave_stride)
     a.proj_b, a.n2_g, a.n2_b, a.fc1_b, a.fc2_b = ptr(proj_b), ptr(n2[0]), ptr(n2[1]), ptr(fc1_b), ptr(fc2_b)
     if next_n1 is not None:
         if qkv is None:
-            qkv = torch.empty((M, 1536), dtype=torch.bfloat16, device=x.device)
+            qkv = torch.empty((M, 1536), dtype=torch.float32 if x3 else torch.bfloat16, device=x.device)
         a.n1_g, a.n1_b, a.qkv_b, a.qkv = ptr(next_n1[0]), ptr(next_n1[1]), ptr(next_qkv_b), ptr(qkv)
     else:
         qkv = None

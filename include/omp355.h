@@ -158,6 +158,7 @@ typedef struct {
   int64_t wave_stride;
   const float *proj_b, *n2_g, *n2_b, *fc1_b, *fc2_b;   /* mode 1 */
   const float *n1_g, *n1_b, *qkv_b;                    /* the LayerNorm + qkv Linear behind the chain (mode 0: the chain itself) */
+  int32_t x3;                                          /* 1 = the parity engine's chain: att split pairs bf16 [M, 1024], qkv fp32 [M, 1536], split weight stream */
 } omp_swin_rows_args;
 int omp_swin_rows_block(const omp_swin_rows_args* a, omp_stream_t s);
 
@@ -337,7 +338,8 @@ typedef struct {
    * blocks of [hi plane | lo plane]); q and the attention output stay fp32 (with gemm_x3 the kernels write the out-projection's
    * pair rows themselves).  kv_img_stride then counts bf16 elements: nH * Mpad * 128. */
   int32_t kv_split;
-  /* rows_fused = 1 (dtype OMP_BF16, pre_norm, d_model 512, d_ff 2048, 8 heads; the host sets it for phases of thousands of rows): the
+  /* rows_fused = 1 (dtype OMP_BF16, or OMP_F32 with gemm_x3: the parity engine's chains over split operands; pre_norm, d_model 512, d_ff 2048,
+   * 8 heads; the host sets it for phases of thousands of rows): the
    * Linear layers of a step run as row-owner chains -- omp_dec_rows_ffn(embedding | q k v), then per layer self-attention,
    * omp_dec_rows_mid, cross-attention, omp_dec_rows_ffn -- 18 launches per step instead of 50; layers[l].rows_mid / rows_ffn and
    * rows_embed (layer 0's sa_in_w) are the packed streams (model/packing.py::pack_rows_*). */
@@ -424,6 +426,11 @@ typedef struct {
   const float *h0_b, *h1_b, *h2_b; /* tail 1 */
   float* logits;
   int32_t vocab;
+  /* x3 = 1: the PARITY engine's chains (csrc/dec_rows_x3.hip): every product as three bf16 matrix-core products of split operands.  att is then
+   * split pairs bf16 [R, 1024] = [hi | lo] (omp_split_bf16 / the split-plane cross-attention), q / qkv are fp32 [R, 512] / [R, 1536], and
+   * wstream carries per (k-step, feature tile) the fragment of w_hi then of w_lo (twice the fragments; model/packing.py, x3=True); a
+   * workgroup owns 48 rows. */
+  int32_t x3;
 } omp_dec_rows_args;
 int omp_dec_rows_mid(const omp_dec_rows_args* a, omp_stream_t s);
 int omp_dec_rows_ffn(const omp_dec_rows_args* a, omp_stream_t s);
