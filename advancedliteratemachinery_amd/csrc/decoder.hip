@@ -1790,7 +1790,7 @@ int check_plan(const omp_decoder_plan* P) {
 }
 
 int sample_and_advance(const omp_decoder_plan* P, hipStream_t st) {
-  if (P->R <= 4096 && omp_cur().dec_fused != 1) {
+  if (P->R <= 65536 && omp_cur().dec_fused != 1) {   // (round 5: also the 10 240-row phases -- the wave-per-row kernel walks 18 logits per lane one dependent round trip at a time: 27-127 us there)
     // a workgroup per row; the last one to finish publishes the next position (P->d_pos[1] is the ticket word)
     hipLaunchKernelGGL(dec_sample_block_kernel, dim3(P->R), dim3(256), 0, st, P->logits, P->vocab, P->R, P->sample, P->seq, P->probs,
                        P->seq_ld, P->finished, P->lengths, P->d_pos, P->d_pos + 1);

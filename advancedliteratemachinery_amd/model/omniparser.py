@@ -57,8 +57,10 @@ class OmniParser(nn.Module):
         self._engine_key = None
         self.use_graph = True          # decoder steps replay as hipGraphs when run on a non-default stream
         self.overlap_decoders = True   # polygon || recognition decoders on two streams
-        # images per encoder pass inside one engine call (see _encode_chunked); OMP355_ENC_CHUNK is the A/B knob of the sweep
-        self.enc_chunk = env_int('OMP355_ENC_CHUNK', 32, 1, 4096)
+        # images per encoder pass inside one engine call (see _encode_chunked); OMP355_ENC_CHUNK is the A/B knob of the sweep.  40 (round 5;
+        # 32 before): at 1024 x 1024 a chunk is then 2048 workgroups of the stage-2 chains = 8.0 rounds over the 256 compute units instead of
+        # 1639 = 6.4 (the partial last round was 8 % of the stage): encode 169.4 -> 164.1 ms per 160 images (profiles/r05n_enc_chunk_32_vs_40.txt)
+        self.enc_chunk = env_int('OMP355_ENC_CHUNK', 40, 1, 4096)
         self._streams = None
         self.phase_events = None       # set to [] to collect (name, torch.cuda.Event) marks per infer()
         self.eval()

@@ -804,7 +804,7 @@ def main():
                                     **(dict(traffic_over_algorithmic=rt_[1], traffic_scope=rt_[2]) if rt_ else {}))))
         if n_mlp:
             tf = f_mlp / (t_mlp / 1e3) / 1e12
-            recs.append((t_mlp, dict(bound='mfma', kernel='mlp_fused_kernel (Swin stages 0/1) + swin_rows_mlp_kernel (stage 2, round 5): LayerNorm + fc1 + GELU + fc2 + residual in one launch',
+            recs.append((t_mlp, dict(bound='mfma', kernel='mlp_fused_kernel (Swin stages 0/1: LayerNorm + fc1 + GELU + fc2 + residual) + dec_rows_ffn_kernel on Swin stage 2 (round 5: a block minus its window attention as one row-owner chain)',
                                      achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None,
                                      launches=int(n_mlp), avg_us=t_mlp / n_mlp * 1e3, flops_per_launch=f_mlp / n_mlp,
                                      alg_bytes_per_launch=b_mlp / n_mlp, frac_of_launch_rooflines=r_mlp / (t_mlp / 1e3),
@@ -975,6 +975,8 @@ def main():
         # the literal BASELINE config-2 batch (one engine call per 8 images) next to the coalesced headline, at top level
         rec['images_per_sec_coalesced'] = ips
         rec['images_per_sec_batch8'] = extra.get('batch8', {}).get('images_per_sec') if isinstance(extra.get('batch8'), dict) else None
+        # the engine that meets north_star's parity gate (logits <= 1e-3, ids identical) on the same workload, at top level beside the bf16 figure
+        rec['images_per_sec_parity_engine'] = extra.get('parity_engine', {}).get('images_per_sec') if isinstance(extra.get('parity_engine'), dict) else None
         if world > 1:
             rec['ranks'] = rank_diag
             rec['per_rank_ms_per_step'] = per_rank_ms

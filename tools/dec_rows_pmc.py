@@ -46,7 +46,7 @@ def alg_bytes(name, R):
 def classify(kname):
     if 'dec_rows_mid_kernel' in kname:
         return 'mid'
-    m = re.search(r'dec_rows_ffn_kernel<\d+, *(\d), *(\d)>|dec_rows_ffn_kernelILi\d+ELi(\d)ELi(\d)E', kname)
+    m = re.search(r'dec_rows_ffn_kernel<\d+, *(\d), *(\d)(?:, *\d)?>|dec_rows_ffn_kernelILi\d+ELi(\d)ELi(\d)E', kname)
     if m:
         pro, tail = (m.group(1), m.group(2)) if m.group(1) is not None else (m.group(3), m.group(4))
         return 'embed' if pro == '1' else ('qkv' if tail == '0' else 'head')
