@@ -80,6 +80,7 @@ struct omp_ctx {
   unsigned long long* gemm_trace = nullptr;   // device buffers of the TRACE instantiations
   long long gemm_trace_cap = 0;
   unsigned long long* mlp_trace = nullptr;
+  int rows_rtt = 0;          // decoder chains: 16-row tiles per workgroup, 0 = by row count (csrc/dec_rows.hip rows_rtt), 2..5 forced (omp_debug_rows_tile)
   OmpGraphSlot slots[OMP_MAX_GRAPH_SLOTS];
   int prof_mask = 0;
   OmpProfClass* prof = nullptr;   // [OMP_PROF_NCLASS], owned by the context (api.hip)

@@ -561,7 +561,23 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_ffn_kernel(RowsP p) {
   }
 }
 
-constexpr int RTT_DEFAULT = 5;   // 80 rows per workgroup: 10 240 rows = 128 workgroups, two decoder streams fill the chip side by side
+constexpr int RTT_DEFAULT = 5;   // 80 rows per workgroup: the Swin chains (thousands of workgroups per launch)
+
+// Rows per workgroup of a DECODER launch.  A workgroup streams the whole weight set whatever its rows (5.5 MB for the FFN chain: about
+// 50 us at the 110 GB/s a CU draws from L2) and runs 16 x RTT rows x 5.5 M parameters on its CU's matrix cores (18 us per 16 rows), so a
+// launch that leaves CUs idle is better cut finer -- but the polygon and the recognition decoder run side by side on two streams, a chain
+// workgroup takes its CU's LDS whole, and what one decoder does not occupy is where the other's HBM-bound attention kernels run.  Measured at
+// 10 240 rows (160 images x 64 instances; profiles/r05o_kbench_dec_rows_tiles.txt): the FFN chain alone 110 / 91 / 84 / 147 us at 80 / 64 /
+// 48 / 32 rows per workgroup (128 / 160 / 214 / 320 workgroups), the whole phase on ONE stream 125.6 / 122.2 / 119.5 / 137.7 ms, on the
+// engine's TWO streams 101.2 / 102.9 / 106.0 / 115.9 ms.  So: the smallest tile of {32, 48, 64, 80} rows that keeps a launch on half the chip
+// (10 240 rows: 80; 5 120 rows: 48).  omp_debug_rows_tile forces a tile (A/B, tests).
+int rows_rtt(int R) {
+  const int forced = omp_cur().rows_rtt;
+  if (forced >= 2 && forced <= 5) return forced;
+  for (int rtt = 2; rtt < 5; ++rtt)
+    if (((int64_t)R + 16 * rtt - 1) / (16 * rtt) <= 128) return rtt;
+  return 5;
+}
 
 template <typename K>
 int raise_lds(K kern, const char* what) {
@@ -572,9 +588,9 @@ int raise_lds(K kern, const char* what) {
   return OMP_OK;
 }
 
-template <int PRO, int TAIL, int ACT = 0>
-int launch_ffn(const RowsP& p, hipStream_t st) {
-  constexpr int RTT = RTT_DEFAULT, RT = RTT * 16;
+template <int RTT, int PRO, int TAIL, int ACT>
+int launch_ffn_t(const RowsP& p, hipStream_t st) {
+  constexpr int RT = RTT * 16;
   const size_t smem = (size_t)RT * A_PITCH + TILE_SLACK + RT * H_PITCH + TILE_SLACK + 2 * NW * RT * 4 + 4 * D * 4;
   auto kern = dec_rows_ffn_kernel<RTT, PRO, TAIL, ACT>;
   static bool done = false;   // per instantiation
@@ -585,6 +601,35 @@ int launch_ffn(const RowsP& p, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(((int64_t)p.R + RT - 1) / RT)), dim3(NW * 64), smem, st, p);
   OMP_CHECK_LAUNCH("omp_dec_rows_ffn");
+  return OMP_OK;
+}
+
+// the Swin chains (ACT 1): always 80 rows; the decoder chains (ACT 0): rows_rtt
+template <int PRO, int TAIL, int ACT = 0>
+int launch_ffn(const RowsP& p, hipStream_t st) {
+  if constexpr (ACT == 0) {
+    switch (rows_rtt(p.R)) {
+      case 2: return launch_ffn_t<2, PRO, TAIL, ACT>(p, st);
+      case 3: return launch_ffn_t<3, PRO, TAIL, ACT>(p, st);
+      case 4: return launch_ffn_t<4, PRO, TAIL, ACT>(p, st);
+      default: break;
+    }
+  }
+  return launch_ffn_t<RTT_DEFAULT, PRO, TAIL, ACT>(p, st);
+}
+
+template <int RTT>
+int launch_mid_t(const RowsP& p, hipStream_t st) {
+  constexpr int RT = RTT * 16;
+  const size_t smem = (size_t)RT * A_PITCH + TILE_SLACK + 2 * NW * RT * 4;
+  auto kern = dec_rows_mid_kernel<RTT>;
+  static bool done = false;
+  if (!done) {
+    const int rc = raise_lds(kern, "omp_dec_rows_mid");
+    if (rc != OMP_OK) return rc;
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(((int64_t)p.R + RT - 1) / RT)), dim3(NW * 64), smem, st, p);
   return OMP_OK;
 }
 
@@ -607,18 +652,16 @@ extern "C" int omp_dec_rows_mid(const omp_dec_rows_args* a, omp_stream_t s) {
   p.R = a->R; p.eps = a->eps; p.d_pos = a->d_pos; p.x = a->x; p.att = reinterpret_cast<const bf16_t*>(a->att);
   p.wstream = reinterpret_cast<const char*>(a->wstream); p.wave_stride = a->wave_stride;
   p.out_b = a->out_b; p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.qbias_tab = a->qbias_tab; p.q = reinterpret_cast<bf16_t*>(a->q);
-  constexpr int RTT = RTT_DEFAULT, RT = RTT * 16;
-  const size_t smem = (size_t)RT * A_PITCH + TILE_SLACK + 2 * NW * RT * 4;
-  auto kern = dec_rows_mid_kernel<RTT>;
-  static bool done = false;
-  if (!done) {
-    const int rc = raise_lds(kern, "omp_dec_rows_mid");
-    if (rc != OMP_OK) return rc;
-    done = true;
-  }
   const int slot = omp_prof_active(OMP_PROF_ROWS) ? omp_prof_begin(OMP_PROF_ROWS, (hipStream_t)s, 4.0 * (double)a->R * D * D, (double)a->R * D * (2 + 4 + 4 + 2) + 2.0 * D * D * 2) : -1;
-  hipLaunchKernelGGL(kern, dim3((p.R + RT - 1) / RT), dim3(NW * 64), smem, (hipStream_t)s, p);
+  int rc;
+  switch (rows_rtt(p.R)) {
+    case 2: rc = launch_mid_t<2>(p, (hipStream_t)s); break;
+    case 3: rc = launch_mid_t<3>(p, (hipStream_t)s); break;
+    case 4: rc = launch_mid_t<4>(p, (hipStream_t)s); break;
+    default: rc = launch_mid_t<5>(p, (hipStream_t)s); break;
+  }
   if (slot >= 0) omp_prof_end(OMP_PROF_ROWS, slot, (hipStream_t)s);
+  if (rc != OMP_OK) return rc;
   OMP_CHECK_LAUNCH("omp_dec_rows_mid");
   return OMP_OK;
 }
@@ -661,6 +704,12 @@ extern "C" int omp_dec_rows_ffn(const omp_dec_rows_args* a, omp_stream_t s) {
 }
 
 extern "C" int omp_dec_rows_tile(void) { return omp_rows_tile(); }
+
+extern "C" int omp_debug_rows_tile(int rtt) {   // 0 = by row count (rows_rtt), 2..5 = 16 x rtt rows per workgroup of every decoder chain launch
+  OMP_CHECK_ARG(rtt == 0 || (rtt >= 2 && rtt <= 5), "omp_debug_rows_tile: 0 (automatic) or 2..5 tiles of 16 rows (got %d)", rtt);
+  omp_cur().rows_rtt = rtt;
+  return OMP_OK;
+}
 
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -460,6 +460,12 @@ def cross_q4(on):
     _lib.check(_lib.lib().omp_debug_cross_q4(int(on)), 'omp_debug_cross_q4')
 
 
+def rows_tile(rtt):
+    """debug/testing: rows per workgroup of the decoder row-owner chains (bf16 engine) = 16 x rtt; 0 = chosen from the launch's row count
+    (csrc/dec_rows.hip rows_rtt), 2..5 forced."""
+    _lib.check(_lib.lib().omp_debug_rows_tile(int(rtt)), 'omp_debug_rows_tile')
+
+
 def dec_fused(mode):
     """debug/testing: 0 = fused few-row decoder step kernels where they apply (default), 1 = one launch per op everywhere."""
     _lib.check(_lib.lib().omp_debug_dec_fused(int(mode)), 'omp_debug_dec_fused')

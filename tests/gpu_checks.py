@@ -733,6 +733,22 @@ def check_dec_rows_x3():
     return check_dec_rows(x3=True)
 
 
+def check_dec_rows_tiles():
+    """The bf16 decoder chains at every workgroup tile csrc/dec_rows.hip instantiates (32 / 48 / 64 / 80 rows, omp_debug_rows_tile): R = 200
+    rows are 7 / 5 / 4 / 3 workgroups, the last one ragged each time (8 / 8 / 8 / 40 rows).  The default (0) picks 32 rows for 200."""
+    out = []
+    try:
+        for rtt in (3, 4, 5, 2):
+            ops.rows_tile(rtt)
+            for r in check_dec_rows():
+                r = dict(r)
+                r['name'] = '%s @ %d rows per workgroup' % (r['name'], 16 * rtt)
+                out.append(r)
+    finally:
+        ops.rows_tile(0)
+    return out
+
+
 def check_swin_rows_block(x3=False):
     """A Swin stage-2 block (C = 512) minus its window attention core as row-owner chains (omp_swin_rows_block, round 5): mode 0 (norm1 + qkv) and
     mode 1 (proj + residual, norm2, fc1 + GELU, fc2 + residual, with and without the next block's norm1 + qkv) against the CPU with bf16 rounding

@@ -377,9 +377,13 @@ def bench_dec_rows_fused():
              ('ffn  (out_proj + LN + FFN + LN + q k v)', 2.0 * R * d * (d + 8 * d + 3 * d), lambda: ops.dec_rows_ffn(x, s_qkv[0], s_qkv[1], dpos, g, b, bias_tab=tab3, qkv=qkv, **common)),
              ('ffn  (out_proj + LN + FFN + LN + head)', 2.0 * R * d * (d + 8 * d + 2 * d + V), lambda: ops.dec_rows_ffn(x, s_head[0], s_head[1], dpos, g, b, head_b=hb, logits=lg, vocab=V, **common)),
              ('embed (embedding + LN + LN + q k v)', 2.0 * R * d * 3 * d, lambda: ops.dec_rows_ffn(x, s_emb[0], s_emb[1], dpos, g, b, embed=(seq, word, ptab, g, b), bias_tab=tab3, qkv=qkv))]
-    for name, fl, fn in cases:
-        us = timeit(fn, iters=30, warm=3)
-        print('dec_rows[R=%d] %-42s : %7.1f us  %7.1f TF/s' % (R, name, us, fl / us / 1e6), flush=True)
+    tiles = [int(t) for t in os.environ.get('KBENCH_ROWS_TILES', '0,5,4,3,2').split(',')]
+    for tile in tiles:
+        ops.rows_tile(tile)
+        for name, fl, fn in cases:
+            us = timeit(fn, iters=30, warm=3)
+            print('dec_rows[R=%d, tile %s] %-42s : %7.1f us  %7.1f TF/s' % (R, '16 x %d' % tile if tile else 'auto', name, us, fl / us / 1e6), flush=True)
+    ops.rows_tile(0)
     # ---- (b) the phase as the engine runs it
     sys.path.insert(0, ROOT)
     import bench as B_
@@ -395,8 +399,11 @@ def bench_dec_rows_fused():
     dec.use_graph = True
     st = torch.cuda.Stream()
     sp, sr = torch.cuda.Stream(), torch.cuda.Stream()
-    for label, thr in (('row-owner chains', 1), ('launch per Linear', 1 << 30)):
+    for label, thr, tile in [('row-owner chains, tile %s' % ('16 x %d' % t if t else 'auto'), 1, t) for t in tiles] + [('launch per Linear', 1 << 30, 0)]:
         dec.rows_min = thr
+        ops.rows_tile(tile)
+        for ph in dec._phases.values():      # the graphs captured at another tile
+            ph.release_graphs()
         with torch.cuda.stream(st):
             for streams in ((sp, sr), None):
                 def fn():
@@ -409,8 +416,9 @@ def bench_dec_rows_fused():
                     fn()
                 b_.record()
                 torch.cuda.synchronize()
-                print('poly + rec phase, %d images x 64 rows, %-18s, %s : %8.2f ms per engine call'
+                print('poly + rec phase, %d images x 64 rows, %-32s, %s : %8.2f ms per engine call'
                       % (I, label, 'two streams' if streams else 'one stream ', a.elapsed_time(b_) / 3), flush=True)
+    ops.rows_tile(0)
 
 
 def bench_swin_rows():
