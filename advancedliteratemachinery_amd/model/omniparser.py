@@ -57,10 +57,9 @@ class OmniParser(nn.Module):
         self._engine_key = None
         self.use_graph = True          # decoder steps replay as hipGraphs when run on a non-default stream
         self.overlap_decoders = True   # polygon || recognition decoders on two streams
-        # images per encoder pass inside one engine call (see _encode_chunked); OMP355_ENC_CHUNK is the A/B knob of the sweep.  40 (round 5;
-        # 32 before): at 1024 x 1024 a chunk is then 2048 workgroups of the stage-2 chains = 8.0 rounds over the 256 compute units instead of
-        # 1639 = 6.4 (the partial last round was 8 % of the stage): encode 169.4 -> 164.1 ms per 160 images (profiles/r05n_enc_chunk_32_vs_40.txt)
-        self.enc_chunk = env_int('OMP355_ENC_CHUNK', 40, 1, 4096)
+        # images per encoder pass inside one engine call (see _encode_chunked); None = by engine (enc_chunk_default), OMP355_ENC_CHUNK is
+        # the A/B knob of the sweeps
+        self.enc_chunk = env_int('OMP355_ENC_CHUNK', 0, 0, 4096) or None
         self._streams = None
         self.phase_events = None       # set to [] to collect (name, torch.cuda.Event) marks per infer()
         self.eval()
@@ -158,12 +157,20 @@ class OmniParser(nn.Module):
                 return out
             return self._decode(dec, kv, prompt, poly_sos, rec_sos, sequence, forced_instances, B, dev, side, packed)
 
+    def enc_chunk_default(self):
+        """Images per encoder pass.  What matters at 1024 x 1024 is the last, partial round of the stage-2 chains over the 256 compute
+        units (18 of the 24 Swin blocks): a chunk of n images is n x 4096 / 80 workgroups of 80 rows (bf16) = n / 5 rounds, n x 4096 / 48 of
+        48 rows (parity engine) = n / 3 rounds.  bf16: 32 -> 40 images (6.4 -> 8.0 rounds) took the encoder from 169.4 to 164.1 ms per 160
+        images (profiles/r05n_enc_chunk_32_vs_40.txt), 80 (16.0 rounds, half the launches) to 160.9 (r05q); parity engine: 40 -> 54
+        (13.33 -> 18.0 rounds: 160 images are then 54 rounds instead of 56) 375.5 -> 372.0 ms (profiles/r05q_enc_chunk.txt)."""
+        return 54 if self.engine_dtype == 'bf16x3' else 80
+
     def _encode_chunked(self, enc, img, mask, no_padding=False):
         """The encoder gains nothing from more than a few images per launch (its kernels already fill the chip) while
         its activations grow with the batch; the decoders do gain (their steps are latency-bound).  So a large engine
         call is encoded `enc_chunk` images at a time; every chunk's input_proj writes its rows of the call's memory
         tensors directly (the first chunk's are copied once its shape is known)."""
-        B, ch = img.shape[0], max(1, int(self.enc_chunk))
+        B, ch = img.shape[0], max(1, int(self.enc_chunk or self.enc_chunk_default()))
         kw = dict(no_padding=True) if no_padding else {}
         if B <= ch:
             return enc.encode(img, mask, **kw)
