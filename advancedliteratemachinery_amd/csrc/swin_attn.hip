@@ -15,6 +15,7 @@
 // needs no cross-lane traffic; K and V of the window/head are staged once in LDS (fp32) and read
 // as wave-wide broadcasts (conflict-free ds_read_b128).
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -205,243 +206,331 @@ struct SwinTraits<float> {
 };
 
 // EXPB: the relative-position bias arrives EXPANDED per head as fp32 [64 queries][64 keys] (omp_swin_expand_bias: bias / scale,
-// -inf on the 15 padding key slots), so it seeds the S^T accumulators as 16-byte loads instead of 64 per-score table
-// lookups; the softmax then runs in base 2 (one v_exp_f32 per score) and the SW-MSA mask arithmetic is skipped for the
-// interior windows, whose tokens all sit in region 0.  (Round 1 measured this kernel at 0.29 of the HBM roofline with
-// ~2000 VALU / LDS instructions per (window, head); these three changes remove about half of them.)
-template <typename T, bool EXPB>
-__global__ __launch_bounds__(256, (EXPB && sizeof(T) == 2) ? 4 : 2) void swin_attn_mfma_kernel(const T* __restrict__ qkv,
+// -inf on the 15 padding key slots), so it seeds the S^T accumulators instead of 64 per-score table lookups; the softmax then runs
+// in base 2 (one v_exp_f32 per score) and the SW-MSA mask arithmetic is skipped for the interior windows, whose tokens all sit in
+// region 0.
+//
+// Round 5 -- what paces this kernel is neither bytes (0.37 of the HBM floor) nor VALU issue (a third fewer vector instructions bought
+// 3 %): wave 0's s_memtime stamps (TRACE, profiles/r05u_kbench_swin_attn_trace.txt) show 10 k of a (window, head)'s 25 k cycles passing
+// while its twelve q / k / v loads ISSUE -- the request rate of a CU's L1 towards L2, ~330 cache-line requests per (window, head).  So:
+//   * PERSISTENT waves: the launcher sizes grid.x to what is co-resident and a wave walks windows blockIdx.x, + gridDim.x, ... of ITS head,
+//     whose expanded bias tile (64 registers per lane) is fetched once -- it was 128 of the 330 requests;
+//   * ONE token per lane: lane t resolves window token min(t, 48) (row of qkv or -1: padding token; SW-MSA region), the (tile, lane) -> token
+//     lookups the loads and the mask need are ds_bpermute reads of that register instead of eight copies of the divide / wrap / bounds arithmetic;
+//   * padding tokens (q / k / v = bias: the last window row / column of an image whose size is not a multiple of 7 -- 19 of the 100 windows of
+//     a 64 x 64 map, 36 under SW-MSA) read token 0 and get the bias SELECTED in once everything is in flight; the substitution used to be a
+//     branch with its own loads behind each load, and the waits inside it made an edge window's twelve loads twelve serial round trips;
+//   * bf16 (PIPE): the NEXT window's loads are issued before this window is computed (two register sets, the loop unrolled by two), and two
+//     workgroups per CU instead of four: 195 -> 150 us per 131 072 tokens with the first three, -> see profiles/r05y_* with the prefetch.
+// TRACE (development, omp_debug_swin_mlp_trace): wave 0 of every workgroup writes s_memtime sums over its windows [workgroup][8]: 0 all of
+// 1..4, 1 token resolution + load issue (of the next window under PIPE), 2 until this window's q / k / v have landed and V^T sits in LDS,
+// 3 the four query tiles (S^T, softmax, PV, store), 5 = windows.
+template <typename T, bool EXPB, bool TRACE = false>
+__global__ __launch_bounds__(256, 2) void swin_attn_mfma_kernel(const T* __restrict__ qkv,
                                                               const float* __restrict__ qkv_bias,
                                                               const float* __restrict__ table,
                                                               T* __restrict__ out, int B, int H, int W, int C,
-                                                              int nH, int shift, int nWy, int nWx, int out_split) {
+                                                              int nH, int shift, int nWy, int nWx, int out_split,
+                                                              unsigned long long* __restrict__ trace = nullptr) {
   typedef Mma<T> MM;
   typedef SwinTraits<T> ST;
   typedef typename MM::frag frag;
   constexpr int NV = Vec16<T>::N;          // elements per 16-byte chunk (8 / 4)
   constexpr int VP = ST::VP;
+  constexpr int CPR = HD / NV;             // chunks per 32-dim row: 4 (bf16) / 8 (f32)
+  constexpr int KPI = 64 / CPR;            // keys per V iteration
+  constexpr int NIT = 64 / KPI;            // V iterations: 4 (bf16) / 8 (f32)
+  constexpr bool PIPE = EXPB && sizeof(T) == 2;   // fp32 operands: two register sets do not fit beside the bias tile
   __shared__ __attribute__((aligned(16))) T vt[4][HD * VP];   // per wave: V^T [32 dims][64 key slots (+pad)]
   __shared__ float tab[4][176];
+  __shared__ __attribute__((aligned(16))) T padb[4][2 * ST::QS + 1][64 * NV];   // per wave and lane: the q / k / v bias chunks a padding token takes
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int head = blockIdx.y * 4 + wave;
   if (head >= nH) return;                  // whole wave; no block-wide barrier below
-  int widx = blockIdx.x;
-  const int wx = widx % nWx; widx /= nWx;
-  const int wy = widx % nWy;
-  const int b = widx / nWy;
   const int Hp = nWy * WS, Wp = nWx * WS;
   const int C3 = 3 * C;
   T* vs = vt[wave];
+  const float scale = 0.17677669529663687f;  // 32^-0.5
+  const float scale2 = 0.17677669529663687f * 1.4426950408889634f;   // scale * log2(e): base-2 softmax (EXPB)
+  const T* qkv_head = qkv + head * HD;
+  auto from_lane = [](int v, int src) -> int { return __builtin_amdgcn_ds_bpermute(src << 2, v); };
 
-  // window-local token t (0..48) -> row of qkv (or -1: padding token, q/k/v = bias)
-  auto token_of = [&](int t, int& sy, int& sx) -> int64_t {
-    const int ty = (t * 37) >> 8, tx = t - ty * WS;   // t / 7 for t < 64
-    sy = wy * WS + ty; sx = wx * WS + tx;
-    int py = sy + shift, px = sx + shift;
-    if (py >= Hp) py -= Hp;
-    if (px >= Wp) px -= Wp;
-    return (py < H && px < W) ? ((int64_t)b * H + py) * W + px : (int64_t)-1;
-  };
-  // 16 bytes of q (sel 0) / k (1) / v (2) of token tok at head dims [d0, d0 + NV)
-  // Windows without padding tokens (all but the last window row / column of an image whose size is not a multiple of
-  // 7) take none of the bias-substitution code: the test is wave-uniform (the whole window is real or not).
-  const int sy_hi = wy * WS + WS - 1 + shift, sx_hi = wx * WS + WS - 1 + shift;
-  const bool all_real = (sy_hi < Hp ? sy_hi : Hp - 1) < H && (sx_hi < Wp ? sx_hi : Wp - 1) < W;
-  auto load_chunk = [&](int64_t tok, int sel, int d0) -> frag {
-    frag f = ld16<T>(qkv + (tok >= 0 ? tok : 0) * C3 + sel * C + head * HD + d0);
-    if (!all_real) {
-      if (tok < 0) {
-        float t[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) t[i] = qkv_bias[sel * C + head * HD + d0 + i];
-        pack16(t, f);
-      }
-    }
-    return f;
-  };
-
-  // ---- issue every global load first -------------------------------------------------------------
-  frag qf[4][ST::QS], kf[4][ST::QS];
-  int64_t qtok[4];
-  int qsy[4], qsx[4];
-#pragma unroll
-  for (int t4 = 0; t4 < 4; ++t4) {
-    int i = t4 * 16 + li; if (i > WT - 1) i = WT - 1;      // clamped rows are never stored / are masked
-    int sy, sx;
-    const int64_t tok = token_of(i, sy, sx);
-    qtok[t4] = (t4 * 16 + li < WT) ? tok : (int64_t)-1;
-    qsy[t4] = sy; qsx[t4] = sx;
-#pragma unroll
-    for (int s = 0; s < ST::QS; ++s) {
-      qf[t4][s] = load_chunk(tok, 0, s * MM::KSTEP + g * MM::KPL);
-      kf[t4][s] = load_chunk(tok, 1, s * MM::KSTEP + g * MM::KPL);
-    }
-  }
-  // V: lane (key = it*16 + lane/CPR, chunk = lane % CPR) -> 16-byte row pieces, coalesced per token
-  constexpr int CPR = HD / NV;             // chunks per 32-dim row: 4 (bf16) / 8 (f32)
-  constexpr int KPI = 64 / CPR;            // keys per iteration
-  frag vchunk[64 / KPI];
-#pragma unroll
-  for (int it = 0; it < 64 / KPI; ++it) {
-    const int j = it * KPI + lane / CPR, dc = lane % CPR;
-    int sy, sx;
-    if (j < WT) {
-      const int64_t tok = token_of(j, sy, sx);
-      vchunk[it] = load_chunk(tok, 2, dc * NV);
-    } else {
-      float z[NV];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) z[i] = 0.f;   // padded key slots must be finite: P = 0 there
-      pack16(z, vchunk[it]);
-    }
-  }
-  // expanded bias of query tile t4 (4 key tiles): requested one query tile ahead, 2 x 16 registers instead of 64
   const float* be = table + (int64_t)head * 4096 + li * 64 + g * 4;   // [query][key] of this head (EXPB)
-  f32x4 bnext[4];
+  f32x4 bias_all[4][4];   // [query tile][key tile]
   if constexpr (EXPB) {
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) bnext[kt] = *reinterpret_cast<const f32x4*>(be + kt * 16);
+    for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) bias_all[t4][kt] = *reinterpret_cast<const f32x4*>(be + t4 * 16 * 64 + kt * 16);
   } else {
     for (int idx = lane; idx < 169; idx += 64) tab[wave][idx] = table[idx * nH + head];
   }
 
-  // ---- V^T -> LDS -----------------------------------------------------------------------------------
+  // The bias chunks this lane substitutes for padding tokens, once per wave, parked in LDS: reading them back costs no vmcnt wait, so the
+  // substitution never drains the prefetched window's loads.
+  {
+    auto bias_chunk = [&](int sel, int d0) -> frag {
+      float t[NV];
 #pragma unroll
-  for (int it = 0; it < 64 / KPI; ++it) {
-    const int j = it * KPI + lane / CPR, dc = lane % CPR;
-    const int pos = ST::slot(j);
+      for (int i = 0; i < NV; ++i) t[i] = qkv_bias[sel * C + head * HD + d0 + i];
+      frag f;
+      pack16(t, f);
+      return f;
+    };
 #pragma unroll
-    for (int e = 0; e < NV; ++e) vs[(dc * NV + e) * VP + pos] = vchunk[it][e];
+    for (int s = 0; s < ST::QS; ++s) {
+      *reinterpret_cast<frag*>(&padb[wave][2 * s][lane * NV]) = bias_chunk(0, s * MM::KSTEP + g * MM::KPL);
+      *reinterpret_cast<frag*>(&padb[wave][2 * s + 1][lane * NV]) = bias_chunk(1, s * MM::KSTEP + g * MM::KPL);
+    }
+    *reinterpret_cast<frag*>(&padb[wave][2 * ST::QS][lane * NV]) = bias_chunk(2, (lane % CPR) * NV);
   }
 
-  // ---- S^T = K Q^T; the reference's q * scale (swin_transformer.py:130) is applied to the fp32 products ----
-  const float scale = 0.17677669529663687f;  // 32^-0.5
-  const float scale2 = 0.17677669529663687f * 1.4426950408889634f;   // scale * log2(e): base-2 softmax (EXPB)
-  // SW-MSA: only the last window row / column of the padded grid mixes regions (swin_transformer.py:369-387)
-  const bool edge = shift > 0 && (wy == nWy - 1 || wx == nWx - 1);
-  // per-lane key geometry: acc[r] of key tile kt is key j = kt*16 + 4g + r
-  int kty[16], ktx[16], krid[16];
-#pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = kt * 16 + g * 4 + r;
-      const int ty = (j * 37) >> 8, tx = j - ty * WS;
-      kty[kt * 4 + r] = ty; ktx[kt * 4 + r] = tx;
-      int rid = 0;
-      if (EXPB ? edge : shift > 0) {
-        const int ssy = wy * WS + ty, ssx = wx * WS + tx;
-        const int ry = ssy < Hp - WS ? 0 : (ssy < Hp - shift ? 1 : 2);
-        const int rx = ssx < Wp - WS ? 0 : (ssx < Wp - shift ? 1 : 2);
-        rid = ry * 3 + rx;
-      }
-      krid[kt * 4 + r] = rid;
+  // everything of a window that is in flight or pending between its load issue and its computation
+  struct Win {
+    frag qf[4][ST::QS], kf[4][ST::QS], vchunk[NIT];
+    int qtok[4];       // row of the lane's query of tile t4 (or -1: padding token / beyond the 49)
+    int my_rid;        // SW-MSA region of the token this LANE resolved
+    unsigned pad;      // bit t4: q / k of tile t4 belong to a padding token; bit 4 + it: v chunk it does
+    bool all_real, edge, masked;   // wave-uniform
+  };
+  unsigned long long t_sum[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+  unsigned long long t_last = 0ull;
+  auto lap = [&](int i, bool drain) {
+    if constexpr (TRACE) {
+      if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("" ::: "memory");
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      t_sum[i] += t - t_last;
+      t_last = t;
     }
+  };
 
-  f32x4 oacc[2][4];   // [dim tile][query tile]
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) oacc[dt][t4] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's V^T and table stores have landed (own data only)
-#pragma unroll
-  for (int t4 = 0; t4 < 4; ++t4) {
-    // geometry of this lane's query of tile t4
-    const int i = t4 * 16 + li;
-    const int ity = (i * 37) >> 8, itx = i - ity * WS;
-    int rid_i = 0;
-    if (EXPB ? edge : shift > 0) {
-      const int ry = qsy[t4] < Hp - WS ? 0 : (qsy[t4] < Hp - shift ? 1 : 2);
-      const int rx = qsx[t4] < Wp - WS ? 0 : (qsx[t4] < Wp - shift ? 1 : 2);
-      rid_i = ry * 3 + rx;
-    }
-    float sc[16];
-    float mx = -INFINITY;
-    f32x4 bcur[4];
-    if constexpr (EXPB) {
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) bcur[kt] = bnext[kt];
-      if (t4 < 3) {
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) bnext[kt] = *reinterpret_cast<const f32x4*>(be + (t4 + 1) * 16 * 64 + kt * 16);
+  // ---- token resolution + every global load of window wcur ----------------------------------------
+  auto issue = [&](int wcur, Win& w) {
+    int widx = wcur;
+    const int wx = widx % nWx; widx /= nWx;
+    const int wy = widx % nWy;
+    const int b = widx / nWy;
+    // SW-MSA: only the last window row / column of the padded grid mixes regions (swin_transformer.py:369-387)
+    w.edge = shift > 0 && (wy == nWy - 1 || wx == nWx - 1);
+    w.masked = EXPB ? w.edge : shift > 0;
+    const int sy_hi = wy * WS + WS - 1 + shift, sx_hi = wx * WS + WS - 1 + shift;
+    w.all_real = (sy_hi < Hp ? sy_hi : Hp - 1) < H && (sx_hi < Wp ? sx_hi : Wp - 1) < W;
+    int my_tok;
+    w.my_rid = 0;
+    {
+      const int t = lane < WT ? lane : WT - 1;
+      const int ty = (t * 37) >> 8, tx = t - ty * WS;   // t / 7 for t < 64
+      const int sy = wy * WS + ty, sx = wx * WS + tx;
+      int py = sy + shift, px = sx + shift;
+      if (py >= Hp) py -= Hp;
+      if (px >= Wp) px -= Wp;
+      my_tok = (py < H && px < W) ? (b * H + py) * W + px : -1;   // token rows fit 32 bits (checked by the launcher)
+      if (w.masked) {
+        const int ry = sy < Hp - WS ? 0 : (sy < Hp - shift ? 1 : 2);
+        const int rx = sx < Wp - WS ? 0 : (sx < Wp - shift ? 1 : 2);
+        w.my_rid = ry * 3 + rx;
       }
     }
+    auto load_chunk = [&](int tok, int sel, int d0) -> frag {   // 16 bytes of q (sel 0) / k (1) / v (2) of token tok at head dims [d0, d0 + NV)
+      return ld16<T>(qkv_head + (uint64_t)(uint32_t)(tok >= 0 ? tok : 0) * (uint32_t)C3 + (sel * C + d0));
+    };
+    w.pad = 0u;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      f32x4 st = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (EXPB) st = bcur[kt];
+    for (int t4 = 0; t4 < 4; ++t4) {
+      int i = t4 * 16 + li; if (i > WT - 1) i = WT - 1;      // clamped rows are never stored / are masked
+      const int tok = from_lane(my_tok, i);
+      w.qtok[t4] = (t4 * 16 + li < WT) ? tok : -1;
+      w.pad |= tok < 0 ? (1u << t4) : 0u;
 #pragma unroll
-      for (int s = 0; s < ST::QS; ++s) MM::mma(st, kf[kt][s], qf[t4][s]);
+      for (int s = 0; s < ST::QS; ++s) {
+        w.qf[t4][s] = load_chunk(tok, 0, s * MM::KSTEP + g * MM::KPL);
+        w.kf[t4][s] = load_chunk(tok, 1, s * MM::KSTEP + g * MM::KPL);
+      }
+    }
+    // V: lane (key = it*KPI + lane/CPR, chunk = lane % CPR) -> 16-byte row pieces, coalesced per token
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = kt * 16 + g * 4 + r;
-        float a;
-        if constexpr (EXPB) {
-          a = st[r] * scale2;   // (q.k + bias / scale) * scale * log2 e; padding keys are -inf through the seed
-          if (edge && krid[kt * 4 + r] != rid_i) a += -100.0f * 1.4426950408889634f;
-        } else {
-          a = st[r] * scale;
-          if (j < WT && i < WT) {
-            a += tab[wave][(ity - kty[kt * 4 + r] + WS - 1) * (2 * WS - 1) + (itx - ktx[kt * 4 + r] + WS - 1)];
-            if (shift > 0 && krid[kt * 4 + r] != rid_i) a += -100.0f;
-          } else if (j >= WT) {
-            a = -INFINITY;
+    for (int it = 0; it < NIT; ++it) {
+      const int j = it * KPI + lane / CPR, dc = lane % CPR;
+      const int tok = from_lane(my_tok, j < WT ? j : WT - 1);   // every lane takes part in the permute
+      w.pad |= (j < WT && tok < 0) ? (16u << it) : 0u;
+      w.vchunk[it] = load_chunk(tok, 2, dc * NV);   // every lane loads (key slots >= 49 re-read token 48 and are zeroed in compute): no
+    }                                                // conditional load, so the count of loads in flight is the same on every path
+  };
+
+  // ---- S^T = K Q^T, softmax, O^T = V^T P, store -------------------------------------------------
+  auto compute = [&](Win& w) {
+    if (!w.all_real) {   // padding tokens: the lane's bias chunks (LDS) selected in
+#pragma unroll
+      for (int s = 0; s < ST::QS; ++s) {
+        const frag bq = *reinterpret_cast<const frag*>(&padb[wave][2 * s][lane * NV]);
+        const frag bk = *reinterpret_cast<const frag*>(&padb[wave][2 * s + 1][lane * NV]);
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          w.qf[t4][s] = (w.pad >> t4) & 1u ? bq : w.qf[t4][s];
+          w.kf[t4][s] = (w.pad >> t4) & 1u ? bk : w.kf[t4][s];
+        }
+      }
+      const frag bv = *reinterpret_cast<const frag*>(&padb[wave][2 * ST::QS][lane * NV]);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) w.vchunk[it] = (w.pad >> (4 + it)) & 1u ? bv : w.vchunk[it];
+    }
+    {   // key slots beyond the 49 tokens must be finite: P = 0 there (only the last V iteration holds any)
+      float z[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) z[i] = 0.f;
+      frag zf;
+      pack16(z, zf);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if ((it + 1) * KPI > WT) w.vchunk[it] = (it * KPI + lane / CPR < WT) ? w.vchunk[it] : zf;
+    }
+    // V^T -> LDS (the previous window's fragment reads are older LDS operations of this wave: in order)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int j = it * KPI + lane / CPR, dc = lane % CPR;
+      const int pos = ST::slot(j);
+#pragma unroll
+      for (int e = 0; e < NV; ++e) vs[(dc * NV + e) * VP + pos] = w.vchunk[it][e];
+    }
+    lap(2, true);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's V^T and table stores have landed (own data only)
+    // a query tile at a time, stored as soon as it is done: 8 accumulator registers live instead of 32 (the prefetched window needs the room)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // [dim tile]
+      // geometry of this lane's query of tile t4 (table variant)
+      const int i = t4 * 16 + li;
+      const int ic = i < WT ? i : WT - 1;
+      const int ity = (i * 37) >> 8, itx = i - ity * WS;
+      float sc[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EXPB) st = bias_all[t4][kt];
+#pragma unroll
+        for (int s = 0; s < ST::QS; ++s) MM::mma(st, w.kf[kt][s], w.qf[t4][s]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = kt * 16 + g * 4 + r;   // acc[r] of key tile kt is key j = kt*16 + 4g + r
+          float a;
+          if constexpr (EXPB) {
+            a = st[r] * scale2;   // (q.k + bias / scale) * scale * log2 e; padding keys are -inf through the seed
+          } else {
+            a = st[r] * scale;
+            if (j < WT && i < WT) {
+              const int jy = (j * 37) >> 8, jx = j - jy * WS;
+              a += tab[wave][(ity - jy + WS - 1) * (2 * WS - 1) + (itx - jx + WS - 1)];
+            } else if (j >= WT) {
+              a = -INFINITY;
+            }
+          }
+          sc[kt * 4 + r] = a;
+        }
+      }
+      if (w.masked) {   // wave-uniform: the SW-MSA mask costs the interior windows no instruction; regions by permute from the lanes that own the tokens
+        const int rid_i = from_lane(w.my_rid, ic);
+        const float m = EXPB ? -100.0f * 1.4426950408889634f : -100.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int j = (k >> 2) * 16 + g * 4 + (k & 3);
+          const int rid_j = from_lane(w.my_rid, j < WT ? j : WT - 1);
+          if (EXPB || (j < WT && i < WT)) sc[k] += rid_j != rid_i ? m : 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) mx = fmaxf(mx, sc[k]);
+      mx = quad_group_max(mx);
+      float l = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if constexpr (EXPB) sc[k] = __builtin_amdgcn_exp2f(sc[k] - mx);
+        else sc[k] = expf(sc[k] - mx);
+        l += sc[k];
+      }
+      l = quad_group_sum(l);
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sc[k] *= inv;
+      // O^T += V^T P : k-step ps covers keys [ps*KPS, +KPS)
+#pragma unroll
+      for (int ps = 0; ps < ST::PS; ++ps) {
+        const frag pf = ST::pfrag(sc + ps * (ST::KPS / 4), sc + ps * (ST::KPS / 4) + 4);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const frag vf = *reinterpret_cast<const frag*>(vs + (dt * 16 + li) * VP + ps * ST::KPS + g * MM::KPL);
+          MM::mma(oacc[dt], vf, pf);
+        }
+      }
+      // store: acc[r] <-> (dim = dt*16 + 4g + r, query = t4*16 + li)
+      if (w.qtok[t4] >= 0) {
+        T* dst = out + (uint64_t)(uint32_t)w.qtok[t4] * (uint32_t)C + (head * HD + g * 4);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const f32x4 o = oacc[dt];
+          if constexpr (sizeof(T) == 4) {
+            if (out_split) {   // fp32 engine with bf16x3 products: the proj GEMM reads split pairs [hi | lo] (OMP_BF16X2)
+              bf16_t* ds = reinterpret_cast<bf16_t*>(out) + (uint64_t)(uint32_t)w.qtok[t4] * (uint32_t)(2 * C) + (head * HD + g * 4 + dt * 16);
+              bf16x4 hi, lo;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)o[e]; lo[e] = (bf16_t)(o[e] - (float)hi[e]); }
+              *reinterpret_cast<bf16x4*>(ds) = hi;
+              *reinterpret_cast<bf16x4*>(ds + C) = lo;
+              continue;
+            }
+            *reinterpret_cast<f32x4*>(dst + dt * 16) = o;
+          } else {
+            bf16x4 ov = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+            *reinterpret_cast<bf16x4*>(dst + dt * 16) = ov;
           }
         }
-        sc[kt * 4 + r] = a;
-        mx = fmaxf(mx, a);
       }
     }
-    mx = quad_group_max(mx);
-    float l = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if constexpr (EXPB) sc[k] = __builtin_amdgcn_exp2f(sc[k] - mx);
-      else sc[k] = expf(sc[k] - mx);
-      l += sc[k];
+    lap(3, false);
+  };
+
+  const int nWin = B * nWy * nWx;
+  const int step = (int)gridDim.x;
+  int nwalked = 0;
+  if constexpr (TRACE) t_last = __builtin_amdgcn_s_memtime();
+  if constexpr (PIPE) {
+    // the next window's loads are issued UNCONDITIONALLY (the last one re-reads its own window): a conditional issue makes the number of
+    // loads in flight path-dependent and the compiler's waits fall back to vmcnt(0), which drains the prefetch
+    Win wa, wb;
+    int wcur = blockIdx.x;
+    if (wcur < nWin) issue(wcur, wa);
+    lap(1, false);
+    while (wcur < nWin) {
+      issue(wcur + step < nWin ? wcur + step : wcur, wb);
+      lap(1, false);
+      compute(wa);
+      ++nwalked;
+      wcur += step;
+      if (wcur >= nWin) break;
+      issue(wcur + step < nWin ? wcur + step : wcur, wa);
+      lap(1, false);
+      compute(wb);
+      ++nwalked;
+      wcur += step;
     }
-    l = quad_group_sum(l);
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) sc[k] *= inv;
-    // O^T += V^T P : k-step ps covers keys [ps*KPS, +KPS)
-#pragma unroll
-    for (int ps = 0; ps < ST::PS; ++ps) {
-      const frag pf = ST::pfrag(sc + ps * (ST::KPS / 4), sc + ps * (ST::KPS / 4) + 4);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const frag vf = *reinterpret_cast<const frag*>(vs + (dt * 16 + li) * VP + ps * ST::KPS + g * MM::KPL);
-        MM::mma(oacc[dt][t4], vf, pf);
-      }
+  } else {
+    for (int wcur = blockIdx.x; wcur < nWin; wcur += step) {
+      Win w;
+      issue(wcur, w);
+      lap(1, false);
+      compute(w);
+      ++nwalked;
     }
   }
-
-  // ---- store: acc[r] <-> (dim = dt*16 + 4g + r, query = t4*16 + li) -----------------------------------
+  if constexpr (TRACE) {
+    if (wave == 0 && lane == 0 && trace != nullptr) {
+      unsigned long long* tr = trace + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 8;
+      tr[0] = t_sum[1] + t_sum[2] + t_sum[3] + t_sum[4];
 #pragma unroll
-  for (int t4 = 0; t4 < 4; ++t4) {
-    if (qtok[t4] >= 0) {
-      T* dst = out + qtok[t4] * C + head * HD + g * 4;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const f32x4 o = oacc[dt][t4];
-        if constexpr (sizeof(T) == 4) {
-          if (out_split) {   // fp32 engine with bf16x3 products: the proj GEMM reads split pairs [hi | lo] (OMP_BF16X2)
-            bf16_t* ds = reinterpret_cast<bf16_t*>(out) + qtok[t4] * 2 * C + head * HD + g * 4 + dt * 16;
-            bf16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)o[e]; lo[e] = (bf16_t)(o[e] - (float)hi[e]); }
-            *reinterpret_cast<bf16x4*>(ds) = hi;
-            *reinterpret_cast<bf16x4*>(ds + C) = lo;
-            continue;
-          }
-          *reinterpret_cast<f32x4*>(dst + dt * 16) = o;
-        } else {
-          bf16x4 ov = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
-          *reinterpret_cast<bf16x4*>(dst + dt * 16) = ov;
-        }
-      }
+      for (int i = 1; i < 5; ++i) tr[i] = t_sum[i];
+      tr[5] = (unsigned long long)nwalked;
     }
   }
 }
@@ -468,185 +557,199 @@ __global__ __launch_bounds__(256, 2) void swin_attn_x3_kernel(const float* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int head = blockIdx.y * 4 + wave;
   if (head >= nH) return;
-  int widx = blockIdx.x;
-  const int wx = widx % nWx; widx /= nWx;
-  const int wy = widx % nWy;
-  const int b = widx / nWy;
   const int Hp = nWy * WS, Wp = nWx * WS;
   const int C3 = 3 * C;
   bf16_t* vh = vt[wave][0];
   bf16_t* vl = vt[wave][1];
-
-  auto token_of = [&](int t, int& sy, int& sx) -> int64_t {
-    const int ty = (t * 37) >> 8, tx = t - ty * WS;
-    sy = wy * WS + ty; sx = wx * WS + tx;
-    int py = sy + shift, px = sx + shift;
-    if (py >= Hp) py -= Hp;
-    if (px >= Wp) px -= Wp;
-    return (py < H && px < W) ? ((int64_t)b * H + py) * W + px : (int64_t)-1;
-  };
-  const int sy_hi = wy * WS + WS - 1 + shift, sx_hi = wx * WS + WS - 1 + shift;
-  const bool all_real = (sy_hi < Hp ? sy_hi : Hp - 1) < H && (sx_hi < Wp ? sx_hi : Wp - 1) < W;
-  // 8 fp32 values of q (sel 0) / k (1) / v (2) of token tok at head dims [d0, d0 + 8)
-  auto load8 = [&](int64_t tok, int sel, int d0, float* v) {
-    const float* src = qkv + (tok >= 0 ? tok : 0) * C3 + sel * C + head * HD + d0;
-    unpack16(ld16<float>(src), v);
-    unpack16(ld16<float>(src + 4), v + 4);
-    if (!all_real) {
-      if (tok < 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = qkv_bias[sel * C + head * HD + d0 + i];
-      }
-    }
-  };
+  const float scale2 = 0.17677669529663687f * 1.4426950408889634f;   // 32^-0.5 * log2(e): base-2 softmax
   auto split8 = [](const float* v, frag& hi, frag& lo) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { hi[i] = (bf16_t)v[i]; lo[i] = (bf16_t)(v[i] - (float)hi[i]); }
   };
-
-  // ---- q / k fragments of the four 16-token tiles: lane (token li, dims 8 g .. 8 g + 7) ------------------------------
-  frag qh[4], ql[4], kh[4], kl[4];
-  int64_t qtok[4];
-  int qsy[4], qsx[4];
-#pragma unroll
-  for (int t4 = 0; t4 < 4; ++t4) {
-    int i = t4 * 16 + li; if (i > WT - 1) i = WT - 1;
-    int sy, sx;
-    const int64_t tok = token_of(i, sy, sx);
-    qtok[t4] = (t4 * 16 + li < WT) ? tok : (int64_t)-1;
-    qsy[t4] = sy; qsx[t4] = sx;
-    float t[8];
-    load8(tok, 0, g * 8, t);
-    split8(t, qh[t4], ql[t4]);
-    load8(tok, 1, g * 8, t);
-    split8(t, kh[t4], kl[t4]);
-  }
-  // ---- V^T -> LDS (both planes): lane (key = it * 16 + lane / 4, dims 8 (lane % 4) ..) ------------------------------
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int j = it * 16 + (lane >> 2), dc = lane & 3;
-    float t[8];
-    if (j < WT) {
-      int sy, sx;
-      load8(token_of(j, sy, sx), 2, dc * 8, t);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) t[i] = 0.f;   // padded key slots must be finite: P = 0 there
-    }
-    const int pos = ST::slot(j);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bf16_t hi = (bf16_t)t[e];
-      vh[(dc * 8 + e) * VP + pos] = hi;
-      vl[(dc * 8 + e) * VP + pos] = (bf16_t)(t[e] - (float)hi);
-    }
-  }
+  auto from_lane = [](int v, int src) -> int { return __builtin_amdgcn_ds_bpermute(src << 2, v); };
+  // persistent over windows, the head's expanded bias tile in registers, one token resolved per lane: as swin_attn_mfma_kernel (round 5)
   const float* be = bias_exp + (int64_t)head * 4096 + li * 64 + g * 4;   // [query][key] of this head
-  f32x4 bnext[4];
+  f32x4 bias_all[4][4];
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) bnext[kt] = *reinterpret_cast<const f32x4*>(be + kt * 16);
-
-  const float scale2 = 0.17677669529663687f * 1.4426950408889634f;   // 32^-0.5 * log2(e): base-2 softmax
-  const bool edge = shift > 0 && (wy == nWy - 1 || wx == nWx - 1);
-  int krid[16];
+  for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = kt * 16 + g * 4 + r;
-      const int ty = (j * 37) >> 8, tx = j - ty * WS;
-      int rid = 0;
+    for (int kt = 0; kt < 4; ++kt) bias_all[t4][kt] = *reinterpret_cast<const f32x4*>(be + t4 * 16 * 64 + kt * 16);
+  const float* qkv_head = qkv + head * HD;
+  const int nWin = B * nWy * nWx;
+  for (int wcur = blockIdx.x; wcur < nWin; wcur += gridDim.x) {
+    int widx = wcur;
+    const int wx = widx % nWx; widx /= nWx;
+    const int wy = widx % nWy;
+    const int b = widx / nWy;
+    const bool edge = shift > 0 && (wy == nWy - 1 || wx == nWx - 1);   // wave-uniform
+    int my_tok, my_rid = 0;
+    {
+      const int t = lane < WT ? lane : WT - 1;
+      const int ty = (t * 37) >> 8, tx = t - ty * WS;
+      const int sy = wy * WS + ty, sx = wx * WS + tx;
+      int py = sy + shift, px = sx + shift;
+      if (py >= Hp) py -= Hp;
+      if (px >= Wp) px -= Wp;
+      my_tok = (py < H && px < W) ? (b * H + py) * W + px : -1;
       if (edge) {
-        const int ssy = wy * WS + ty, ssx = wx * WS + tx;
-        const int ry = ssy < Hp - WS ? 0 : (ssy < Hp - shift ? 1 : 2);
-        const int rx = ssx < Wp - WS ? 0 : (ssx < Wp - shift ? 1 : 2);
-        rid = ry * 3 + rx;
-      }
-      krid[kt * 4 + r] = rid;
-    }
-
-  f32x4 oacc[2][4];
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) oacc[dt][t4] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's V^T stores have landed (own data only)
-#pragma unroll
-  for (int t4 = 0; t4 < 4; ++t4) {
-    int rid_i = 0;
-    if (edge) {
-      const int ry = qsy[t4] < Hp - WS ? 0 : (qsy[t4] < Hp - shift ? 1 : 2);
-      const int rx = qsx[t4] < Wp - WS ? 0 : (qsx[t4] < Wp - shift ? 1 : 2);
-      rid_i = ry * 3 + rx;
-    }
-    float sc[16];
-    float mx = -INFINITY;
-    f32x4 bcur[4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) bcur[kt] = bnext[kt];
-    if (t4 < 3) {
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) bnext[kt] = *reinterpret_cast<const f32x4*>(be + (t4 + 1) * 16 * 64 + kt * 16);
-    }
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      f32x4 st = bcur[kt];
-      MM::mma(st, kl[kt], qh[t4]);
-      MM::mma(st, kh[kt], ql[t4]);
-      MM::mma(st, kh[kt], qh[t4]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = st[r] * scale2;   // (q.k + bias / scale) * scale * log2 e; padding keys are -inf through the seed
-        if (edge && krid[kt * 4 + r] != rid_i) a += -100.0f * 1.4426950408889634f;
-        sc[kt * 4 + r] = a;
-        mx = fmaxf(mx, a);
+        const int ry = sy < Hp - WS ? 0 : (sy < Hp - shift ? 1 : 2);
+        const int rx = sx < Wp - WS ? 0 : (sx < Wp - shift ? 1 : 2);
+        my_rid = ry * 3 + rx;
       }
     }
-    mx = quad_group_max(mx);
-    float l = 0.f;
+    const int sy_hi = wy * WS + WS - 1 + shift, sx_hi = wx * WS + WS - 1 + shift;
+    const bool all_real = (sy_hi < Hp ? sy_hi : Hp - 1) < H && (sx_hi < Wp ? sx_hi : Wp - 1) < W;
+    // 8 fp32 values of q (sel 0) / k (1) / v (2) of token tok at head dims [d0, d0 + 8); padding tokens read token 0 and get the bias selected
+    // in once every load of the wave is in flight (no loads, hence no waits, inside a branch between the loads)
+    auto load8 = [&](int tok, int sel, int d0, float* v) {
+      const float* src = qkv_head + (uint64_t)(uint32_t)(tok >= 0 ? tok : 0) * (uint32_t)C3 + (sel * C + d0);
+      unpack16(ld16<float>(src), v);
+      unpack16(ld16<float>(src + 4), v + 4);
+    };
+
+    // ---- every global load of the wave first: q / k of the four 16-token tiles (lane: token li, dims 8 g .. 8 g + 7), v (lane: key it * 16 + lane / 4,
+    //      dims 8 (lane % 4) ..) ----------------------------------------------------------------------------------------
+    float qraw[4][8], kraw[4][8], vraw[4][8];
+    int qtok[4], qrid[4];
+    bool qpad[4], vpad[4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { sc[k] = __builtin_amdgcn_exp2f(sc[k] - mx); l += sc[k]; }
-    l = quad_group_sum(l);
-    const float inv = 1.0f / l;
+    for (int t4 = 0; t4 < 4; ++t4) {
+      int i = t4 * 16 + li; if (i > WT - 1) i = WT - 1;
+      const int tok = from_lane(my_tok, i);
+      qtok[t4] = (t4 * 16 + li < WT) ? tok : -1;
+      qpad[t4] = tok < 0;
+      qrid[t4] = 0;
+      if (edge) qrid[t4] = from_lane(my_rid, i);
+      load8(tok, 0, g * 8, qraw[t4]);
+      load8(tok, 1, g * 8, kraw[t4]);
+    }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sc[k] *= inv;
+    for (int it = 0; it < 4; ++it) {
+      const int j = it * 16 + (lane >> 2), dc = lane & 3;
+      const int tok = from_lane(my_tok, j < WT ? j : WT - 1);
+      vpad[it] = j < WT && tok < 0;
+      if (j < WT) {
+        load8(tok, 2, dc * 8, vraw[it]);
+      } else {
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {   // 32 keys per step
-      frag ph, pl;
-      split8(sc + ps * 8, ph, pl);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const int off = (dt * 16 + li) * VP + ps * 32 + g * 8;
-        const frag vfh = *reinterpret_cast<const frag*>(vh + off);
-        const frag vfl = *reinterpret_cast<const frag*>(vl + off);
-        MM::mma(oacc[dt][t4], vfl, ph);
-        MM::mma(oacc[dt][t4], vfh, pl);
-        MM::mma(oacc[dt][t4], vfh, ph);
+        for (int i = 0; i < 8; ++i) vraw[it][i] = 0.f;   // padded key slots must be finite: P = 0 there
       }
     }
-  }
+    if (!all_real) {
+      float bq[8], bk[8], bv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        bq[i] = qkv_bias[head * HD + g * 8 + i];
+        bk[i] = qkv_bias[C + head * HD + g * 8 + i];
+        bv[i] = qkv_bias[2 * C + head * HD + (lane & 3) * 8 + i];
+      }
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          qraw[t4][i] = qpad[t4] ? bq[i] : qraw[t4][i];
+          kraw[t4][i] = qpad[t4] ? bk[i] : kraw[t4][i];
+          vraw[t4][i] = vpad[t4] ? bv[i] : vraw[t4][i];
+        }
+    }
+    frag qh[4], ql[4], kh[4], kl[4];
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      split8(qraw[t4], qh[t4], ql[t4]);
+      split8(kraw[t4], kh[t4], kl[t4]);
+    }
+    // ---- V^T -> LDS (both planes) ---------------------------------------------------------------------------------------
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int j = it * 16 + (lane >> 2), dc = lane & 3;
+      const int pos = ST::slot(j);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bf16_t hi = (bf16_t)vraw[it][e];
+        vh[(dc * 8 + e) * VP + pos] = hi;
+        vl[(dc * 8 + e) * VP + pos] = (bf16_t)(vraw[it][e] - (float)hi);
+      }
+    }
+    int krid[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int j = (k >> 2) * 16 + g * 4 + (k & 3);   // acc[r] of key tile kt is key kt * 16 + 4 g + r
+      krid[k] = 0;
+      if (edge) krid[k] = from_lane(my_rid, j < WT ? j : WT - 1);
+    }
 
-  // ---- store: acc[r] <-> (dim = dt*16 + 4g + r, query = t4*16 + li) -----------------------------------
+    f32x4 oacc[2][4];
 #pragma unroll
-  for (int t4 = 0; t4 < 4; ++t4) {
-    if (qtok[t4] >= 0) {
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const f32x4 o = oacc[dt][t4];
-        if (out_split) {
-          bf16_t* ds = reinterpret_cast<bf16_t*>(out) + qtok[t4] * 2 * C + head * HD + g * 4 + dt * 16;
-          bf16x4 hi, lo;
+      for (int t4 = 0; t4 < 4; ++t4) oacc[dt][t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's V^T stores have landed (own data only)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)o[e]; lo[e] = (bf16_t)(o[e] - (float)hi[e]); }
-          *reinterpret_cast<bf16x4*>(ds) = hi;
-          *reinterpret_cast<bf16x4*>(ds + C) = lo;
-        } else {
-          *reinterpret_cast<f32x4*>(out + qtok[t4] * C + head * HD + g * 4 + dt * 16) = o;
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const int rid_i = qrid[t4];
+      float sc[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 st = bias_all[t4][kt];
+        MM::mma(st, kl[kt], qh[t4]);
+        MM::mma(st, kh[kt], ql[t4]);
+        MM::mma(st, kh[kt], qh[t4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[kt * 4 + r] = st[r] * scale2;   // (q.k + bias / scale) * scale * log2 e; padding keys are -inf through the seed
+      }
+      if (edge) {   // wave-uniform: the SW-MSA mask costs the interior windows no instruction
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sc[k] += krid[k] != rid_i ? -100.0f * 1.4426950408889634f : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) mx = fmaxf(mx, sc[k]);
+      mx = quad_group_max(mx);
+      float l = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { sc[k] = __builtin_amdgcn_exp2f(sc[k] - mx); l += sc[k]; }
+      l = quad_group_sum(l);
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sc[k] *= inv;
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {   // 32 keys per step
+        frag ph, pl;
+        split8(sc + ps * 8, ph, pl);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int off = (dt * 16 + li) * VP + ps * 32 + g * 8;
+          const frag vfh = *reinterpret_cast<const frag*>(vh + off);
+          const frag vfl = *reinterpret_cast<const frag*>(vl + off);
+          MM::mma(oacc[dt][t4], vfl, ph);
+          MM::mma(oacc[dt][t4], vfh, pl);
+          MM::mma(oacc[dt][t4], vfh, ph);
         }
       }
     }
-  }
+
+    // ---- store: acc[r] <-> (dim = dt*16 + 4g + r, query = t4*16 + li) -----------------------------------
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      if (qtok[t4] >= 0) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const f32x4 o = oacc[dt][t4];
+          if (out_split) {
+            bf16_t* ds = reinterpret_cast<bf16_t*>(out) + (uint64_t)(uint32_t)qtok[t4] * (uint32_t)(2 * C) + (head * HD + g * 4 + dt * 16);
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)o[e]; lo[e] = (bf16_t)(o[e] - (float)hi[e]); }
+            *reinterpret_cast<bf16x4*>(ds) = hi;
+            *reinterpret_cast<bf16x4*>(ds + C) = lo;
+          } else {
+            *reinterpret_cast<f32x4*>(out + (uint64_t)(uint32_t)qtok[t4] * (uint32_t)C + (head * HD + g * 4 + dt * 16)) = o;
+          }
+        }
+      }
+    }
+  }   // windows of this wave
 }
 
 // relative_position_bias_table [169, nH] -> per head [64 queries][64 keys] fp32: bias[(dy + 6) * 13 + (dx + 6)] / scale for
@@ -674,6 +777,20 @@ extern "C" int omp_swin_expand_bias(const float* rel_bias_table, int nH, float* 
   return OMP_OK;
 }
 
+namespace {
+int device_cus() {   // compute units of the current device (cached per device)
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cus[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+}  // namespace
+
 extern "C" int omp_swin_window_attn(const void* qkv, const float* qkv_bias, const float* rel_bias_table,
                                     void* out, int dtype, int B, int H, int W, int C, int nH, int window,
                                     int shift, omp_stream_t s) {
@@ -693,9 +810,17 @@ extern "C" int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, con
   OMP_CHECK_ARG(nH > 0 && C == nH * HD, "omp_swin_window_attn: head_dim must be 32 (C=%d nH=%d)", C, nH);
   OMP_CHECK_ARG(B > 0 && H > 0 && W > 0, "omp_swin_window_attn: bad shape");
   const int nWy = (H + WS - 1) / WS, nWx = (W + WS - 1) / WS;
+  OMP_CHECK_ARG((int64_t)B * nWy * nWx < (1ll << 31) && (int64_t)B * H * W < (1ll << 31), "omp_swin_window_attn: more than 2^31 windows / tokens");
   dim3 grid((unsigned)((int64_t)B * nWy * nWx), (unsigned)((nH + 3) / 4));
   if (dtype != OMP_F32 && dtype != OMP_BF16) { omp_set_error("omp_swin_window_attn: bad dtype %d", dtype); return OMP_ERR_INVALID; }
   const int swin_impl = omp_cur().swin_impl;
+  // swin_attn_mfma_kernel / swin_attn_x3_kernel walk windows: as many workgroups as are co-resident (two per CU: their launch bounds)
+  dim3 pgrid = grid;
+  {
+    const int per_cu = 2;
+    const int64_t co = (int64_t)device_cus() * per_cu / grid.y;
+    if (co >= 1 && co < (int64_t)grid.x) pgrid.x = (unsigned)co;
+  }
   if (swin_impl == 1) {
     if (dtype == OMP_F32)
       hipLaunchKernelGGL((swin_attn_kernel<float>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv,
@@ -710,15 +835,17 @@ extern "C" int omp_swin_window_attn2(const void* qkv, const float* qkv_bias, con
     if (dtype == OMP_F32 && expb && out_split && swin_impl != 3) {
       // the parity engine's call (fp32 qkv from a bf16x3 product, split-pair rows for the next one): three bf16 MFMAs per product
       // instead of fp32 ones (swin_attn_x3_kernel); selector 3 keeps the fp32 matrix-core kernel for A/B
-      hipLaunchKernelGGL(swin_attn_x3_kernel, grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, 1);
+      hipLaunchKernelGGL(swin_attn_x3_kernel, pgrid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, 1);
     } else if (dtype == OMP_F32 && expb && swin_impl == 4) {   // development: the same kernel with fp32 rows out (tests compare it with the reference)
-      hipLaunchKernelGGL(swin_attn_x3_kernel, grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, out_split);
+      hipLaunchKernelGGL(swin_attn_x3_kernel, pgrid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, out_split);
     } else if (dtype == OMP_F32) {
-      if (expb) hipLaunchKernelGGL((swin_attn_mfma_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, out_split);
-      else hipLaunchKernelGGL((swin_attn_mfma_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, out_split);
+      if (expb) hipLaunchKernelGGL((swin_attn_mfma_kernel<float, true>), pgrid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, out_split, (unsigned long long*)nullptr);
+      else hipLaunchKernelGGL((swin_attn_mfma_kernel<float, false>), pgrid, dim3(256), 0, (hipStream_t)s, (const float*)qkv, qkv_bias, tb, (float*)out, B, H, W, C, nH, shift, nWy, nWx, out_split, (unsigned long long*)nullptr);
     } else {
-      if (expb) hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t, true>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, qkv_bias, tb, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx, 0);
-      else hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, qkv_bias, tb, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx, 0);
+      unsigned long long* tr = omp_cur().mlp_trace;   // development: the traced instantiation writes [workgroup][8] phase cycles of wave 0
+      if (expb && tr != nullptr) hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t, true, true>), pgrid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, qkv_bias, tb, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx, 0, tr);
+      else if (expb) hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t, true>), pgrid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, qkv_bias, tb, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx, 0, (unsigned long long*)nullptr);
+      else hipLaunchKernelGGL((swin_attn_mfma_kernel<bf16_t, false>), pgrid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, qkv_bias, tb, (bf16_t*)out, B, H, W, C, nH, shift, nWy, nWx, 0, (unsigned long long*)nullptr);
     }
   }
   OMP_CHECK_LAUNCH("omp_swin_window_attn");

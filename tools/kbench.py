@@ -421,6 +421,39 @@ def bench_dec_rows_fused():
     ops.rows_tile(0)
 
 
+def bench_swin_attn_trace():
+    """round 5: the window attention kernel alone at a stage-2 chunk (C = 512, 16 heads, 64 x 64 tokens per image), W-MSA and SW-MSA, with the phase
+    cycles of wave 0 of every workgroup (omp_debug_swin_mlp_trace -> swin_attn_mfma_kernel<bf16, expanded bias, TRACE>)."""
+    bf = torch.bfloat16
+    C, nH = 512, 16
+    B = int(os.environ.get('KBENCH_SWIN_B', '32'))
+    H = W = 64
+    M = B * H * W
+    qkv = torch.randn(M, 3 * C, device=DEV).to(bf)
+    bqkv = torch.randn(3 * C, device=DEV) * 0.1
+    table = torch.randn(169, nH, device=DEV) * 0.2
+    bexp = ops.swin_expand_bias(table)
+    att = torch.empty(M, C, device=DEV, dtype=bf)
+    h = _lib.lib()
+    nW = (H + 6) // 7
+    names = ['whole window', 'token resolution + load issue of the NEXT window', 'own loads landed, V^T in LDS', 'four query tiles (S^T, softmax, PV, store)', '-']
+    for shift in (0, 3):
+        us = timeit(lambda: ops.swin_window_attn(qkv, bqkv, table, B, H, W, C, nH, shift, out=att, bias_expanded=bexp), iters=10, warm=2)
+        byt = M * C * 2 * 4
+        print('swin_attn[C=512, shift %d] %d tokens : %7.1f us  %6.2f TB/s (q, k, v in + o out)' % (shift, M, us, byt / us / 1e6), flush=True)
+        nwg = B * nW * nW * (nH // 4)
+        trace = torch.zeros(nwg, 8, dtype=torch.int64, device=DEV)
+        h.omp_debug_swin_mlp_trace(ops.ptr(trace))
+        ops.swin_window_attn(qkv, bqkv, table, B, H, W, C, nH, shift, out=att, bias_expanded=bexp)
+        torch.cuda.synchronize()
+        h.omp_debug_swin_mlp_trace(None)
+        t = trace.cpu().double()
+        t = t[t[:, 5] > 0]                      # the persistent grid writes one row per workgroup: sums over the windows it walked
+        nwin = t[:, 5].sum().item()
+        print('    %d workgroups x %.1f windows; per window (wave 0): ' % (t.shape[0], nwin / t.shape[0])
+              + ', '.join('%s %.0f' % (names[i], t[:, i].sum().item() / nwin) for i in range(4)) + ' cycles', flush=True)
+
+
 def bench_swin_rows():
     """round 5: a Swin stage-2 block (C = 512, 16 heads) at the encoder's chunk size (32 images of 1024 x 1024: 131 072 tokens): LayerNorm, qkv,
     window attention, proj, LayerNorm, fc1 + GELU, fc2 as seven launches vs window attention + ONE row-owner chain (omp_swin_rows_block)."""
@@ -553,6 +586,8 @@ if __name__ == '__main__':
         bench_dec_gemm()
     if 'swin_rows' in what:
         bench_swin_rows()
+    if 'swin_attn_trace' in what:
+        bench_swin_attn_trace()
     if 'dec_rows_fused' in what:
         bench_dec_rows_fused()
     if 'patch_embed' in what:
