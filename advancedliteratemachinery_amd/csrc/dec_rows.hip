@@ -571,10 +571,10 @@ constexpr int RTT_DEFAULT = 5;   // 80 rows per workgroup: the Swin chains (thou
 // 48 / 32 rows per workgroup (128 / 160 / 214 / 320 workgroups), the whole phase on ONE stream 125.6 / 122.2 / 119.5 / 137.7 ms, on the
 // engine's TWO streams 101.2 / 102.9 / 106.0 / 115.9 ms.  So: the smallest tile of {32, 48, 64, 80} rows that keeps a launch on half the chip
 // (10 240 rows: 80; 5 120 rows: 48).  omp_debug_rows_tile forces a tile (A/B, tests).
-int rows_rtt(int R) {
+int rows_rtt(int R, int lo = 2) {   // lo: the smallest tile the kernel is instantiated for (the mid chain also runs 16 rows: few-row phases)
   const int forced = omp_cur().rows_rtt;
   if (forced >= 2 && forced <= 5) return forced;
-  for (int rtt = 2; rtt < 5; ++rtt)
+  for (int rtt = lo; rtt < 5; ++rtt)
     if (((int64_t)R + 16 * rtt - 1) / (16 * rtt) <= 128) return rtt;
   return 5;
 }
@@ -654,7 +654,8 @@ extern "C" int omp_dec_rows_mid(const omp_dec_rows_args* a, omp_stream_t s) {
   p.out_b = a->out_b; p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.qbias_tab = a->qbias_tab; p.q = reinterpret_cast<bf16_t*>(a->q);
   const int slot = omp_prof_active(OMP_PROF_ROWS) ? omp_prof_begin(OMP_PROF_ROWS, (hipStream_t)s, 4.0 * (double)a->R * D * D, (double)a->R * D * (2 + 4 + 4 + 2) + 2.0 * D * D * 2) : -1;
   int rc;
-  switch (rows_rtt(p.R)) {
+  switch (rows_rtt(p.R, 1)) {
+    case 1: rc = launch_mid_t<1>(p, (hipStream_t)s); break;
     case 2: rc = launch_mid_t<2>(p, (hipStream_t)s); break;
     case 3: rc = launch_mid_t<3>(p, (hipStream_t)s); break;
     case 4: rc = launch_mid_t<4>(p, (hipStream_t)s); break;

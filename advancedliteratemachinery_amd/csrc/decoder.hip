@@ -1736,6 +1736,14 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
   cp.kmask = P->key_mask; cp.groups = P->tiles; cp.out = P->att; cp.ldo = d;
   cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R; cp.kpw = 0; cp.lo_off = 0;
   const int TC = P->kv_split ? OMP_BF16X2 : T;   // slab format the cross-attention kernels read (split planes: fp32 q / out)
+  // Phases between the fused few-row kernels (<= 63 rows) and the full chains (rows_fused): when the caller bound layers[].rows_mid, the three
+  // launches between self- and cross-attention -- 1 MB of weights, 23 us at 160 rows, bound by two launch boundaries -- are the mid chain on
+  // 16-row workgroups (the point decoder of a 160-image call: 10 workgroups stream the megabyte in 9 us).  The FFN half stays on launches: its
+  // 5.5 MB per workgroup would stream longer than the launches take.
+  bool mid_chain = !fused && omp_cur().dec_fused != 1 && T == OMP_BF16 && P->pre_norm && d == 512 && P->n_heads == 8 && !P->kv_split && R >= 16;
+  for (int li = 0; li < P->n_layers && mid_chain; ++li) mid_chain = P->layers[li].rows_mid != nullptr;
+  omp_dec_rows_args ma{};
+  ma.R = R; ma.eps = P->eps; ma.d_pos = P->d_pos; ma.x = P->x; ma.att = P->att; ma.q = P->q; ma.wave_stride = 128 * 1024;
   for (int li = 0; li < P->n_layers; ++li) {
     const omp_dec_layer& L = P->layers[li];
     cp.K = L.crossK; cp.V = L.crossVt;
@@ -1746,8 +1754,13 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
         RUN(ln_gemm(P, L.n1_g, L.n1_b, L.sa_in_w, 3 * d, L.sa_bias_tab, P->d_pos, 3 * d, P->qkv, T, OMP_ACT_NONE, st));
         RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, T, R, P->n_heads, d, P->Lmax, st));
       }
-      RUN(gemm(P, P->att, d, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
-      RUN(ln_gemm(P, L.n2_g, L.n2_b, L.ca_q_w, d, L.ca_qbias_tab, P->d_pos, d, P->q, T, OMP_ACT_NONE, st));
+      if (mid_chain) {   // out-projection + residual, norm2, cross-attention query: ONE launch (csrc/dec_rows.hip) instead of three
+        ma.wstream = L.rows_mid; ma.out_b = L.sa_out_b; ma.ln_g = L.n2_g; ma.ln_b = L.n2_b; ma.qbias_tab = L.ca_qbias_tab;
+        RUN(omp_dec_rows_mid(&ma, st));
+      } else {
+        RUN(gemm(P, P->att, d, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
+        RUN(ln_gemm(P, L.n2_g, L.n2_b, L.ca_q_w, d, L.ca_qbias_tab, P->d_pos, d, P->q, T, OMP_ACT_NONE, st));
+      }
       RUN(launch_cross(cp, P->n_tiles, TC, P->n_split, P->q_tiles, st));
       RUN(gemm(P, P->att, d, L.ca_out_w, d, d, L.ca_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
       RUN(ln_gemm(P, L.n3_g, L.n3_b, L.ff1_w, P->d_ff, L.ff1_b, nullptr, 0, P->ffh, T, OMP_ACT_RELU, st));

@@ -201,6 +201,9 @@ class Decoder(object):
     # bf16 engine: phases with at least this many rows run their Linear layers as row-owner chains (csrc/dec_rows.hip: 80 rows per
     # workgroup, weights streamed from L2): from ~50 workgroups on they beat the launch-per-Linear path (profiles/r05*_kbench_dec_rows*)
     ROWS_MIN_ROWS = env_int('OMP355_ROWS_MIN', 4096, 1, 1 << 30)
+    # from this many rows (the fused few-row kernels end at 63) the launch-per-Linear path runs its three launches between self- and
+    # cross-attention as the mid chain; OMP355_MID_MIN=1073741824 switches it off (A/B)
+    MID_MIN_ROWS = env_int('OMP355_MID_MIN', 64, 16, 1 << 30)
 
     def _rows_streams(self, kind):
         """Packed weight streams of decoder `kind` for the row-owner chains, built on first use (model/packing.py::pack_rows_*):
@@ -218,6 +221,17 @@ class Decoder(object):
                 per.append((mid, ffn))
             self._rows_cache[kind] = (embed, per)
         return self._rows_cache[kind]
+
+    def _rows_mid_streams(self, kind):
+        """Only the mid streams (sa_out_w, ca_q_w: 1 MB per layer) of decoder `kind`: the phases between the fused few-row kernels and the full
+        chains run the three launches between self- and cross-attention as the mid chain (csrc/decoder.hip step_launch)."""
+        key = ('mid', kind)
+        if key not in self._rows_cache:
+            if kind in self._rows_cache:
+                self._rows_cache[key] = [m for m, _ in self._rows_cache[kind][1]]
+            else:
+                self._rows_cache[key] = [packing.pack_rows_mid(w['sa_out_w'], w['ca_q_w'])[0] for w in self.layers[kind]]
+        return self._rows_cache[key]
 
     def _x3_weights(self, kind):
         """[out, 3 in] bf16 images of decoder `kind`'s matrices, built on first use (the fp32 masters stay bound for the
@@ -312,6 +326,10 @@ class Decoder(object):
             P.rows_embed = r_embed.data_ptr()
         else:
             P.rows_embed = None
+        # in between (more rows than the fused few-row kernels take, fewer than the chains want): the mid chain alone
+        use_mid = bool(not use_rows and self.dtype == torch.bfloat16 and not self.kv_split and a.tfm_pre_norm and self.MID_MIN_ROWS <= ph.R
+                       and d == 512 and self.nH == 8)
+        r_mid = self._rows_mid_streams(ph.kind) if use_mid else None
         x3_layers, x3_head = self._x3_weights(ph.kind) if use_x3 else (None, None)
         P.R, P.Lmax, P.M, P.Mpad, P.n_tiles, P.q_tiles, P.n_split, P.n_prompt = (ph.R, ph.Lmax, kv['M'], kv['Mpad'], len(tiles), qt,
                                                                                  ph.n_split, n_prompt)
@@ -328,7 +346,7 @@ class Decoder(object):
                          'ca_out_b', 'ff1_w', 'ff1_b', 'ff2_w', 'ff2_b', 'n1_g', 'n1_b', 'n2_g', 'n2_b', 'n3_g', 'n3_b'):
                 setattr(Lc, name, (x3_layers[l][name] if use_x3 and name in x3_layers[l] else w[name]).data_ptr())
             Lc.kcache, Lc.vcache = ph.kc[l].data_ptr(), ph.vc[l].data_ptr()
-            Lc.rows_mid, Lc.rows_ffn = (r_layers[l][0].data_ptr(), r_layers[l][1].data_ptr()) if use_rows else (None, None)
+            Lc.rows_mid, Lc.rows_ffn = (r_layers[l][0].data_ptr(), r_layers[l][1].data_ptr()) if use_rows else (r_mid[l].data_ptr() if use_mid else None, None)
             off = (kidx * self.L + l) * slab * esz
             Lc.crossK = kv['K'].data_ptr() + off
             Lc.crossVt = kv['Vt'].data_ptr() + off

@@ -323,7 +323,9 @@ typedef struct {
   const void* crossK;          /* this layer's K slab   [B][nH][Mpad][64] */
   const void* crossVt;         /* this layer's V^T slab [B][nH][Mpad/KB][64][KB] */
   /* row-owner chains (omp_decoder_plan.rows_fused, see omp_dec_rows_mid / omp_dec_rows_ffn): packed weight streams of this layer */
-  const void* rows_mid;        /* sa_out_w, ca_q_w */
+  const void* rows_mid;        /* sa_out_w, ca_q_w.  Bound on EVERY layer of a bf16 pre-norm plan WITHOUT rows_fused (d_model 512, 8 heads, more than 63 rows), it
+                                  makes the launch-per-Linear step run out-projection + residual, norm2 and the cross-attention query as ONE omp_dec_rows_mid
+                                  launch (16-row workgroups) instead of three; NULL: three launches */
   const void* rows_ffn;        /* ca_out_w, ff1_w / ff2_w in 16 chunks, then the NEXT layer's sa_in_w -- the last layer: h0_w, h1_w, h2_w */
 } omp_dec_layer;
 

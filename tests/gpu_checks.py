@@ -841,10 +841,13 @@ def check_decoder_rows(with_mask=True):
             try:
                 dec.rows_min = 1
                 lg = dec.teacher_forced_logits(kind, kv, seqs, counts, 3).cpu()
-                dec.rows_min = 1 << 30
+                dec.rows_min, dec.MID_MIN_ROWS = 1 << 30, 1 << 30      # one launch per Linear, without the mid chain either
                 lg0 = dec.teacher_forced_logits(kind, kv, seqs, counts, 3).cpu()
+                dec.MID_MIN_ROWS = type(dec).MID_MIN_ROWS              # ... and with it (phases of 64+ rows below the chains' threshold)
+                lgm = dec.teacher_forced_logits(kind, kv, seqs, counts, 3).cpu()
             finally:
                 dec.rows_min = keep
+                dec.MID_MIN_ROWS = type(dec).MID_MIN_ROWS
             worst, r0, scale = 0.0, 0, 0.0
             for b in range(B):
                 n = counts[b]
@@ -858,6 +861,18 @@ def check_decoder_rows(with_mask=True):
             out.append(rec(tag + ' vs oracle', worst, 0.6, 'max|logit|=%.2f' % scale))
             out.append(rec(tag + ' vs launch-per-op path', (lg - lg0).abs().max().item(), 0.35))
             out.append(rec(tag + ' the chains ran (result differs in the last bits)', 0.0 if not torch.equal(lg, lg0) else 1.0, 0.0))
+            # the mid chain alone inside the launch-per-Linear step (16-row workgroups: 165 / 94 rows are 11 / 6 of them, the last one ragged)
+            wm, r0 = 0.0, 0
+            for b in range(B):
+                n = counts[b]
+                mem_b = mem.reshape(B, M, d)[b].unsqueeze(1)
+                pos_b = mem_pos.reshape(B, M, d)[b].unsqueeze(1) - mem_b
+                ref = O.decode(sd, args, seqs[r0:r0 + n], mem_b, kmask[b:b + 1], pos_b, kind)
+                wm = max(wm, (lgm[r0:r0 + n] - ref).abs().max().item())
+                r0 += n
+            out.append(rec(tag + ' mid chain in the launch-per-Linear step vs oracle', wm, 0.6))
+            out.append(rec(tag + ' mid chain vs three launches', (lgm - lg0).abs().max().item(), 0.35))
+            out.append(rec(tag + ' the mid chain ran', 0.0 if not torch.equal(lgm, lg0) else 1.0, 0.0))
     return out
 
 
