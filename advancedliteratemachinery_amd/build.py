@@ -15,9 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libomp355.so')
-SOURCES = ['api.hip', 'gemm.hip', 'mlp.hip', 'norm.hip', 'swin_attn.hip', 'swin_block.hip', 'fpn.hip', 'decoder.hip', 'dec_rows.hip', 'dec_rows_x3.hip', 'vit.hip', 'preprocess.hip']
+SOURCES = ['api.hip', 'gemm.hip', 'mlp.hip', 'norm.hip', 'swin_attn.hip', 'swin_block.hip', 'fpn.hip', 'decoder.hip', 'dec_rows.hip', 'dec_rows_x3.hip', 'kv_rows.hip', 'vit.hip', 'preprocess.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'omp355_debug.h'), os.path.join(CSRC, 'gemm256.inc'), os.path.join(CSRC, 'gemm4w.inc'), os.path.join(CSRC, 'gemm4wr.inc'), os.path.join(CSRC, 'gemm4wp.inc'), os.path.join(CSRC, 'rows_common.inc'), os.path.join(os.path.dirname(HERE), 'include', 'omp355.h')]
-AUDITED = ('gemm.hip', 'dec_rows.hip', 'dec_rows_x3.hip')   # their device assembly stays next to the object: the audits read it
+AUDITED = ('gemm.hip', 'dec_rows.hip', 'dec_rows_x3.hip', 'kv_rows.hip')   # their device assembly stays next to the object: the audits read it
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 
@@ -105,7 +105,7 @@ def _audit():
         n, bad = audit.audit(asm)
         if bad or n == 0:
             raise RuntimeError('gemm_4w register audit failed (%d kernels):\n%s' % (n, '\n'.join(bad) or 'no gemm_4w kernel found in ' + asm))
-    for stem in ('dec_rows', 'dec_rows_x3'):
+    for stem in ('dec_rows', 'dec_rows_x3', 'kv_rows'):
         asm = os.path.join(OBJ, '%s-hip-amdgcn-amd-amdhsa-gfx950.s' % stem)
         if os.path.exists(asm):
             n, bad = audit.audit_dec_rows(asm)

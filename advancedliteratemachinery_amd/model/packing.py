@@ -149,6 +149,26 @@ def _same_kind(*ws):
     return ws[0].dtype == torch.float32
 
 
+def pack_kv_rows_k(wk_all):
+    """omp_kv_project_rows(vt = 0): the key projections of all (decoder, layer) slabs, [n_slabs * 512, 512] bf16 with rows ordered (slab, head,
+    dim).  Inside every head the 64 dims are permuted so that matrix-core row 4 g + r of feature tile ft is dim 16 g + 4 ft + r: the lane that
+    owns rows 4 g .. 4 g + 3 of the four tiles then holds dims 16 g .. 16 g + 15 of a key -- 32 contiguous bytes of the K slab row."""
+    if wk_all.dtype != torch.bfloat16 or wk_all.shape[0] % 512 or wk_all.shape[1] != 512:
+        raise ValueError('pack_kv_rows_k: [n_slabs * 512, 512] bf16')
+    j = torch.arange(64)
+    ft, row = j // 16, j % 16                       # position in the wave's stream: tile ft, matrix-core row
+    src = (row // 4) * 16 + ft * 4 + (row % 4)      # the dim that position computes
+    w = wk_all.reshape(-1, 64, 512)[:, src.to(wk_all.device)].reshape(-1, 512)
+    return _rows_finish(_rows_product(w))
+
+
+def pack_kv_rows_v(wv_all):
+    """omp_kv_project_rows(vt = 1): the value projections of all slabs, natural dim order (the operands are swapped: a lane owns one dim)."""
+    if wv_all.dtype != torch.bfloat16 or wv_all.shape[0] % 512 or wv_all.shape[1] != 512:
+        raise ValueError('pack_kv_rows_v: [n_slabs * 512, 512] bf16')
+    return _rows_finish(_rows_product(wv_all))
+
+
 def pack_rows_mid(sa_out_w, ca_q_w):
     """omp_dec_rows_mid: self_attn.out_proj [512, 512], then the query rows of multihead_attn.in_proj [512, 512]."""
     _same_kind(sa_out_w, ca_q_w)

@@ -194,6 +194,8 @@ class Decoder(object):
             self.Wv_all, self.bv_all = mat(torch.cat(wv, 0)), torch.cat(bv, 0).contiguous()
         self.NL = len(KINDS) * self.L
         self._rows_cache = {}   # kind -> packed weight streams of the row-owner chains (bf16 engine, many-row phases)
+        self._kv_streams = None  # packed Wk_all / Wv_all of the row-owner memory projection (bf16 engine, built on first use)
+        self.kv_rows = env_flag('OMP355_KV_ROWS', True)   # False: the two tiled GEMMs with slab epilogues (A/B)
         self.rows_min = self.ROWS_MIN_ROWS
         self._x3_cache = {}   # kind -> (layers, head) with every matrix as its [w_hi | w_hi | w_lo] image (bf16x3 engine, R > 64)
 
@@ -277,6 +279,14 @@ class Decoder(object):
                      M=B * M, N=self.Wk_all.shape[0], K=3 * d)
             ops.gemm(self.Wv_all, ops.split_bf16(memory, triple=True), self.bv_all, out=Vt_all, out_dtype=od, store_mode=_lib.STORE_VBLK, kv=geom,
                      bias_along_m=True, a_wrap=2 * d, M=self.Wv_all.shape[0], N=B * M, K=3 * d)
+            return dict(K=K_all, Vt=Vt_all, B=B, M=M, Mpad=Mpad, KB=KB, key_mask=key_mask)
+        if self.kv_rows and self.dtype == torch.bfloat16 and self.d == 512 and self.nH == 8 and M % 64 == 0:
+            # one row-owner launch per tensor (csrc/kv_rows.hip): 64 memory rows per workgroup, the weights of all slabs streamed; bit-identical slabs
+            if self._kv_streams is None:
+                self._kv_streams = (packing.pack_kv_rows_k(self.Wk_all), packing.pack_kv_rows_v(self.Wv_all))
+            (sk, nk), (sv, nv) = self._kv_streams
+            ops.kv_project_rows(mem_pos, sk, nk, self.bk_all, K_all, B, M, Mpad, self.NL, False)
+            ops.kv_project_rows(memory, sv, nv, self.bv_all, Vt_all, B, M, Mpad, self.NL, True)
             return dict(K=K_all, Vt=Vt_all, B=B, M=M, Mpad=Mpad, KB=KB, key_mask=key_mask)
         ops.gemm(mem_pos, self.Wk_all, self.bk_all, out=K_all, store_mode=_lib.STORE_KBLK, kv=geom)
         # swapped operands: rows = value features, columns = memory tokens, so a lane owns 4 consecutive keys

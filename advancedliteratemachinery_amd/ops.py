@@ -483,6 +483,17 @@ def swin_mlp_variant(v):
     _lib.check(_lib.lib().omp_debug_swin_mlp_variant(int(v)), 'omp_debug_swin_mlp_variant')
 
 
+def kv_project_rows(rows, wstream, wave_stride, bias, out, B, M, Mpad, n_slabs, vt):
+    """omp_kv_project_rows: the cross-attention memory projection of all (decoder, layer) slabs in one row-owner launch (csrc/kv_rows.hip).
+    rows [B * M, 512] bf16; wstream / wave_stride from model/packing.py::pack_kv_rows_k / _v; out: the K (vt False) or V^T (vt True) slab tensor."""
+    _c(rows, "rows"); _c(bias, "bias"); _c(out, "out")
+    if rows.dtype != torch.bfloat16 or out.dtype != torch.bfloat16 or rows.shape != (B * M, 512) or not rows.is_contiguous():
+        raise ValueError('kv_project_rows: [B * M, 512] contiguous bf16 rows and bf16 slabs')
+    _lib.check(_lib.lib().omp_kv_project_rows(ptr(rows), ptr(wstream), int(wave_stride), ptr(bias), ptr(out), int(B), int(M), int(Mpad), int(n_slabs),
+                                              1 if vt else 0, stream()), 'omp_kv_project_rows')
+    return out
+
+
 def dec_rows_mid(att, x, wstream, wave_stride, out_b, ln_g, ln_b, qbias_tab, d_pos, q=None, eps=1e-5, x3=False):
     """x += att Wo^T + bo;  q = bf16(LayerNorm(x) Wq^T + qbias_tab[*d_pos])  -- one launch, a workgroup owns 80 rows (include/omp355.h).
     x3: the parity engine's chain -- att as split pairs bf16 [R, 1024], q fp32, split weight stream, 48 rows per workgroup."""

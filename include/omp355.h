@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 18
+#define OMP_ABI_VERSION 19
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -437,6 +437,16 @@ typedef struct {
 int omp_dec_rows_mid(const omp_dec_rows_args* a, omp_stream_t s);
 int omp_dec_rows_ffn(const omp_dec_rows_args* a, omp_stream_t s);
 int omp_dec_rows_tile(void);   /* rows per workgroup (80) */
+
+/* Cross-attention memory projection as a row-owner stream kernel (csrc/kv_rows.hip, round 5) -- replaces, for bf16 engines with d_model 512,
+ * 8 heads and M % 64 == 0, the two omp_gemm_bias_act launches with OMP_STORE_KBLK / OMP_STORE_VBLK that computed what nn.MultiheadAttention
+ * recomputes per step and instance (model/transformer.py:88-96, 442-446).  rows: [B * M, 512] bf16 memory rows (memory + pos for K, memory
+ * for V^T); wstream: the [n_slabs * 512, 512] projection weights of all (decoder, layer) pairs as per-wave fragment streams
+ * (model/packing.py::pack_kv_rows_k -- dims permuted per head so that a lane stores 16 consecutive dims -- / pack_kv_rows_v), wave_stride
+ * bytes apart; bias [n_slabs * 512] fp32; out: the slab base, K [slab][B][8][Mpad][64] (vt = 0) or V^T [slab][B][8][Mpad / 32][64][32] in the
+ * key-slot order of OMP_STORE_VBLK (vt = 1).  The padded tail (keys >= M) is not written.  Bit-identical to the tiled GEMM path. */
+int omp_kv_project_rows(const void* rows, const void* wstream, int64_t wave_stride, const float* bias, void* out, int B, int M, int Mpad,
+                        int n_slabs, int vt, omp_stream_t s);
 
 /* ---- MGP-STR recogniser (reference: OCR/MGP-STR; BASELINE config 5) ------------------------------------
  * The ViT-B encoder reuses omp_layernorm / omp_gemm_bias_act / omp_dec_cross_attn_step (a ViT layer's k and v

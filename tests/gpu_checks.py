@@ -876,6 +876,49 @@ def check_decoder_rows(with_mask=True):
     return out
 
 
+def check_kv_rows():
+    """The cross-attention memory projection as ONE row-owner launch per tensor (omp_kv_project_rows, csrc/kv_rows.hip) against the two tiled GEMMs
+    with OMP_STORE_KBLK / OMP_STORE_VBLK epilogues it replaces: same matrix-core instruction, accumulation order and rounding points, so the K and
+    V^T slabs must be IDENTICAL bit for bit; and against the CPU product on probe entries.  3 images x 192 keys (9 workgroups of 64 rows) and
+    1 image x 4096 keys (the benchmark's memory)."""
+    dt = torch.bfloat16
+    out = []
+    args = make_args(tfm_pre_norm=True, use_fpn=True, use_char_window_prompt=True)
+    sd = weights.make_state_dict(args, seed=3, depths=(2, 2, 2, 2))
+    model = build_model(args, sd, (2, 2, 2, 2), dt)
+    _, dec = model.engine()
+    d = 512
+    for B, M in ((3, 192), (1, 4096)):
+        mem = q(rnd(B * M, d, seed=11), dt).to(DEV, dt)
+        mem_pos = q(rnd(B * M, d, seed=12), dt).to(DEV, dt)
+        res = {}
+        for on in (True, False):
+            dec.kv_rows = on
+            kv = dec.project_memory(mem, mem_pos, B, M, None)
+            torch.cuda.synchronize()
+            res[on] = (kv['K'].clone(), kv['Vt'].clone())
+            kv['K'].zero_()
+            kv['Vt'].zero_()
+        dec.kv_rows = True
+        tag = 'kv_rows[B=%d, M=%d]' % (B, M)
+        out.append(rec(tag + ' K slabs identical to the tiled GEMM path', 0.0 if torch.equal(res[True][0], res[False][0]) else (res[True][0].float() - res[False][0].float()).abs().max().item() + 1e-9, 0.0))
+        out.append(rec(tag + ' V^T slabs identical to the tiled GEMM path', 0.0 if torch.equal(res[True][1], res[False][1]) else (res[True][1].float() - res[False][1].float()).abs().max().item() + 1e-9, 0.0))
+        out.append(rec(tag + ' slabs are not empty', 0.0 if res[True][0].abs().sum().item() > 0 and res[True][1].abs().sum().item() > 0 else 1.0, 0.0))
+        # probe against the CPU: slab nl, image b, head h, key m
+        Wk, bk, Wv, bv = dec.Wk_all.float().cpu(), dec.bk_all.cpu(), dec.Wv_all.float().cpu(), dec.bv_all.cpu()
+        K, Vt = res[True][0].float().cpu(), res[True][1].float().cpu()
+        worst = 0.0
+        for (nl, b, h, m) in ((0, 0, 0, 0), (5, B - 1, 3, M - 1), (dec.NL - 1, B // 2, 7, M // 2 + 5)):
+            kr = mem_pos[b * M + m].float().cpu() @ Wk[nl * d + h * 64:nl * d + h * 64 + 64].T + bk[nl * d + h * 64:nl * d + h * 64 + 64]
+            vr = mem[b * M + m].float().cpu() @ Wv[nl * d + h * 64:nl * d + h * 64 + 64].T + bv[nl * d + h * 64:nl * d + h * 64 + 64]
+            kl = m % 32
+            pos = ((kl & 15) >> 2) * 8 + (kl >> 4) * 4 + (kl & 3)
+            worst = max(worst, (K[nl, b, h, m] - kr).abs().max().item() / max(kr.abs().max().item(), 1e-6),
+                        (Vt[nl, b, h, m // 32, :, pos] - vr).abs().max().item() / max(vr.abs().max().item(), 1e-6))
+        out.append(rec(tag + ' probe rows vs CPU product (relative)', worst, 8e-3))
+    return out
+
+
 def check_sampling_block():
     """greedy sampling inside omp_decoder_run (workgroup per row + fused position advance) == the stand-alone sampling entry point:
     covered end to end by the token-identity gates; here the free-running fp32 result with the fused kernels off and on."""

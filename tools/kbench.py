@@ -454,6 +454,26 @@ def bench_swin_attn_trace():
               + ', '.join('%s %.0f' % (names[i], t[:, i].sum().item() / nwin) for i in range(4)) + ' cycles', flush=True)
 
 
+def bench_kv_rows():
+    """round 5: the cross-attention memory projection of an engine call (KBENCH_KV_IMAGES images x 4096 memory tokens, 12 slabs): the two tiled GEMMs
+    with slab epilogues vs the row-owner stream kernel (omp_kv_project_rows)."""
+    sys.path.insert(0, ROOT)
+    import bench as B_
+    bf = torch.bfloat16
+    I = int(os.environ.get('KBENCH_KV_IMAGES', '160'))
+    M, d = 4096, 512
+    model, args, _ = B_.build_model('bf16', 1, torch.device(DEV))
+    _, dec = model.engine()
+    mem = torch.randn(I * M, d, device=DEV).to(bf)
+    mem_pos = torch.randn(I * M, d, device=DEV).to(bf)
+    fl = 2 * 2.0 * I * M * d * d * dec.NL
+    for on, label in ((False, 'two tiled GEMMs (OMP_STORE_KBLK / VBLK epilogues)'), (True, 'row-owner stream kernel, K + V^T launches')):
+        dec.kv_rows = on
+        us = timeit(lambda: dec.project_memory(mem, mem_pos, I, M, None), iters=5, warm=2)
+        print('kv_project[%d images x %d keys, %d slabs] %-52s : %8.1f us  %7.1f TF/s' % (I, M, dec.NL, label, us, fl / us / 1e6), flush=True)
+    dec.kv_rows = True
+
+
 def bench_swin_rows():
     """round 5: a Swin stage-2 block (C = 512, 16 heads) at the encoder's chunk size (32 images of 1024 x 1024: 131 072 tokens): LayerNorm, qkv,
     window attention, proj, LayerNorm, fc1 + GELU, fc2 as seven launches vs window attention + ONE row-owner chain (omp_swin_rows_block)."""
@@ -588,6 +608,8 @@ if __name__ == '__main__':
         bench_swin_rows()
     if 'swin_attn_trace' in what:
         bench_swin_attn_trace()
+    if 'kv_rows' in what:
+        bench_kv_rows()
     if 'dec_rows_fused' in what:
         bench_dec_rows_fused()
     if 'patch_embed' in what:
