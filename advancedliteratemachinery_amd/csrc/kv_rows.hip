@@ -11,7 +11,8 @@
 // fragment streams in consumption order (model/packing.py::pack_kv_rows_k / _v), the asm register ring of rows_common.inc.  Wave w owns the 64
 // features of HEAD w of every slab, and the two slab layouts fall out of the accumulators without a transpose:
 //   * K (A operand = weight fragment, D[feature][row]): the packer permutes a head's dims so that matrix-core row 4 g + r of feature tile ft
-//     is dim 16 g + 4 ft + r -- a lane then holds 16 CONSECUTIVE dims of one key: two 16-byte stores, four lanes complete the key's 128-byte row;
+//     is dim 32 (ft / 2) + 8 g + 4 (ft % 2) + r -- a lane then holds dims 8 g .. 8 g + 7 and 32 + 8 g .. of one key: two 16-byte stores, each of
+//     which four lanes make 64 contiguous bytes (a first version with 16 consecutive dims per lane wrote 16-byte pieces at a 32-byte stride);
 //   * V^T (operands swapped, D[row][feature]): a lane holds keys 4 g + r of a 16-key tile for ONE dim; the slot order of a 32-key block
 //     (slot 8 g + 4 half + r <- key 16 half + 4 g + r, the order the first cross-attention product delivers P) puts the two tiles of a block
 //     side by side: 8 consecutive slots = one 16-byte store, sixteen lanes x four g complete 16 dims x 64 bytes = 1 KB contiguous.
@@ -26,12 +27,13 @@ namespace {
 
 #include "rows_common.inc"
 
-// Weight fragments in flight per wave.  A slab's eight stores per lane enter the same vmcnt as the ring, and `s_waitcnt vmcnt(PF - 1)` cannot
-// be relaxed for them (loads return in order among themselves, stores in any order: with every store done and the oldest load not, exactly
-// PF ops are outstanding), so while stores drain they take ring slots; a ring of 16 measured the same 4.1 ms per launch as 8
-// (profiles/r05zd_kbench_kv_rows.txt): the launch is the sum of its weight stream (64 GB at the 29 TB/s the L2s deliver) and its 8 GB of stores.
+// Weight fragments in flight per wave.  MEASURED (160 images: 655 360 rows, profiles/r05zc-r05zg_kbench_kv_rows.txt): 4.0-4.1 ms per launch
+// = 1.0 PF, against 5.7-6.2 ms for the tiled GEMMs -- and the same 4.0-4.1 ms with a ring of 16, with 128 rows per workgroup (half the weight
+// bytes), with the K stores as 64-byte runs instead of 16-byte pieces, and with a slab's stores issued one per ring revolution under the NEXT
+// slab's product: none of the three suspects (weight stream, store pattern, stores behind the products) is what paces it.  A slab's stores
+// share vmcnt with the ring (`s_waitcnt vmcnt(PF - 1)` cannot be relaxed for them: loads return in order among themselves, stores in any
+// order), which is the next thing to measure with in-kernel timestamps.
 constexpr int PF = 8;
-constexpr int RTT = 4, RT = RTT * 16;  // 64 rows per workgroup: two 32-key blocks
 constexpr int A_PITCH = D * 2 + 32;    // operand tile row pitch, bytes (conflict-free b128 fragment reads, as csrc/dec_rows.hip)
 constexpr int TILE_SLACK = 64;         // the operand prefetch reads one k-step past the last row
 
@@ -44,6 +46,60 @@ struct KvP {
   int64_t rows;           // B * M
   int M, Mpad, B, n_slabs;
 };
+
+constexpr int RTT = 4, RT = RTT * 16;  // 64 rows per workgroup: two 32-key blocks
+constexpr int NP = 2 * RTT;            // 16-byte pieces per lane and slab
+
+// A slab's results of this lane, rounded and packed, and where they go.
+struct Pieces {
+  bf16x8 v[NP];
+  bf16_t* base;     // lane base of the slab
+};
+
+template <bool SWAP>
+__device__ __forceinline__ int64_t piece_offset(int i) {   // elements from Pieces::base, static per piece
+  if constexpr (!SWAP) return (int64_t)(i >> 1) * 16 * 64 + (i & 1) * 32;      // K: piece (rt, half): key tile rt, dims 8 g .. / 32 + 8 g ..
+  else return ((int64_t)(i & 1) * 64 + (i >> 1) * 16) * 32;                     // V^T: piece (ft, b): key block b, dims 16 ft + li
+}
+
+// acc (+ bias), rounded to bf16 and packed into the lane's NP pieces of slab nl
+template <bool SWAP>
+__device__ __forceinline__ void pack_slab(Pieces& pc, const f32x4 (&acc)[4][RTT], const KvP& p, int nl, int image, int key0, int wave, int li_, int g_) {
+  const int li = opaque(li_), g = opaque(g_);
+  const int64_t head = ((int64_t)nl * p.B + image) * NW + wave;   // (slab, image, head): 8 heads = the 8 waves
+  if constexpr (!SWAP) {
+    // lane: key rt * 16 + li, dims 32 (ft / 2) + 8 g + 4 (ft % 2) + r: tiles 0, 1 are dims 8 g .. 8 g + 7, tiles 2, 3 the same + 32
+    const float* bp = p.bias + nl * D + wave * 64 + g * 8;
+    f32x4 bb[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) bb[ft] = *reinterpret_cast<const f32x4*>(bp + (ft >> 1) * 32 + (ft & 1) * 4);
+    pc.base = p.out + (head * p.Mpad + key0 + li) * 64 + g * 8;
+#pragma unroll
+    for (int rt = 0; rt < RTT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pc.v[2 * rt][r] = (bf16_t)(acc[0][rt][r] + bb[0][r]);          // four lanes: 64 contiguous bytes of the key's row
+        pc.v[2 * rt][4 + r] = (bf16_t)(acc[1][rt][r] + bb[1][r]);
+        pc.v[2 * rt + 1][r] = (bf16_t)(acc[2][rt][r] + bb[2][r]);
+        pc.v[2 * rt + 1][4 + r] = (bf16_t)(acc[3][rt][r] + bb[3][r]);
+      }
+  } else {
+    // lane: keys rt * 16 + 4 g + r, dim 16 ft + li; tiles 2 b and 2 b + 1 are the halves of key block b
+    const float* bp = p.bias + nl * D + wave * 64 + li;
+    pc.base = p.out + ((head * (p.Mpad >> 5) + (key0 >> 5)) * 64 + li) * 32 + g * 8;
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const float bv = bp[ft * 16];
+#pragma unroll
+      for (int b = 0; b < RTT / 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pc.v[2 * ft + b][r] = (bf16_t)(acc[ft][2 * b][r] + bv);
+          pc.v[2 * ft + b][4 + r] = (bf16_t)(acc[ft][2 * b + 1][r] + bv);
+        }
+    }
+  }
+}
 
 // acc[ft][rt] += over K = 512 (16 k-steps); the wave's next 64 stream fragments, ordered (k-step, feature tile).  SWAP: the row fragment is the
 // A operand (D[row][feature]) -- the register contents of both fragments are the same either way.
@@ -73,50 +129,12 @@ __device__ __forceinline__ void gemm_pass_kv(f32x4 (&acc)[4][RTT], const char* a
   }
 }
 
-// one slab's 64 rows x 64 features of this wave -> HBM
 template <bool SWAP>
-__device__ __forceinline__ void store_slab(const f32x4 (&acc)[4][RTT], const KvP& p, int nl, int image, int key0, int wave, int li_, int g_) {
-  const int li = opaque(li_), g = opaque(g_);
-  const int64_t head = ((int64_t)nl * p.B + image) * NW + wave;   // (slab, image, head): 8 heads = the 8 waves
-  if constexpr (!SWAP) {
-    // lane: key rt * 16 + li, dims 16 g + 4 ft + r
-    const float* bp = p.bias + nl * D + wave * 64 + g * 16;
-    f32x4 bb[4];
+__device__ __forceinline__ void store_slab(const f32x4 (&acc)[4][RTT], const KvP& p, int nl, int image, int key0, int wave, int li, int g) {
+  Pieces pc;
+  pack_slab<SWAP>(pc, acc, p, nl, image, key0, wave, li, g);
 #pragma unroll
-    for (int ft = 0; ft < 4; ++ft) bb[ft] = *reinterpret_cast<const f32x4*>(bp + ft * 4);
-    bf16_t* kb = p.out + (head * p.Mpad + key0 + li) * 64 + g * 16;
-#pragma unroll
-    for (int rt = 0; rt < RTT; ++rt) {
-      bf16x8 lo, hi;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        lo[r] = (bf16_t)(acc[0][rt][r] + bb[0][r]);
-        lo[4 + r] = (bf16_t)(acc[1][rt][r] + bb[1][r]);
-        hi[r] = (bf16_t)(acc[2][rt][r] + bb[2][r]);
-        hi[4 + r] = (bf16_t)(acc[3][rt][r] + bb[3][r]);
-      }
-      *reinterpret_cast<bf16x8*>(kb + rt * 16 * 64) = lo;
-      *reinterpret_cast<bf16x8*>(kb + rt * 16 * 64 + 8) = hi;
-    }
-  } else {
-    // lane: keys rt * 16 + 4 g + r, dim 16 ft + li; tiles 2 b and 2 b + 1 are the halves of key block b
-    const float* bp = p.bias + nl * D + wave * 64 + li;
-    bf16_t* vb = p.out + ((head * (p.Mpad >> 5) + (key0 >> 5)) * 64 + li) * 32 + g * 8;
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
-      const float bv = bp[ft * 16];
-#pragma unroll
-      for (int b = 0; b < RTT / 2; ++b) {
-        bf16x8 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o[r] = (bf16_t)(acc[ft][2 * b][r] + bv);
-          o[4 + r] = (bf16_t)(acc[ft][2 * b + 1][r] + bv);
-        }
-        *reinterpret_cast<bf16x8*>(vb + ((int64_t)b * 64 + ft * 16) * 32) = o;
-      }
-    }
-  }
+  for (int i = 0; i < NP; ++i) *reinterpret_cast<bf16x8*>(pc.base + piece_offset<SWAP>(i)) = pc.v[i];
 }
 
 template <bool SWAP>

@@ -151,13 +151,14 @@ def _same_kind(*ws):
 
 def pack_kv_rows_k(wk_all):
     """omp_kv_project_rows(vt = 0): the key projections of all (decoder, layer) slabs, [n_slabs * 512, 512] bf16 with rows ordered (slab, head,
-    dim).  Inside every head the 64 dims are permuted so that matrix-core row 4 g + r of feature tile ft is dim 16 g + 4 ft + r: the lane that
-    owns rows 4 g .. 4 g + 3 of the four tiles then holds dims 16 g .. 16 g + 15 of a key -- 32 contiguous bytes of the K slab row."""
+    dim).  Inside every head the 64 dims are permuted so that matrix-core row 4 g + r of feature tile ft is dim 32 (ft / 2) + 8 g + 4 (ft % 2) + r:
+    the lane that owns rows 4 g .. 4 g + 3 of the four tiles then holds dims 8 g .. 8 g + 7 (tiles 0, 1) and 32 + 8 g .. (tiles 2, 3) of a key --
+    two 16-byte stores, each completing 64 contiguous bytes of the K slab row with its three neighbour lanes."""
     if wk_all.dtype != torch.bfloat16 or wk_all.shape[0] % 512 or wk_all.shape[1] != 512:
         raise ValueError('pack_kv_rows_k: [n_slabs * 512, 512] bf16')
     j = torch.arange(64)
     ft, row = j // 16, j % 16                       # position in the wave's stream: tile ft, matrix-core row
-    src = (row // 4) * 16 + ft * 4 + (row % 4)      # the dim that position computes
+    src = (ft // 2) * 32 + (row // 4) * 8 + (ft % 2) * 4 + (row % 4)      # the dim that position computes
     w = wk_all.reshape(-1, 64, 512)[:, src.to(wk_all.device)].reshape(-1, 512)
     return _rows_finish(_rows_product(w))
 

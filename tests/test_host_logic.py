@@ -664,7 +664,7 @@ def test_env_knobs_are_validated(monkeypatch):
 def test_pack_kv_rows_streams_name_the_rows_the_kernel_expects():
     """model/packing.py::pack_kv_rows_k / _v (csrc/kv_rows.hip): wave w's stream holds, per slab, 16 k-steps x 4 feature tiles of 1 KB fragments
     [64 lanes][8]; lane (li, g) of tile ft carries 8 consecutive k of ONE weight row -- for V^T the row of dim 16 ft + li of head w, for K the row
-    of dim 16 (li / 4) + 4 ft + li % 4 (so that the lane owning matrix-core rows 4 g .. 4 g + 3 of the four tiles stores 16 consecutive dims)."""
+    of dim 32 (ft / 2) + 8 (li / 4) + 4 (ft % 2) + li % 4 (so that the lane owning matrix-core rows 4 g .. 4 g + 3 stores dims 8 g .. 8 g + 7 and 32 + 8 g ..)."""
     import torch
     from advancedliteratemachinery_amd.model import packing
     n_slabs = 2
@@ -680,6 +680,6 @@ def test_pack_kv_rows_streams_name_the_rows_the_kernel_expects():
         fc = bc[:8 * stride].view(torch.bfloat16).reshape(8, n_slabs, 16, 4, 64, 8).float()
         for (wv, p, ks, ft, lane) in ((0, 0, 0, 0, 0), (2, 1, 5, 3, 37), (7, 1, 15, 1, 63), (4, 0, 9, 2, 18)):
             li, g = lane & 15, lane >> 4
-            dim = (li // 4) * 16 + ft * 4 + li % 4 if perm else ft * 16 + li
+            dim = (ft // 2) * 32 + (li // 4) * 8 + (ft % 2) * 4 + li % 4 if perm else ft * 16 + li
             assert fr[wv, p, ks, ft, lane].tolist() == [float(torch.tensor(p * 512 + wv * 64 + dim, dtype=torch.float32).to(torch.bfloat16))] * 8, name
             assert fc[wv, p, ks, ft, lane].tolist() == [float(torch.tensor(ks * 32 + g * 8 + e, dtype=torch.float32).to(torch.bfloat16)) for e in range(8)], name
