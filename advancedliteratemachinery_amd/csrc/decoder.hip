@@ -1250,6 +1250,73 @@ __global__ __launch_bounds__(256) void dec_sample_block_kernel(const float* __re
   }
 }
 
+// Many rows (the polygon / recognition phases: thousands of rows): a WAVE per row with the whole row in registers -- every lane requests its
+// (up to) eight 16-byte pieces of the row before it looks at any of them, the candidate filter, the maximum and the exponentials run on those
+// registers (the row is read once), and the position advance is folded in as in the block kernel.  The wave-per-row kernel above walks a row 64
+// logits at a time, one dependent round trip each (27 us alone at 10 240 rows); the workgroup-per-row kernel pays 10 240 workgroups of three
+// barriers (122 us alone; profiles/r05zh_kernel_shapes_bf16.txt).  ld % 4 == 0, vocab <= 2048.
+__global__ __launch_bounds__(256) void dec_sample_rows_kernel(const float* __restrict__ logits, int ld, int R, omp_sample_cfg c,
+                                                              int32_t* __restrict__ seq, float* __restrict__ probs, int seq_ld,
+                                                              int32_t* __restrict__ finished, int32_t* __restrict__ lengths,
+                                                              int32_t* d_pos, int32_t* ticket) {
+  constexpr int NQ = 8;   // 16-byte pieces per lane: 8 x 256 = 2048 logits
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  const int p = *d_pos;
+  const int i = p + 1 - c.step0;
+  if (i >= 0 && r < R) {
+    const bool slice = c.infer_vie && c.kind != OMP_DEC_PT;
+    const int Vs = c.vocab - (slice ? c.vie_categories : 0);
+    const float* lg = logits + (int64_t)r * ld;
+    f32x4 v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int t0 = q * 256 + lane * 4;
+      v[q] = t0 < ld ? *reinterpret_cast<const f32x4*>(lg + t0) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // ld % 4 == 0: a piece is inside the row or not at all
+    }
+    float mx = -INFINITY, best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int t = q * 256 + lane * 4 + e;
+        if (t < Vs) {
+          mx = fmaxf(mx, v[q][e]);
+          if (is_candidate(c, t, i) && v[q][e] > best) { best = v[q][e]; bi = t; }   // ascending t per lane: the first maximum wins, as in the kernels above
+        }
+      }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (q * 256 + lane * 4 + e < Vs) sum += expf(v[q][e] - mx);
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) {
+      seq[(int64_t)r * seq_ld + p + 1] = bi;
+      probs[(int64_t)r * seq_ld + p + 1] = expf(best - mx) / sum;
+      if (c.kind == OMP_DEC_PT && finished != nullptr) {
+        if (!finished[r] && bi == c.pt_eos) { finished[r] = 1; lengths[r] = p + 1; }
+      }
+    }
+  }
+  if (ticket != nullptr) {
+    __syncthreads();   // the four rows of this workgroup are done (every wave has read *d_pos long before)
+    if (tid == 0) {
+      const int t = atomicAdd(ticket, 1);
+      if (t == (int)gridDim.x - 1) { *ticket = 0; *d_pos = p + 1; }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Text-spotting results of an engine call -> fixed-size padded tensors (the payload of the per-call all-gather of an image-
 // sharded deployment): one launch instead of a Python loop of ~12 tiny device copies per image.
@@ -1483,13 +1550,28 @@ extern "C" int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K
   return launch_cross(cp, n_groups, dtype, n_split, q_tiles, (hipStream_t)s);
 }
 
+namespace {
+int sample_block_max_rows() {   // up to this many rows a WORKGROUP per row samples (few-row phases: latency), beyond a wave per row with the row in registers
+  static const int v = [] {
+    const char* e = getenv("OMP355_SAMPLE_BLOCK_MAX_ROWS");
+    const long x = e ? strtol(e, nullptr, 10) : 1024;
+    return (int)(x < 0 ? 0 : (x > (1 << 30) ? (1 << 30) : x));
+  }();
+  return v;
+}
+}  // namespace
+
 extern "C" int omp_head_softmax_mask_argmax(const float* logits, int ld, int R, const omp_sample_cfg* cfg,
                                             int32_t* seq, float* probs, int seq_ld, int32_t* finished,
                                             int32_t* lengths, int32_t* d_pos, int advance, omp_stream_t s) {
   OMP_CHECK_ARG(logits && cfg && seq && probs && d_pos, "omp_head_softmax_mask_argmax: null pointer");
   OMP_CHECK_ARG(R > 0 && cfg->vocab > 0 && cfg->vocab <= ld, "omp_head_softmax_mask_argmax: bad shape");
-  hipLaunchKernelGGL(dec_sample_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, ld, R, *cfg,
-                     seq, probs, seq_ld, finished, lengths, d_pos);
+  if (R > sample_block_max_rows() && ld % 4 == 0 && ((uintptr_t)logits % 16) == 0 && cfg->vocab <= 2048)   // many rows: the row in registers (dec_sample_rows_kernel)
+    hipLaunchKernelGGL(dec_sample_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, ld, R, *cfg, seq, probs, seq_ld, finished, lengths,
+                       d_pos, (int32_t*)nullptr);
+  else
+    hipLaunchKernelGGL(dec_sample_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, ld, R, *cfg,
+                       seq, probs, seq_ld, finished, lengths, d_pos);
   OMP_CHECK_LAUNCH("omp_head_softmax_mask_argmax");
   if (advance) {
     hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, d_pos);
@@ -1803,7 +1885,14 @@ int check_plan(const omp_decoder_plan* P) {
 }
 
 int sample_and_advance(const omp_decoder_plan* P, hipStream_t st) {
-  if (P->R <= 65536 && omp_cur().dec_fused != 1) {   // (round 5: also the 10 240-row phases -- the wave-per-row kernel walks 18 logits per lane one dependent round trip at a time: 27-127 us there)
+  if (P->R > sample_block_max_rows() && P->vocab % 4 == 0 && P->vocab <= 2048 && omp_cur().dec_fused != 1) {
+    // many rows: a wave per row, the row in registers (dec_sample_rows_kernel); the last workgroup publishes the next position
+    hipLaunchKernelGGL(dec_sample_rows_kernel, dim3((P->R + 3) / 4), dim3(256), 0, st, P->logits, P->vocab, P->R, P->sample, P->seq, P->probs,
+                       P->seq_ld, P->finished, P->lengths, P->d_pos, P->d_pos + 1);
+    OMP_CHECK_LAUNCH("omp_decoder_run(sample)");
+    return OMP_OK;
+  }
+  if (P->R <= 65536 && omp_cur().dec_fused != 1) {
     // a workgroup per row; the last one to finish publishes the next position (P->d_pos[1] is the ticket word)
     hipLaunchKernelGGL(dec_sample_block_kernel, dim3(P->R), dim3(256), 0, st, P->logits, P->vocab, P->R, P->sample, P->seq, P->probs,
                        P->seq_ld, P->finished, P->lengths, P->d_pos, P->d_pos + 1);

@@ -378,39 +378,44 @@ def check_posembed():
 
 
 def check_sampling():
-    """omp_head_softmax_mask_argmax vs the reference's filter+topk (oracle pt_step_filter/rec_filter)."""
+    """omp_head_softmax_mask_argmax vs the reference's filter+topk (oracle pt_step_filter/rec_filter).  37 rows: the wave-per-row kernel;
+    2501 rows: the many-row kernel with the row in registers (dec_sample_rows_kernel, more than 1024 rows; last workgroup ragged).  Rows are
+    padded to a multiple of four floats with a huge value that no kernel may read as a logit."""
     from advancedliteratemachinery_amd import _lib
     out = []
     for vie in (0, 4):
         a = make_args(vie_categories=vie, infer_vie=vie > 0)
         V = a.num_classes
-        R = 37
-        for kind, kid in (('pt', 0), ('poly', 1), ('rec', 2)):
-            for step in range(3):
-                logits = rnd(R, V, seed=step + 10 * kid) * 3
-                lg = logits if not (vie and kind != 'pt') else logits[:, :-vie]
-                pr = lg.softmax(-1)
-                if kind == 'pt':
-                    pr = O.pt_step_filter(a, pr, step)
-                elif kind == 'poly':
-                    pr = pr[:, :a.num_bins]
-                else:
-                    pr = O.rec_filter(a, pr)
-                p_ref, t_ref = pr.topk(dim=-1, k=1)
-                cfg = _lib.SampleCfg(kid, a.num_bins, a.pt_eos_index, a.poly_eos_index, a.rec_eos_index, V, vie,
-                                     1 if vie else 0, 0, 3)
-                seq = torch.zeros(R, 16, dtype=torch.int32, device=DEV)
-                probs = torch.zeros(R, 16, device=DEV)
-                fin = torch.zeros(R, dtype=torch.int32, device=DEV)
-                lens = torch.zeros(R, dtype=torch.int32, device=DEV)
-                d_pos = torch.tensor([2 + step], dtype=torch.int32, device=DEV)
-                ops.head_sample(logits.to(DEV), cfg, seq, probs, fin, lens, d_pos)
-                tok = seq[:, 3 + step].cpu().long()
-                mism = (tok != t_ref[:, 0]).sum().item()
-                perr = maxerr(probs[:, 3 + step], p_ref[:, 0])
-                adv = abs(int(d_pos.item()) - (3 + step))
-                out.append(rec('sample[%s,vie%d,step%d]' % (kind, vie, step), mism + adv + (0 if perr < 1e-5 else 1), 0,
-                               'perr=%.2e' % perr))
+        ldp = (V + 3) // 4 * 4
+        for R in (37, 2501):
+            for kind, kid in (('pt', 0), ('poly', 1), ('rec', 2)):
+                for step in range(3):
+                    logits = rnd(R, V, seed=step + 10 * kid) * 3
+                    lg = logits if not (vie and kind != 'pt') else logits[:, :-vie]
+                    pr = lg.softmax(-1)
+                    if kind == 'pt':
+                        pr = O.pt_step_filter(a, pr, step)
+                    elif kind == 'poly':
+                        pr = pr[:, :a.num_bins]
+                    else:
+                        pr = O.rec_filter(a, pr)
+                    p_ref, t_ref = pr.topk(dim=-1, k=1)
+                    cfg = _lib.SampleCfg(kid, a.num_bins, a.pt_eos_index, a.poly_eos_index, a.rec_eos_index, V, vie,
+                                         1 if vie else 0, 0, 3)
+                    seq = torch.zeros(R, 16, dtype=torch.int32, device=DEV)
+                    probs = torch.zeros(R, 16, device=DEV)
+                    fin = torch.zeros(R, dtype=torch.int32, device=DEV)
+                    lens = torch.zeros(R, dtype=torch.int32, device=DEV)
+                    d_pos = torch.tensor([2 + step], dtype=torch.int32, device=DEV)
+                    lg_dev = torch.full((R, ldp), 1e9, device=DEV)
+                    lg_dev[:, :V] = logits.to(DEV)
+                    ops.head_sample(lg_dev[:, :V], cfg, seq, probs, fin, lens, d_pos)   # a view: row stride ldp
+                    tok = seq[:, 3 + step].cpu().long()
+                    mism = (tok != t_ref[:, 0]).sum().item()
+                    perr = maxerr(probs[:, 3 + step], p_ref[:, 0])
+                    adv = abs(int(d_pos.item()) - (3 + step))
+                    out.append(rec('sample[%s,vie%d,step%d,R=%d]' % (kind, vie, step, R), mism + adv + (0 if perr < 1e-5 else 1), 0,
+                                   'perr=%.2e' % perr))
     return out
 
 
