@@ -280,7 +280,9 @@ int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K, const voi
  * filtering, argmax, probability; appends the token at seq[r, *d_pos + 1], the probability at
  * probs[r, *d_pos + 1], maintains finished/lengths for the point decoder, then (if advance)
  * increments *d_pos.  Replaces transformer.py:106-129 (pt), :258-263 (poly), :272-282 (rec) and
- * the KIE variants :154-183.  `step0` = sequence position of the first generated token. */
+ * the KIE variants :154-183.  `step0` = sequence position of the first generated token.
+ * A wave per row; beyond 1024 rows (OMP355_SAMPLE_BLOCK_MAX_ROWS) with 16-byte aligned rows (ld % 4 == 0) and vocab <= 2048 the row is held in
+ * registers (one pass over the logits).  Probabilities may differ in the last bit between the kernels (summation order); tokens do not. */
 typedef struct {
   int32_t kind;        /* OMP_DEC_* */
   int32_t num_bins, pt_eos, poly_eos, rec_eos, vocab;
