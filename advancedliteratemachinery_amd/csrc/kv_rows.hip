@@ -27,12 +27,13 @@ namespace {
 
 #include "rows_common.inc"
 
-// Weight fragments in flight per wave.  MEASURED (160 images: 655 360 rows, profiles/r05zc-r05zg_kbench_kv_rows.txt): 4.0-4.1 ms per launch
-// = 1.0 PF, against 5.7-6.2 ms for the tiled GEMMs -- and the same 4.0-4.1 ms with a ring of 16, with 128 rows per workgroup (half the weight
-// bytes), with the K stores as 64-byte runs instead of 16-byte pieces, and with a slab's stores issued one per ring revolution under the NEXT
-// slab's product: none of the three suspects (weight stream, store pattern, stores behind the products) is what paces it.  A slab's stores
-// share vmcnt with the ring (`s_waitcnt vmcnt(PF - 1)` cannot be relaxed for them: loads return in order among themselves, stores in any
-// order), which is the next thing to measure with in-kernel timestamps.
+// Weight fragments in flight per wave.  MEASURED (160 images: 655 360 rows, profiles/r05zc-r05zl_kbench_kv_rows*.txt): 3.9-4.1 ms per launch
+// = 1.0 PF, against 5.7-6.2 ms for the tiled GEMMs -- and the same with a ring of 16, with 128 rows per workgroup, with the K stores as 64-byte
+// runs instead of 16-byte pieces, and with a slab's stores issued one per ring revolution under the NEXT slab's product.  The phase ticks of
+// wave 0 (p.trace): a workgroup holds its CU for 100 us = products 73 us (matrix-core floor 41, weight-stream floor 57) + pack and stores 27 us
+// (786 KB at the ~10 B / clk a CU writes); with TWO workgroups per CU (half-slab passes, 106 registers) every phase takes twice as long and
+// the launch 4.4 ms: what is saturated is the CU's read path from L2 (~100 GB/s: 40 workgroups x 6.3 MB per CU = 2.5 ms) plus its write path,
+// which do not overlap.  Fewer weight bytes per row need more rows per workgroup than the register file holds beside a 6144-wide output.
 constexpr int PF = 8;
 constexpr int A_PITCH = D * 2 + 32;    // operand tile row pitch, bytes (conflict-free b128 fragment reads, as csrc/dec_rows.hip)
 constexpr int TILE_SLACK = 64;         // the operand prefetch reads one k-step past the last row
@@ -45,6 +46,7 @@ struct KvP {
   bf16_t* out;            // slab base
   int64_t rows;           // B * M
   int M, Mpad, B, n_slabs;
+  unsigned long long* trace;   // development (omp_debug_swin_mlp_trace): [workgroup][8] s_memtime ticks of wave 0 -- 0 both, 2 products, 3 pack + stores
 };
 
 constexpr int RTT = 4, RT = RTT * 16;  // 64 rows per workgroup: two 32-key blocks
@@ -158,6 +160,16 @@ __global__ __launch_bounds__(NW * 64) void kv_rows_kernel(KvP p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
+  const bool tracing = p.trace != nullptr && wave == 0;
+  unsigned long long tr[4] = {0, 0, 0, 0};
+  unsigned long long t_last = tracing ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto lap = [&](int i) {
+    if (tracing) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      tr[i] += t - t_last;
+      t_last = t;
+    }
+  };
   const char* a_lane = tile + li * A_PITCH + g * 16;
   const int image = (int)(r0 / p.M), key0 = (int)(r0 - (int64_t)image * p.M);   // M % 64 == 0: a workgroup never straddles images
   f32x4 acc[4][RTT];
@@ -165,12 +177,25 @@ __global__ __launch_bounds__(NW * 64) void kv_rows_kernel(KvP p) {
   for (int nl = 0; nl < p.n_slabs - 1; ++nl) {
     zero_acc(acc);
     gemm_pass_kv<SWAP>(acc, a_lane, ring, st);
+    lap(2);
     store_slab<SWAP>(acc, p, nl, image, key0, wave, li, g);
+    lap(3);
   }
   zero_acc(acc);
   gemm_pass_kv<SWAP>(acc, a_lane, ring, st);
   ws_drain(ring);   // the ring's run-ahead requests (PF fragments of slack behind the stream)
+  lap(2);
   store_slab<SWAP>(acc, p, p.n_slabs - 1, image, key0, wave, li, g);
+  if (tracing) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lap(3);
+    if (lane == 0) {
+      unsigned long long* o = p.trace + (int64_t)blockIdx.x * 8;
+      o[0] = tr[2] + tr[3];
+      o[2] = tr[2];
+      o[3] = tr[3];
+    }
+  }
 }
 
 template <bool SWAP>
@@ -202,6 +227,7 @@ extern "C" int omp_kv_project_rows(const void* rows, const void* wstream, int64_
   KvP p;
   p.a = reinterpret_cast<const bf16_t*>(rows); p.wstream = reinterpret_cast<const char*>(wstream); p.wave_stride = wave_stride;
   p.bias = bias; p.out = reinterpret_cast<bf16_t*>(out); p.rows = (int64_t)B * M; p.M = M; p.Mpad = Mpad; p.B = B; p.n_slabs = n_slabs;
+  p.trace = omp_cur().mlp_trace;
   hipStream_t st = (hipStream_t)s;
   const double fl = 2.0 * (double)p.rows * D * D * n_slabs;
   const double by = (double)p.rows * D * 2 + (double)p.rows * D * n_slabs * 2 + (double)n_slabs * D * D * 2;

@@ -472,6 +472,20 @@ def bench_kv_rows():
         us = timeit(lambda: dec.project_memory(mem, mem_pos, I, M, None), iters=5, warm=2)
         print('kv_project[%d images x %d keys, %d slabs] %-52s : %8.1f us  %7.1f TF/s' % (I, M, dec.NL, label, us, fl / us / 1e6), flush=True)
     dec.kv_rows = True
+    # phase cycles of wave 0 (omp_debug_swin_mlp_trace): K launch then V^T launch
+    h = _lib.lib()
+    nwg = I * M // 64
+    for vt, rows_, (sk, nk), bias, slab in ((False, mem_pos, dec._kv_streams[0], dec.bk_all, 0), (True, mem, dec._kv_streams[1], dec.bv_all, 1)):
+        kv = dec.project_memory(mem, mem_pos, I, M, None)
+        out = kv['Vt'] if vt else kv['K']
+        trace = torch.zeros(nwg, 8, dtype=torch.int64, device=DEV)
+        h.omp_debug_swin_mlp_trace(ops.ptr(trace))
+        ops.kv_project_rows(rows_, sk, nk, bias, out, I, M, kv['Mpad'], dec.NL, vt)
+        torch.cuda.synchronize()
+        h.omp_debug_swin_mlp_trace(None)
+        t = trace.cpu().double()
+        print('    %s launch, wave 0 per workgroup (%d workgroups): products %.0f cycles, pack + stores %.0f cycles (12 slabs each)'
+              % ('V^T' if vt else 'K', nwg, t[:, 2].mean().item(), t[:, 3].mean().item()), flush=True)
 
 
 def bench_swin_rows():
