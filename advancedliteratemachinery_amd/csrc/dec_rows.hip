@@ -563,8 +563,8 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_ffn_kernel(RowsP p) {
 
 constexpr int RTT_DEFAULT = 5;   // 80 rows per workgroup: the Swin chains (thousands of workgroups per launch)
 
-// Rows per workgroup of a DECODER launch.  A workgroup streams the whole weight set whatever its rows (5.5 MB for the FFN chain: about
-// 50 us at the 110 GB/s a CU draws from L2) and runs 16 x RTT rows x 5.5 M parameters on its CU's matrix cores (18 us per 16 rows), so a
+// Rows per workgroup of a DECODER launch.  A workgroup streams the whole weight set whatever its rows (6.3 MB for the FFN chain: about
+// 57 us at the 110 GB/s a CU draws from L2) and runs 16 x RTT rows x 3.15 M parameters on its CU's matrix cores (10-15 us per 16 rows), so a
 // launch that leaves CUs idle is better cut finer -- but the polygon and the recognition decoder run side by side on two streams, a chain
 // workgroup takes its CU's LDS whole, and what one decoder does not occupy is where the other's HBM-bound attention kernels run.  Measured at
 // 10 240 rows (160 images x 64 instances; profiles/r05o_kbench_dec_rows_tiles.txt): the FFN chain alone 110 / 91 / 84 / 147 us at 80 / 64 /

@@ -1821,7 +1821,7 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
   // Phases between the fused few-row kernels (<= 63 rows) and the full chains (rows_fused): when the caller bound layers[].rows_mid, the three
   // launches between self- and cross-attention -- 1 MB of weights, 23 us at 160 rows, bound by two launch boundaries -- are the mid chain on
   // 16-row workgroups (the point decoder of a 160-image call: 10 workgroups stream the megabyte in 9 us).  The FFN half stays on launches: its
-  // 5.5 MB per workgroup would stream longer than the launches take.
+  // 6.3 MB per workgroup would stream longer than the launches take.
   bool mid_chain = !fused && omp_cur().dec_fused != 1 && T == OMP_BF16 && P->pre_norm && d == 512 && P->n_heads == 8 && !P->kv_split && R >= 16;
   for (int li = 0; li < P->n_layers && mid_chain; ++li) mid_chain = P->layers[li].rows_mid != nullptr;
   omp_dec_rows_args ma{};

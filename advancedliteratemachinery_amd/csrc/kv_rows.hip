@@ -27,13 +27,13 @@ namespace {
 
 #include "rows_common.inc"
 
-// Weight fragments in flight per wave.  MEASURED (160 images: 655 360 rows, profiles/r05zc-r05zl_kbench_kv_rows*.txt): 3.9-4.1 ms per launch
+// Weight fragments in flight per wave.  MEASURED (160 images: 655 360 rows, profiles/r05zc-r05zm_kbench_kv_rows*.txt): 3.9-4.1 ms per launch
 // = 1.0 PF, against 5.7-6.2 ms for the tiled GEMMs -- and the same with a ring of 16, with 128 rows per workgroup, with the K stores as 64-byte
-// runs instead of 16-byte pieces, and with a slab's stores issued one per ring revolution under the NEXT slab's product.  The phase ticks of
-// wave 0 (p.trace): a workgroup holds its CU for 100 us = products 73 us (matrix-core floor 41, weight-stream floor 57) + pack and stores 27 us
-// (786 KB at the ~10 B / clk a CU writes); with TWO workgroups per CU (half-slab passes, 106 registers) every phase takes twice as long and
-// the launch 4.4 ms: what is saturated is the CU's read path from L2 (~100 GB/s: 40 workgroups x 6.3 MB per CU = 2.5 ms) plus its write path,
-// which do not overlap.  Fewer weight bytes per row need more rows per workgroup than the register file holds beside a 6144-wide output.
+// runs instead of 16-byte pieces, and with a slab's stores issued one per ring revolution under the NEXT slab's product.  The phase clocks of
+// wave 0 (p.trace): a workgroup holds its CU for 158 k cycles = products 114 k (issue floor of its 3072 MFMAs per wave at two waves per SIMD:
+// 98 k) + pack and stores 44 k (786 KB at the ~10 B / clk a CU writes); with TWO workgroups per CU (half-slab passes, 106 registers) products
+// take 207 k (floor 196 k), stores 82 k, the launch 4.4 ms.  The product phase is matrix-core-bound at the clock the chip sustains under it
+// (s_memtime / s_memrealtime: 1.60-1.73 GHz, not the nominal 2.4); what is left is the store phase that nothing overlaps.
 constexpr int PF = 8;
 constexpr int A_PITCH = D * 2 + 32;    // operand tile row pitch, bytes (conflict-free b128 fragment reads, as csrc/dec_rows.hip)
 constexpr int TILE_SLACK = 64;         // the operand prefetch reads one k-step past the last row
@@ -46,7 +46,7 @@ struct KvP {
   bf16_t* out;            // slab base
   int64_t rows;           // B * M
   int M, Mpad, B, n_slabs;
-  unsigned long long* trace;   // development (omp_debug_swin_mlp_trace): [workgroup][8] s_memtime ticks of wave 0 -- 0 both, 2 products, 3 pack + stores
+  unsigned long long* trace;   // development (omp_debug_swin_mlp_trace): [workgroup][8] shader clocks (s_memtime) of wave 0 -- 0 both, 2 products, 3 pack + stores; 4 = the same interval in 10 ns ticks (s_memrealtime)
 };
 
 constexpr int RTT = 4, RT = RTT * 16;  // 64 rows per workgroup: two 32-key blocks
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(NW * 64) void kv_rows_kernel(KvP p) {
   const bool tracing = p.trace != nullptr && wave == 0;
   unsigned long long tr[4] = {0, 0, 0, 0};
   unsigned long long t_last = tracing ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rt0 = tracing ? __builtin_amdgcn_s_memrealtime() : 0ull;   // the constant 100 MHz counter: calibrates the shader clock
   auto lap = [&](int i) {
     if (tracing) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(NW * 64) void kv_rows_kernel(KvP p) {
       o[0] = tr[2] + tr[3];
       o[2] = tr[2];
       o[3] = tr[3];
+      o[4] = __builtin_amdgcn_s_memrealtime() - rt0;   // 10 ns ticks over the same interval as o[0]
     }
   }
 }

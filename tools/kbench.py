@@ -484,8 +484,8 @@ def bench_kv_rows():
         torch.cuda.synchronize()
         h.omp_debug_swin_mlp_trace(None)
         t = trace.cpu().double()
-        print('    %s launch, wave 0 per workgroup (%d workgroups): products %.0f cycles, pack + stores %.0f cycles (12 slabs each)'
-              % ('V^T' if vt else 'K', nwg, t[:, 2].mean().item(), t[:, 3].mean().item()), flush=True)
+        print('    %s launch, wave 0 per workgroup (%d workgroups): products %.0f cycles, pack + stores %.0f cycles (12 slabs each); shader clock over that interval %.0f MHz (s_memtime / s_memrealtime)'
+              % ('V^T' if vt else 'K', nwg, t[:, 2].mean().item(), t[:, 3].mean().item(), (t[:, 0] / (t[:, 4] * 0.01)).mean().item()), flush=True)
 
 
 def bench_swin_rows():
