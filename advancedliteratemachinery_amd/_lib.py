@@ -122,6 +122,7 @@ _SIGS = {
     'omp_debug_set_gemm_trace': (c_int, [c_void_p, c_int64]),
     'omp_debug_swin_attn_impl': (c_int, [c_int]),
     'omp_debug_rows_tile': (c_int, [c_int]),
+    'omp_debug_rows_tile_choice': (c_int, [c_int, c_int]),
     'omp_debug_cross_q4': (c_int, [c_int]),
     'omp_debug_cross_nt': (c_int, [c_int]),
     'omp_debug_self_attn_impl': (c_int, [c_int]),

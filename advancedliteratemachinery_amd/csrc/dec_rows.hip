@@ -706,6 +706,11 @@ extern "C" int omp_dec_rows_ffn(const omp_dec_rows_args* a, omp_stream_t s) {
 
 extern "C" int omp_dec_rows_tile(void) { return omp_rows_tile(); }
 
+extern "C" int omp_debug_rows_tile_choice(int R, int mid) {   // host logic: rows per workgroup a decoder chain launch of R rows would take (mid: omp_dec_rows_mid)
+  if (R <= 0) return OMP_ERR_INVALID;
+  return 16 * rows_rtt(R, mid ? 1 : 2);
+}
+
 extern "C" int omp_debug_rows_tile(int rtt) {   // 0 = by row count (rows_rtt), 2..5 = 16 x rtt rows per workgroup of every decoder chain launch
   OMP_CHECK_ARG(rtt == 0 || (rtt >= 2 && rtt <= 5), "omp_debug_rows_tile: 0 (automatic) or 2..5 tiles of 16 rows (got %d)", rtt);
   omp_cur().rows_rtt = rtt;

@@ -49,6 +49,7 @@ int omp_debug_set_gemm_trace(void* buffer, int64_t n_workgroups);
 int omp_debug_swin_attn_impl(int which); /* 0 = matrix-core kernel (default), 1 = scalar cross-check kernel, 2 = matrix cores with per-score table lookups */
 int omp_debug_dec_fused(int mode);       /* 0 = fused few-row decoder step kernels where they apply (default), 1 = one launch per op everywhere (A/B, cross-check) */
 int omp_debug_self_attn_impl(int which); /* 0 auto, 1 = one wave per (row, head), 2 = one wave per row (all 8 heads) */
+int omp_debug_rows_tile_choice(int R, int mid); /* host logic, no launch: rows per workgroup (16..80) a decoder row-owner launch of R rows takes; mid != 0: omp_dec_rows_mid (also 16 rows) */
 int omp_debug_rows_tile(int rtt);        /* decoder row-owner chains (bf16): rows per workgroup = 16 x rtt, 0 = chosen by row count (default), 2..5 forced */
 int omp_debug_cross_nt(int on);          /* non-temporal K / V^T loads in the cross-attention kernels: 1 = always (default), 2 = only from 32 groups per launch, 0 = never */
 int omp_debug_cross_q4(int on);          /* 1 = LDS-ring cross-attention for 33..64 rows/image in 64-key chunks, non-temporal DMA (default), 2 = one 32-key block per step, 4 = chunks with temporal loads, 0 = register-streaming kernel */

@@ -460,6 +460,14 @@ def cross_q4(on):
     _lib.check(_lib.lib().omp_debug_cross_q4(int(on)), 'omp_debug_cross_q4')
 
 
+def rows_tile_choice(R, mid=False):
+    """host logic (no launch, no device): rows per workgroup a decoder row-owner chain launch of R rows takes (csrc/dec_rows.hip rows_rtt)."""
+    rc = _lib.lib().omp_debug_rows_tile_choice(int(R), 1 if mid else 0)
+    if rc < 0:
+        _lib.check(rc, 'omp_debug_rows_tile_choice')
+    return rc
+
+
 def rows_tile(rtt):
     """debug/testing: rows per workgroup of the decoder row-owner chains (bf16 engine) = 16 x rtt; 0 = chosen from the launch's row count
     (csrc/dec_rows.hip rows_rtt), 2..5 forced."""

@@ -683,3 +683,26 @@ def test_pack_kv_rows_streams_name_the_rows_the_kernel_expects():
             dim = (ft // 2) * 32 + (li // 4) * 8 + (ft % 2) * 4 + li % 4 if perm else ft * 16 + li
             assert fr[wv, p, ks, ft, lane].tolist() == [float(torch.tensor(p * 512 + wv * 64 + dim, dtype=torch.float32).to(torch.bfloat16))] * 8, name
             assert fc[wv, p, ks, ft, lane].tolist() == [float(torch.tensor(ks * 32 + g * 8 + e, dtype=torch.float32).to(torch.bfloat16)) for e in range(8)], name
+
+
+def test_rows_tile_rule():
+    """csrc/dec_rows.hip rows_rtt as host logic (omp_debug_rows_tile_choice): a decoder chain launch takes the smallest tile of 32 / 48 / 64 / 80
+    rows (the mid chain: from 16) that keeps it on half the chip (128 workgroups) -- the rule DESIGN.md section 11 derives from the two-stream
+    measurement -- and a forced tile (omp_debug_rows_tile) overrides it."""
+    from advancedliteratemachinery_amd import ops
+    T = ops.rows_tile_choice
+    assert T(10240) == 80            # 160 images x 64 instances: 128 workgroups
+    assert T(5120) == 48             # 107 workgroups (32 rows would be 160)
+    assert T(4096) == 32             # exactly 128
+    assert T(4097) == 48
+    assert T(200) == 32
+    assert T(1 << 20) == 80          # beyond the chip: the largest tile
+    assert T(160, mid=True) == 16    # the point decoder of a 160-image call: 10 workgroups
+    assert T(2048, mid=True) == 16 and T(2049, mid=True) == 32
+    assert T(10240, mid=True) == 80
+    try:
+        ops.rows_tile(3)
+        assert T(10240) == 48 and T(160, mid=True) == 48
+    finally:
+        ops.rows_tile(0)
+    assert T(10240) == 80
