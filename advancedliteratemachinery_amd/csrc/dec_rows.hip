@@ -251,6 +251,41 @@ __device__ __forceinline__ void store_bias(const f32x4 (&acc)[NFT][RTT], const f
   else store_bias_t<NFT, RTT, T, RELU, false>(acc, bb, ob, ld, nrow, fwave, flimit, li, g);
 }
 
+// The q | k | v tail of a chain: model/packing.py::_qkv_tail_rows orders the weight rows of every 64-feature group so that this lane's quads of
+// tiles 0 / 1 are features 8 g .. 8 g + 7 of its rows and those of tiles 2 / 3 the same + 32 -- 16-byte stores (four lanes: 64 contiguous
+// bytes of a row), half as many as store_bias_t issues.  A pass's stores share vmcnt with the weight ring, and the next pass's first takes
+// wait until all but seven of the outstanding operations are done: the fewer stores, the sooner the stream resumes.
+__device__ __forceinline__ void load_bias_perm(f32x4 (&bb)[4], const float* __restrict__ bias, int fwave, int g) {
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) bb[ft] = *reinterpret_cast<const f32x4*>(bias + fwave + (ft >> 1) * 32 + g * 8 + (ft & 1) * 4);
+}
+template <int RTT, bool FULL>
+__device__ __forceinline__ void store_bias_perm_t(const f32x4 (&acc)[4][RTT], const f32x4 (&bb)[4], bf16_t* __restrict__ ob, int ld, int nrow, int fwave, int li_, int g_) {
+  const int li = opaque(li_), g = opaque(g_);
+#pragma unroll
+  for (int rt = 0; rt < RTT; ++rt) {
+    const int lr = rt * 16 + li;
+    if (FULL || lr < nrow) {
+      bf16x8 lo, hi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        lo[r] = (bf16_t)(acc[0][rt][r] + bb[0][r]);
+        lo[4 + r] = (bf16_t)(acc[1][rt][r] + bb[1][r]);
+        hi[r] = (bf16_t)(acc[2][rt][r] + bb[2][r]);
+        hi[4 + r] = (bf16_t)(acc[3][rt][r] + bb[3][r]);
+      }
+      bf16_t* o = ob + (int64_t)lr * ld + fwave + g * 8;
+      *reinterpret_cast<bf16x8*>(o) = lo;
+      *reinterpret_cast<bf16x8*>(o + 32) = hi;
+    }
+  }
+}
+template <int RTT>
+__device__ __forceinline__ void store_bias_perm(const f32x4 (&acc)[4][RTT], const f32x4 (&bb)[4], bf16_t* __restrict__ ob, int ld, int nrow, int fwave, int li, int g) {
+  if (nrow == RTT * 16) store_bias_perm_t<RTT, true>(acc, bb, ob, ld, nrow, fwave, li, g);
+  else store_bias_perm_t<RTT, false>(acc, bb, ob, ld, nrow, fwave, li, g);
+}
+
 // x[row][f] = acc: the residual stream back to memory
 template <int RTT>
 __device__ __forceinline__ void store_x(const f32x4 (&acc)[4][RTT], float* __restrict__ xb, int nrow, int wave, int li_, int g_) {
@@ -500,10 +535,10 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_ffn_kernel(RowsP p) {
     auto qkv_pass = [&](int ps, auto LAST) {
       zero_acc(acc);
       f32x4 bb[4];
-      load_bias<4>(bb, p.bias_tab + (int64_t)pos * (3 * D) + ps * D, wave * 64, D, g);
+      load_bias_perm(bb, p.bias_tab + (int64_t)pos * (3 * D) + ps * D, wave * 64, g);
       gemm_pass<4, 16, RTT, A_PITCH>(acc, a_lane, ring, st);
       if constexpr (decltype(LAST)::value) ws_drain(ring);
-      store_bias<4, RTT, bf16_t, false>(acc, bb, p.qkv + r0 * (3 * D) + ps * D, 3 * D, nrow, wave * 64, D, li, g);
+      store_bias_perm<RTT>(acc, bb, p.qkv + r0 * (3 * D) + ps * D, 3 * D, nrow, wave * 64, li, g);
     };
 #pragma unroll 1
     for (int ps = 0; ps < 2; ++ps) qkv_pass(ps, std::false_type());

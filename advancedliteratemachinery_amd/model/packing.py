@@ -189,10 +189,24 @@ def _rows_ffn_pieces(ca_out_w, ff1_w, ff2_w):
     return pieces
 
 
+def _qkv_tail_rows(w):
+    """The q | k | v Linear behind a chain (tail 0).  bf16 engine: inside every 64-feature group (a wave's features of a 512-feature pass) the
+    rows are ordered so that matrix-core row 4 g + r of feature tile ft computes feature 32 (ft / 2) + 8 g + 4 (ft % 2) + r: the lane that owns
+    rows 4 g .. 4 g + 3 of the four tiles then holds features 8 g .. 8 g + 7 and 32 + 8 g .. of a row -- two 16-byte stores instead of four
+    8-byte ones (csrc/dec_rows.hip store_bias_perm; a pass's stores share vmcnt with the weight ring: fewer of them, shorter stall).  The
+    parity engine's chains (fp32 masters, fp32 outputs: 16 bytes per quad already) keep the natural order."""
+    if w.dtype != torch.bfloat16:
+        return w
+    j = torch.arange(64)
+    ft, row = j // 16, j % 16
+    src = (ft // 2) * 32 + (row // 4) * 8 + (ft % 2) * 4 + (row % 4)
+    return w.reshape(-1, 64, w.shape[1])[:, src.to(w.device)].reshape(w.shape)
+
+
 def pack_rows_ffn_qkv(ca_out_w, ff1_w, ff2_w, next_sa_in_w):
     """omp_dec_rows_ffn(prologue 0, tail 0): multihead_attn.out_proj, linear1 / linear2 in chunks, then the NEXT layer's self_attn.in_proj [1536, 512]."""
     _same_kind(ca_out_w, next_sa_in_w)
-    return _rows_finish(_rows_ffn_pieces(ca_out_w, ff1_w, ff2_w) + _rows_product(next_sa_in_w))
+    return _rows_finish(_rows_ffn_pieces(ca_out_w, ff1_w, ff2_w) + _rows_product(_qkv_tail_rows(next_sa_in_w)))
 
 
 def _rows_head_pieces(h0_w, h1_w, h2_w):
@@ -213,7 +227,7 @@ def pack_rows_ffn_head(ca_out_w, ff1_w, ff2_w, h0_w, h1_w, h2_w):
 def pack_rows_embed_qkv(sa_in_w):
     """omp_dec_rows_ffn(prologue 1, tail 0): layer 0's self_attn.in_proj behind the embedding."""
     _same_kind(sa_in_w)
-    return _rows_finish(_rows_product(sa_in_w))
+    return _rows_finish(_rows_product(_qkv_tail_rows(sa_in_w)))
 
 
 def pack_rows_ffn(out_w, ff1_w, ff2_w):
