@@ -706,3 +706,20 @@ def test_rows_tile_rule():
     finally:
         ops.rows_tile(0)
     assert T(10240) == 80
+
+
+def test_qkv_tail_rows_match_the_16_byte_store_mapping():
+    """model/packing.py::_qkv_tail_rows (bf16 chains' q | k | v tail) against csrc/dec_rows.hip::store_bias_perm: the accumulator quad of feature
+    tile ft that lane g holds (matrix-core rows 4 g + r) is stored at feature offset 32 (ft / 2) + 8 g + 4 (ft % 2) + r of the wave's 64 -- so the
+    weight row packed at stream position (tile ft, row 4 g + r) must be exactly that feature; fp32 masters (parity engine) keep their order."""
+    import torch
+    from advancedliteratemachinery_amd.model import packing
+    w = torch.arange(1536, dtype=torch.float32)[:, None].repeat(1, 512)
+    assert torch.equal(packing._qkv_tail_rows(w), w)                       # fp32: untouched
+    p = packing._qkv_tail_rows(w.to(torch.bfloat16)).float()
+    for group in (0, 5, 23):                                               # a wave's 64 features of some pass
+        for ft in range(4):
+            for g in range(4):
+                for r in range(4):
+                    stored_at = 32 * (ft // 2) + 8 * g + 4 * (ft % 2) + r
+                    assert p[group * 64 + ft * 16 + 4 * g + r, 0].item() == float(torch.tensor(group * 64 + stored_at, dtype=torch.float32).to(torch.bfloat16))
