@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16, OMP_BF16X2 = 0, 1, 2   # BF16X2: split-bf16 pair rows [hi | lo] (include/omp355.h)
-ABI_VERSION = 19
+ABI_VERSION = 20
 STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
@@ -115,6 +115,7 @@ _SIGS = {
     'omp_kv_project_rows': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_swin_rows_block': (c_int, [ctypes.POINTER(SwinRowsArgs), c_void_p]),
     'omp_decoder_run': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_int, c_int, c_void_p]),
+    'omp_decoder_run_pair': (c_int, [ctypes.POINTER(DecoderPlan), ctypes.POINTER(DecoderPlan), c_int, c_int, c_int, c_void_p, c_void_p]),
     'omp_decoder_graph_reset': (c_int, [c_int]),
     'omp_decoder_step_logits': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_void_p]),
     'omp_debug_force_gemm_kernel': (c_int, [c_int]),

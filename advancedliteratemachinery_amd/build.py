@@ -37,12 +37,16 @@ def _digest(paths, extra=''):
     return h.hexdigest()
 
 
-def _fresh(target, digest):
+def _asm_of(src):
+    return os.path.join(OBJ, '%s-hip-amdgcn-amd-amdhsa-gfx950.s' % src.replace('.hip', ''))
+
+
+def _fresh(target, digest, stamp=None):
     """An object is fresh when the stamp beside it holds the digest of (compiler flags, source, every header): CONTENT, not mtimes --
     a snapshot of the tree (gpurun, a checkout) does not keep mtimes, and `build()` then proves that the library on disk was compiled
     from the sources on disk."""
     try:
-        with open(target + '.stamp') as f:
+        with open(stamp or target + '.stamp') as f:
             return os.path.exists(target) and f.read().strip() == digest
     except OSError:
         return False
@@ -54,6 +58,7 @@ def build(force=False, verbose=True):
     jobs = []
     objs = []
     stamps = []
+    audited = {}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace('.hip', '.o'))
@@ -61,21 +66,26 @@ def build(force=False, verbose=True):
         flags = FLAGS + (['-save-temps=obj'] if src in AUDITED else [])
         dg = _digest([s] + HEADERS, ' '.join(flags))
         stamps.append(dg)
-        if force or not _fresh(o, dg):
+        # an AUDITED object must be provably audited: either its audit stamp holds this digest (the assembly of exactly this object passed -- the
+        # stamp travels to the GPU box, the 40 MB of compiler temporaries do not) or its device assembly is here to be read; otherwise it is stale
+        if src in AUDITED:
+            audited[src] = dg
+        if force or not _fresh(o, dg) or (src in AUDITED and not _fresh(o, dg, o + '.audit.stamp') and not os.path.exists(_asm_of(src))):
             jobs.append(([hipcc] + flags + ['-c', s, '-o', o], o, dg))
 
     def run(job):
-        cmd, obj, dg = job if isinstance(job, tuple) else (job, None, None)
-        if obj is not None and os.path.exists(obj + '.stamp'):
-            os.remove(obj + '.stamp')
+        cmd, obj, dg = job[:3]
+        stamp = job[3] if len(job) > 3 else obj + '.stamp'
+        for st in (stamp, obj + '.audit.stamp'):
+            if os.path.exists(st):
+                os.remove(st)
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed:\n%s\n%s' % (' '.join(cmd), r.stderr))
-        if obj is not None:
-            with open(obj + '.stamp', 'w') as f:
-                f.write(dg)
+        with open(stamp, 'w') as f:
+            f.write(dg)
         return r
 
     if jobs:
@@ -84,33 +94,36 @@ def build(force=False, verbose=True):
     # the register audits read the device assembly of THIS build and run before the link: a library whose asm-addressed kernels the
     # compiler broke (spills, accumulator-file traffic, copies of registers with loads in flight) must not be left on disk
     try:
-        _audit()
+        _audit(audited)
     except Exception:
         if os.path.exists(LIB):
             os.remove(LIB)
         raise
     ldg = hashlib.sha256(' '.join(stamps).encode()).hexdigest()
-    if force or jobs or not _fresh(LIB, ldg):
-        run(([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs, LIB, ldg))
+    # the library's stamp lives with the objects (csrc/build/, git-ignored): a checkout cannot deliver a stamp for a library it does not hold
+    lstamp = os.path.join(OBJ, 'libomp355.so.stamp')
+    if force or jobs or not _fresh(LIB, ldg, lstamp):
+        run(([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs, LIB, ldg, lstamp))
     return LIB
 
 
-def _audit():
+def _audit(audited):
     """gemm_4w names all 256 accumulator registers in asm; gemm_4w_r / _p and the decoders' row-owner kernel (csrc/dec_rows.hip) load
     operand fragments with asm statements and count the waits by hand: refuse a build in which the compiler spilled, used the
     accumulator file itself or copied a register with a load in flight (advancedliteratemachinery_amd/audit.py; silent corruption otherwise)."""
     from . import audit
-    asm = os.path.join(OBJ, 'gemm-hip-amdgcn-amd-amdhsa-gfx950.s')
-    if os.path.exists(asm):   # objects from an older build tree have none: the next rebuild of gemm.hip writes it
-        n, bad = audit.audit(asm)
+    for src, dg in audited.items():
+        asm, stem = _asm_of(src), src.replace('.hip', '')
+        astamp = os.path.join(OBJ, stem + '.o.audit.stamp')
+        if _fresh(os.path.join(OBJ, stem + '.o'), dg, astamp):
+            continue   # the assembly of exactly this object passed before
+        if not os.path.exists(asm):   # build() recompiles an audited source with neither stamp nor assembly: cannot happen
+            raise RuntimeError('%s register audit: %s is missing' % (stem, asm))
+        n, bad = audit.audit(asm) if src == 'gemm.hip' else audit.audit_dec_rows(asm)
         if bad or n == 0:
-            raise RuntimeError('gemm_4w register audit failed (%d kernels):\n%s' % (n, '\n'.join(bad) or 'no gemm_4w kernel found in ' + asm))
-    for stem in ('dec_rows', 'dec_rows_x3', 'kv_rows'):
-        asm = os.path.join(OBJ, '%s-hip-amdgcn-amd-amdhsa-gfx950.s' % stem)
-        if os.path.exists(asm):
-            n, bad = audit.audit_dec_rows(asm)
-            if bad or n == 0:
-                raise RuntimeError('%s register audit failed (%d kernels):\n%s' % (stem, n, '\n'.join(bad) or 'no row-owner kernel found in ' + asm))
+            raise RuntimeError('%s register audit failed (%d kernels):\n%s' % (stem, n, '\n'.join(bad) or 'no audited kernel found in ' + asm))
+        with open(astamp, 'w') as f:
+            f.write(dg)
 
 
 if __name__ == '__main__':

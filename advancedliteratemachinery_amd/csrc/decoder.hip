@@ -1698,115 +1698,111 @@ int launch_fused_self_attn(const omp_decoder_plan* P, const omp_dec_layer& L, bo
   return OMP_OK;
 }
 
-// Many-row phases of the bf16 engine (plan->rows_fused): the Linear layers as row-owner chains (csrc/dec_rows.hip) -- embedding | q k v,
-// then per layer self-attention, out-projection .. cross-attention query, cross-attention, out-projection .. FFN .. next layer's q k v (the
-// last layer: .. prediction head): 2 + 4 per layer launches instead of 11 per layer + 5.  Prefill positions run the head too (its
-// logits are not sampled): one kernel variant fewer.
-int step_launch_rows(const omp_decoder_plan* P, hipStream_t st) {
-  const int d = P->d_model, R = P->R, nL = P->n_layers;
-  const int vpad = (P->vocab + 127) / 128 * 128;
+// Many-row phases (plan->rows_fused): the Linear layers as row-owner chains (bf16 engine: csrc/dec_rows.hip; parity engine, plan->gemm_x3:
+// csrc/dec_rows_x3.hip -- three bf16 matrix-core products per Linear over split operands, fp32 self-attention, split-plane cross-attention) --
+// embedding | q k v, then per layer self-attention, out-projection .. cross-attention query, cross-attention, out-projection .. FFN .. next
+// layer's q k v (the last layer: .. prediction head): 2 + 4 per layer launches instead of 11 per layer + 5.  Prefill positions run the head too
+// (its logits are not sampled): one kernel variant fewer.  The step is cut at its cross-attention kernels (RowsStep::embed / pre_cross / cross /
+// post_cross) so that omp_decoder_run_pair can interleave TWO decoders' steps around them.
+struct RowsStep {
+  const omp_decoder_plan* P;
   omp_dec_rows_args a{};
-  a.R = R; a.eps = P->eps; a.d_pos = P->d_pos; a.x = P->x; a.att = P->att;
-  a.seq = P->seq; a.seq_ld = P->seq_ld; a.word_emb = P->word_emb; a.pos_tab = P->pos_tab; a.emb_g = P->emb_g; a.emb_b = P->emb_b;
-  a.qkv = P->qkv; a.q = P->q; a.logits = P->logits; a.vocab = P->vocab; a.h0_b = P->h0_b; a.h1_b = P->h1_b; a.h2_b = P->h2_b;
-  // layer 0's q | k | v behind the embedding
-  a.prologue = 1; a.tail = 0; a.wstream = P->rows_embed; a.wave_stride = 192 * 1024;
-  a.lnt_g = P->layers[0].n1_g; a.lnt_b = P->layers[0].n1_b; a.bias_tab = P->layers[0].sa_bias_tab;
-  RUN(omp_dec_rows_ffn(&a, st));
   CrossP cp;
-  cp.q = P->q; cp.ldq = d; cp.img_stride = P->kv_img_stride; cp.Mpad = P->Mpad;
-  cp.kmask = P->key_mask; cp.groups = P->tiles; cp.out = P->att; cp.ldo = d;
-  cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R; cp.kpw = 0; cp.lo_off = 0;
-  for (int li = 0; li < nL; ++li) {
+  bool x3;
+  int mul;       // bytes of a stream fragment pair over a bf16 fragment: the parity engine's streams hold (hi, lo) pairs
+  int64_t vfr;   // fragments of the vocabulary projection per wave
+
+  explicit RowsStep(const omp_decoder_plan* P_) : P(P_) {
+    const int d = P->d_model, R = P->R;
+    const int vpad = (P->vocab + 127) / 128 * 128;
+    x3 = P->gemm_x3 != 0;
+    mul = x3 ? 2 : 1;
+    vfr = (vpad / 512) * 64 + ((vpad % 512) / 128) * 16;
+    a.x3 = x3 ? 1 : 0;
+    a.R = R; a.eps = P->eps; a.d_pos = P->d_pos; a.x = P->x;
+    a.att = x3 ? P->ffh : P->att;   // x3: attention outputs as split pairs [R, 2 d] bf16 (the FFN hidden buffer is unused on this path)
+    a.seq = P->seq; a.seq_ld = P->seq_ld; a.word_emb = P->word_emb; a.pos_tab = P->pos_tab; a.emb_g = P->emb_g; a.emb_b = P->emb_b;
+    a.qkv = P->qkv; a.q = P->q; a.logits = P->logits; a.vocab = P->vocab; a.h0_b = P->h0_b; a.h1_b = P->h1_b; a.h2_b = P->h2_b;
+    cp.q = P->q; cp.ldq = d; cp.img_stride = P->kv_img_stride; cp.Mpad = P->Mpad;
+    cp.kmask = P->key_mask; cp.groups = P->tiles; cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R; cp.kpw = 0;
+    if (x3 && P->kv_split) { cp.out = P->ffh; cp.ldo = 2 * (int64_t)d; cp.lo_off = d; }   // the split-plane kernels write the chains' pair rows themselves
+    else { cp.out = P->att; cp.ldo = d; cp.lo_off = 0; }
+  }
+  // layer 0's q | k | v behind the embedding
+  int embed(hipStream_t st) {
+    a.prologue = 1; a.tail = 0; a.wstream = P->rows_embed; a.wave_stride = (int64_t)mul * 192 * 1024;
+    a.lnt_g = P->layers[0].n1_g; a.lnt_b = P->layers[0].n1_b; a.bias_tab = P->layers[0].sa_bias_tab;
+    return omp_dec_rows_ffn(&a, st);
+  }
+  // self-attention, then out-projection + residual, norm2, cross-attention query (the mid chain)
+  int pre_cross(int li, hipStream_t st) {
     const omp_dec_layer& L = P->layers[li];
-    cp.K = L.crossK; cp.V = L.crossVt;
-    RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, OMP_BF16, R, P->n_heads, d, P->Lmax, st));
-    a.wstream = L.rows_mid; a.wave_stride = 128 * 1024;
+    const int d = P->d_model, R = P->R;
+    RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, x3 ? OMP_F32 : OMP_BF16, R, P->n_heads, d, P->Lmax, st));
+    if (x3) RUN(omp_split_bf16(reinterpret_cast<const float*>(P->att), d, P->ffh, 2 * d, R, d, 0, st));
+    a.wstream = L.rows_mid; a.wave_stride = (int64_t)mul * 128 * 1024;
     a.out_b = L.sa_out_b; a.ln_g = L.n2_g; a.ln_b = L.n2_b; a.qbias_tab = L.ca_qbias_tab;
-    RUN(omp_dec_rows_mid(&a, st));
-    RUN(launch_cross(cp, P->n_tiles, OMP_BF16, P->n_split, P->q_tiles, st));
+    return omp_dec_rows_mid(&a, st);
+  }
+  int cross(int li, hipStream_t st) {
+    const omp_dec_layer& L = P->layers[li];
+    const int d = P->d_model, R = P->R;
+    cp.K = L.crossK; cp.V = L.crossVt;
+    if (!x3) return launch_cross(cp, P->n_tiles, OMP_BF16, P->n_split, P->q_tiles, st);
+    if (P->kv_split) return launch_cross(cp, P->n_tiles, OMP_BF16X2, P->n_split, P->q_tiles, st);
+    RUN(launch_cross(cp, P->n_tiles, OMP_F32, P->n_split, P->q_tiles, st));
+    return omp_split_bf16(reinterpret_cast<const float*>(P->att), d, P->ffh, 2 * d, R, d, 0, st);
+  }
+  // out-projection + residual, norm3, FFN, and the next layer's norm1 + q k v (last layer: final norm + prediction head)
+  int post_cross(int li, hipStream_t st) {
+    const omp_dec_layer& L = P->layers[li];
     a.prologue = 0; a.wstream = L.rows_ffn;
     a.out_b = L.ca_out_b; a.ln_g = L.n3_g; a.ln_b = L.n3_b; a.ff1_b = L.ff1_b; a.ff2_b = L.ff2_b;
-    if (li + 1 < nL) {
-      a.tail = 0; a.wave_stride = (64 + 16 * 32 + 192) * 1024;
+    if (li + 1 < P->n_layers) {
+      a.tail = 0; a.wave_stride = (int64_t)mul * (64 + 16 * 32 + 192) * 1024;
       a.lnt_g = P->layers[li + 1].n1_g; a.lnt_b = P->layers[li + 1].n1_b; a.bias_tab = P->layers[li + 1].sa_bias_tab;
     } else {
-      a.tail = 1; a.wave_stride = (int64_t)(64 + 16 * 32 + 128 + (vpad / 512) * 64 + ((vpad % 512) / 128) * 16) * 1024;
+      a.tail = 1; a.wave_stride = (int64_t)mul * (64 + 16 * 32 + 128 + vfr) * 1024;
       a.lnt_g = P->fn_g; a.lnt_b = P->fn_b;
     }
-    RUN(omp_dec_rows_ffn(&a, st));
+    return omp_dec_rows_ffn(&a, st);
+  }
+};
+
+int step_launch_rows(const omp_decoder_plan* P, hipStream_t st) {
+  RowsStep rs(P);
+  RUN(rs.embed(st));
+  for (int li = 0; li < P->n_layers; ++li) {
+    RUN(rs.pre_cross(li, st));
+    RUN(rs.cross(li, st));
+    RUN(rs.post_cross(li, st));
   }
   return OMP_OK;
 }
 
-// The same step for the parity engine (plan->gemm_x3 with rows_fused): the chains of csrc/dec_rows_x3.hip -- three bf16 matrix-core products per
-// Linear over split operands -- between the fp32 self-attention kernel and the split-plane cross-attention kernel.  The attention outputs reach
-// the chains as split pairs: the cross-attention kernels write them themselves (kv_split), the self-attention output goes through omp_split_bf16.
-int step_launch_rows_x3(const omp_decoder_plan* P, hipStream_t st) {
-  const int d = P->d_model, R = P->R, nL = P->n_layers, F = OMP_F32;
-  const int vpad = (P->vocab + 127) / 128 * 128;
-  void* as = P->ffh;   // attention outputs as split pairs [R, 2 d] bf16 (the FFN hidden buffer is unused on this path)
-  omp_dec_rows_args a{};
-  a.x3 = 1;
-  a.R = R; a.eps = P->eps; a.d_pos = P->d_pos; a.x = P->x; a.att = as;
-  a.seq = P->seq; a.seq_ld = P->seq_ld; a.word_emb = P->word_emb; a.pos_tab = P->pos_tab; a.emb_g = P->emb_g; a.emb_b = P->emb_b;
-  a.qkv = P->qkv; a.q = P->q; a.logits = P->logits; a.vocab = P->vocab; a.h0_b = P->h0_b; a.h1_b = P->h1_b; a.h2_b = P->h2_b;
-  a.prologue = 1; a.tail = 0; a.wstream = P->rows_embed; a.wave_stride = 2 * 192 * 1024;
-  a.lnt_g = P->layers[0].n1_g; a.lnt_b = P->layers[0].n1_b; a.bias_tab = P->layers[0].sa_bias_tab;
-  RUN(omp_dec_rows_ffn(&a, st));
-  CrossP cp;
-  cp.q = P->q; cp.ldq = d; cp.img_stride = P->kv_img_stride; cp.Mpad = P->Mpad;
-  cp.kmask = P->key_mask; cp.groups = P->tiles; cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R; cp.kpw = 0;
-  if (P->kv_split) { cp.out = as; cp.ldo = 2 * (int64_t)d; cp.lo_off = d; }
-  else { cp.out = P->att; cp.ldo = d; cp.lo_off = 0; }
-  for (int li = 0; li < nL; ++li) {
-    const omp_dec_layer& L = P->layers[li];
-    cp.K = L.crossK; cp.V = L.crossVt;
-    RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, F, R, P->n_heads, d, P->Lmax, st));
-    RUN(omp_split_bf16(reinterpret_cast<const float*>(P->att), d, as, 2 * d, R, d, 0, st));
-    a.wstream = L.rows_mid; a.wave_stride = 2 * 128 * 1024;
-    a.out_b = L.sa_out_b; a.ln_g = L.n2_g; a.ln_b = L.n2_b; a.qbias_tab = L.ca_qbias_tab;
-    RUN(omp_dec_rows_mid(&a, st));
-    if (P->kv_split) {
-      RUN(launch_cross(cp, P->n_tiles, OMP_BF16X2, P->n_split, P->q_tiles, st));
-    } else {
-      RUN(launch_cross(cp, P->n_tiles, F, P->n_split, P->q_tiles, st));
-      RUN(omp_split_bf16(reinterpret_cast<const float*>(P->att), d, as, 2 * d, R, d, 0, st));
-    }
-    a.prologue = 0; a.wstream = L.rows_ffn;
-    a.out_b = L.ca_out_b; a.ln_g = L.n3_g; a.ln_b = L.n3_b; a.ff1_b = L.ff1_b; a.ff2_b = L.ff2_b;
-    if (li + 1 < nL) {
-      a.tail = 0; a.wave_stride = 2 * (64 + 16 * 32 + 192) * 1024;
-      a.lnt_g = P->layers[li + 1].n1_g; a.lnt_b = P->layers[li + 1].n1_b; a.bias_tab = P->layers[li + 1].sa_bias_tab;
-    } else {
-      a.tail = 1; a.wave_stride = 2 * (int64_t)(64 + 16 * 32 + 128 + (vpad / 512) * 64 + ((vpad % 512) / 128) * 16) * 1024;
-      a.lnt_g = P->fn_g; a.lnt_b = P->fn_b;
-    }
-    RUN(omp_dec_rows_ffn(&a, st));
-  }
+int check_rows_plan(const omp_decoder_plan* P) {
+  const int d = P->d_model;
+  if (P->gemm_x3)
+    OMP_CHECK_ARG(P->dtype == OMP_F32 && P->pre_norm && d % 64 == 0 && P->d_ff % 64 == 0, "omp_decoder_run: gemm_x3 plans are fp32, pre-norm, widths multiples of 64");
+  else
+    OMP_CHECK_ARG(P->dtype == OMP_BF16 && P->pre_norm && !P->kv_split, "omp_decoder_run: rows_fused plans without gemm_x3 are bf16, pre-norm, plain slabs");
+  OMP_CHECK_ARG(d == 512 && P->d_ff == 2048 && P->n_heads == 8 && P->vocab % 4 == 0 && P->rows_embed != nullptr,
+                "omp_decoder_run: rows_fused plans are d_model 512 / d_ff 2048 / 8 heads, vocab %% 4 == 0, with packed streams bound");
+  for (int li = 0; li < P->n_layers; ++li)
+    OMP_CHECK_ARG(P->layers[li].rows_mid && P->layers[li].rows_ffn, "omp_decoder_run: rows_fused plan without the packed streams of layer %d", li);
   return OMP_OK;
 }
 
 int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
   const int d = P->d_model, R = P->R, T = P->dtype;
+  if (P->rows_fused) {
+    RUN(check_rows_plan(P));
+    return step_launch_rows(P, st);
+  }
   if (P->gemm_x3) {
     OMP_CHECK_ARG(T == OMP_F32 && P->pre_norm && R > 64 && d % 64 == 0 && P->d_ff % 64 == 0,
-                  "omp_decoder_run: gemm_x3 plans are fp32, pre-norm, more than 64 rows, widths multiples of 64");
-    if (P->rows_fused) {
-      OMP_CHECK_ARG(d == 512 && P->d_ff == 2048 && P->n_heads == 8 && P->vocab % 4 == 0 && P->rows_embed != nullptr,
-                    "omp_decoder_run: rows_fused plans are d_model 512 / d_ff 2048 / 8 heads, vocab %% 4 == 0, with packed streams bound");
-      for (int li = 0; li < P->n_layers; ++li)
-        OMP_CHECK_ARG(P->layers[li].rows_mid && P->layers[li].rows_ffn, "omp_decoder_run: rows_fused plan without the packed streams of layer %d", li);
-      return step_launch_rows_x3(P, st);
-    }
+                  "omp_decoder_run: gemm_x3 plans are fp32, pre-norm, more than 64 rows (any number on the row-owner chains), widths multiples of 64");
     return step_launch_x3(P, do_head, st);
-  }
-  if (P->rows_fused) {
-    OMP_CHECK_ARG(T == OMP_BF16 && P->pre_norm && d == 512 && P->d_ff == 2048 && P->n_heads == 8 && P->vocab % 4 == 0 && !P->kv_split && P->rows_embed != nullptr,
-                  "omp_decoder_run: rows_fused plans are bf16, pre-norm, d_model 512 / d_ff 2048 / 8 heads, vocab %% 4 == 0, with packed streams bound");
-    for (int li = 0; li < P->n_layers; ++li)
-      OMP_CHECK_ARG(P->layers[li].rows_mid && P->layers[li].rows_ffn, "omp_decoder_run: rows_fused plan without the packed streams of layer %d", li);
-    return step_launch_rows(P, st);
   }
   const bool fused = fused_step_ok(P);
   // embedding: pre-norm needs only the fp32 stream; post-norm also the T copy (fused: layer 0's first kernel embeds)
@@ -1975,6 +1971,81 @@ extern "C" int omp_decoder_run(const omp_decoder_plan* P, int first_pos, int n_s
     if (e != hipSuccess) { omp_set_error("omp_decoder_run: graph launch: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
   }
   return OMP_OK;
+}
+
+// Two decoders' many-row phases (polygon || recognition: transformer.py:252-284) as ONE interleaved schedule on two streams.
+// A step of a many-row phase alternates between two kinds of launches: the row-owner chains -- matrix-core work on at most HALF the compute
+// units (a 10 240-row launch is 128 workgroups, each holding its CU's LDS whole) -- and the cross-attention kernel, which streams K / V^T of
+// every image at the HBM rate the CUs it gets can draw (2.3 / 4.2 / 5.4 / 6.3 TB/s on 64 / 128 / 192 / 256 CUs, profiles/r02u_*).  Free-running
+// on two streams the two decoders fall into lock-step: both reach their cross-attention together (each at half rate: 438-464 us instead of
+// 230, profiles/r05m_q4_overlap_bf16.txt), then both run their chains together.  Here the cross-attention launches of the two decoders are
+// SERIALISED by events -- A.cross[l] -> B.cross[l] -> A.cross[l + 1] ... -- so that one decoder's chains (and its self-attention) always run
+// beside the OTHER decoder's cross-attention: the chain's 128 CUs compute while the remaining CUs stream.  Eager launches (a step is 19
+// launches of 20-280 us: the host stays far ahead); positions beyond the shorter decoder's last run as plain steps on its stream.
+extern "C" int omp_decoder_run_pair(const omp_decoder_plan* PA, const omp_decoder_plan* PB, int first_pos, int n_steps_a, int n_steps_b,
+                                    omp_stream_t sa, omp_stream_t sb) {
+  RUN(check_plan(PA));
+  RUN(check_plan(PB));
+  OMP_CHECK_ARG(PA->rows_fused && PB->rows_fused && PA->n_layers == PB->n_layers, "omp_decoder_run_pair: two rows_fused plans with the same number of layers");
+  RUN(check_rows_plan(PA));
+  RUN(check_rows_plan(PB));
+  OMP_CHECK_ARG(first_pos >= 0 && n_steps_a >= 0 && n_steps_b >= 0 && first_pos + n_steps_a <= PA->Lmax && first_pos + n_steps_b <= PB->Lmax,
+                "omp_decoder_run_pair: positions exceed Lmax");
+  OMP_CHECK_ARG(first_pos + n_steps_a + 1 <= PA->seq_ld && first_pos + n_steps_b + 1 <= PB->seq_ld, "omp_decoder_run_pair: seq_ld too small");
+  OMP_CHECK_ARG(sa != sb && sa != nullptr && sb != nullptr, "omp_decoder_run_pair: two distinct non-default streams");
+  hipStream_t st[2] = {(hipStream_t)sa, (hipStream_t)sb};
+  const omp_decoder_plan* P[2] = {PA, PB};
+  const int n[2] = {n_steps_a, n_steps_b};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  for (int k = 0; k < 2; ++k)
+    if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) {
+      if (ev[0]) (void)hipEventDestroy(ev[0]);
+      omp_set_error("omp_decoder_run_pair: hipEventCreate failed");
+      return OMP_ERR_LAUNCH;
+    }
+  RowsStep rs[2] = {RowsStep(PA), RowsStep(PB)};
+  auto finish = [&](int k, int pos) -> int {
+    if (pos >= P[k]->n_prompt - 1) return sample_and_advance(P[k], st[k]);
+    hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, st[k], P[k]->d_pos);
+    OMP_CHECK_LAUNCH("omp_decoder_run_pair(advance)");
+    return OMP_OK;
+  };
+  int rc = OMP_OK;
+  bool crossed = false;   // ev[1] has been recorded: A's next cross-attention waits for B's last
+  auto body = [&]() -> int {
+    const int steps = n[0] > n[1] ? n[0] : n[1];
+    for (int i = 0; i < steps; ++i) {
+      const int pos = first_pos + i;
+      const bool on[2] = {i < n[0], i < n[1]};
+      if (on[0] != on[1]) {   // the longer decoder alone
+        const int k = on[0] ? 0 : 1;
+        RUN(step_launch_rows(P[k], st[k]));
+        RUN(finish(k, pos));
+        continue;
+      }
+      RUN(rs[0].embed(st[0]));
+      RUN(rs[1].embed(st[1]));
+      for (int li = 0; li < PA->n_layers; ++li) {
+        RUN(rs[0].pre_cross(li, st[0]));
+        RUN(rs[1].pre_cross(li, st[1]));
+        if (crossed && hipStreamWaitEvent(st[0], ev[1], 0) != hipSuccess) { omp_set_error("omp_decoder_run_pair: stream wait failed"); return OMP_ERR_LAUNCH; }
+        RUN(rs[0].cross(li, st[0]));
+        if (hipEventRecord(ev[0], st[0]) != hipSuccess || hipStreamWaitEvent(st[1], ev[0], 0) != hipSuccess) { omp_set_error("omp_decoder_run_pair: event record / wait failed"); return OMP_ERR_LAUNCH; }
+        RUN(rs[1].cross(li, st[1]));
+        if (hipEventRecord(ev[1], st[1]) != hipSuccess) { omp_set_error("omp_decoder_run_pair: event record failed"); return OMP_ERR_LAUNCH; }
+        crossed = true;
+        RUN(rs[0].post_cross(li, st[0]));
+        RUN(rs[1].post_cross(li, st[1]));
+      }
+      RUN(finish(0, pos));
+      RUN(finish(1, pos));
+    }
+    return OMP_OK;
+  };
+  rc = body();
+  (void)hipEventDestroy(ev[0]);   // released once the recorded work has completed
+  (void)hipEventDestroy(ev[1]);
+  return rc;
 }
 
 extern "C" int omp_decoder_step_logits(const omp_decoder_plan* P, int pos, omp_stream_t s) {

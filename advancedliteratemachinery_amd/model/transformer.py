@@ -197,6 +197,9 @@ class Decoder(object):
         self._kv_streams = None  # packed Wk_all / Wv_all of the row-owner memory projection (bf16 engine, built on first use)
         self.kv_rows = env_flag('OMP355_KV_ROWS', True)   # False: the two tiled GEMMs with slab epilogues (A/B)
         self.rows_min = self.ROWS_MIN_ROWS
+        # polygon || recognition phases on the chains: their steps interleaved with serialised cross-attention launches (omp_decoder_run_pair);
+        # OMP355_PAIR=0: two free-running streams of step graphs (round 5; A/B)
+        self.pair_stagger = env_flag('OMP355_PAIR', True)
         self._x3_cache = {}   # kind -> (layers, head) with every matrix as its [w_hi | w_hi | w_lo] image (bf16x3 engine, R > 64)
 
     X3_MIN_ROWS = 65    # phases with more rows run their products as split-bf16 products (csrc/decoder.hip: step_launch_x3)
@@ -324,12 +327,14 @@ class Decoder(object):
         esz = 4 if self.dtype == torch.float32 else 2   # bytes per (key, dim): a split-plane pair is 2 x 2
         P.dtype, P.n_layers, P.d_model, P.n_heads, P.d_ff, P.vocab = ops.dt(self.dtype), self.L, d, self.nH, self.ff, self.V
         P.pre_norm = 1 if a.tfm_pre_norm else 0
-        use_x3 = bool(self.x3 and a.tfm_pre_norm and ph.R >= self.X3_MIN_ROWS and d % 64 == 0 and self.ff % 64 == 0)
+        # row-owner chains: the bf16 engine's (csrc/dec_rows.hip) or, on a gemm_x3 plan, the parity engine's (csrc/dec_rows_x3.hip).  A phase that
+        # takes the chains is a gemm_x3 plan whatever its row count (the tiled x3 GEMMs want more than 64 rows, the chains any number: the parity
+        # tests lower rows_min to put the fixtures' 1 .. 64-row phases on the benchmark's kernels)
+        rows_ok = bool(a.tfm_pre_norm and ph.R >= self.rows_min and d == 512 and self.ff == 2048 and self.nH == 8 and self.V % 4 == 0)
+        use_x3 = bool(self.x3 and a.tfm_pre_norm and (ph.R >= self.X3_MIN_ROWS or rows_ok) and d % 64 == 0 and self.ff % 64 == 0)
         P.gemm_x3 = 1 if use_x3 else 0
         P.kv_split = 1 if self.kv_split else 0
-        # row-owner chains: the bf16 engine's (csrc/dec_rows.hip) or, on a gemm_x3 plan, the parity engine's (csrc/dec_rows_x3.hip)
-        use_rows = bool((self.dtype == torch.bfloat16 or use_x3) and a.tfm_pre_norm and ph.R >= self.rows_min and d == 512 and self.ff == 2048
-                        and self.nH == 8 and self.V % 4 == 0)
+        use_rows = bool((self.dtype == torch.bfloat16 or use_x3) and rows_ok)
         P.rows_fused = 1 if use_rows else 0
         if use_rows:
             r_embed, r_layers = self._rows_streams(ph.kind)
@@ -528,6 +533,14 @@ class Decoder(object):
         with torch.cuda.stream(sr):
             phr = self.begin_instances('rec', kv, points, counts, rec_sos, rec_length, infer_vie)
         np_, nr = 2 + 32, 2 + rec_length
+        if self.pair_stagger and php.plan.rows_fused and phr.plan.rows_fused:
+            # both phases on the row-owner chains: ONE interleaved schedule whose cross-attention launches are serialised by events, so that one
+            # decoder's chains (half the compute units) run beside the other's HBM-bound cross-attention (csrc/decoder.hip: omp_decoder_run_pair)
+            rc = _lib.lib().omp_decoder_run_pair(ctypes.byref(php.plan), ctypes.byref(phr.plan), 0, np_, nr, sp.cuda_stream, sr.cuda_stream)
+            _lib.check(rc, 'omp_decoder_run_pair')
+            cur.wait_stream(sp)
+            cur.wait_stream(sr)
+            return self.instances_result(php), self.instances_result(phr)
         for pos in range(max(np_, nr)):
             if pos < np_:
                 with torch.cuda.stream(sp):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 19
+#define OMP_ABI_VERSION 20
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -386,6 +386,15 @@ typedef struct {
 int omp_decoder_run(const omp_decoder_plan* plan, int first_pos, int n_steps, int graph_slot,
                     omp_stream_t s);
 int omp_decoder_graph_reset(int graph_slot);
+/* Two decoders' many-row phases as ONE interleaved schedule on two streams (round 6; the polygon and recognition loops of
+ * Transformer.forward, transformer.py:252-284, which depend on the points only).  Both plans must be rows_fused plans with the same number
+ * of layers.  Positions first_pos .. first_pos + max(n_steps_a, n_steps_b) - 1: while both decoders have steps left their launches are
+ * interleaved and their cross-attention kernels serialised by events (a.cross[l] -> b.cross[l] -> a.cross[l + 1] ...), so that one decoder's
+ * row-owner chains -- matrix-core work on half the compute units -- always run beside the OTHER decoder's HBM-bound cross-attention instead
+ * of beside its own kind; the longer decoder finishes alone.  Eager launches on sa / sb (two distinct non-default streams); results are the
+ * same bits as two omp_decoder_run calls (the same kernels on the same operands: only WHEN they run changes). */
+int omp_decoder_run_pair(const omp_decoder_plan* plan_a, const omp_decoder_plan* plan_b, int first_pos, int n_steps_a, int n_steps_b,
+                         omp_stream_t sa, omp_stream_t sb);
 
 /* ---- Many-row decoder phases: the Linear chain between two attention kernels as ONE launch (round 5, csrc/dec_rows.hip) -----------
  * Replaces, for phases of thousands of rows (polygon / recognition decoders of a large engine call), the per-Linear launches of

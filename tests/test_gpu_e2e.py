@@ -32,6 +32,28 @@ def test_parity_engine_bf16x3(C, name):
     _assert_all(C.check_e2e(name, 'bf16x3'))
 
 
+# the decode path bench.py TIMES (row-owner chains, csrc/dec_rows*.hip; Swin stage-2 chain) under the reference's fixtures,
+# free-running.  (b) every fixture of the bench's shapes with the chains' row thresholds lowered to 1 -- the kernels and tiles of the 10 240-row
+# phases on the fixtures' 1 .. 64-row phases -- under the SAME gates as above; (a, c) test_decode_path_at_its_threshold below.
+@pytest.mark.parametrize('name', ['spot_1024_n40', 'spot_640_n64', 'kie_960x1280', 'spot_padded', 'spot_224'])
+def test_parity_engine_bf16x3_on_the_chains(C, name):
+    _assert_all(C.check_e2e(name, 'bf16x3', chains=True))
+
+
+@pytest.mark.parametrize('name', ['spot_1024_n40', 'spot_640_n64', 'spot_padded'])
+def test_config_shapes_bf16_on_the_chains(C, name):
+    _assert_all(C.check_e2e(name, 'bf16', chains=True))
+
+
+@pytest.mark.parametrize('dtype', ['bf16x3', 'bf16'])
+@pytest.mark.timeout(400, method='thread')
+def test_decode_path_at_its_threshold(C, dtype):
+    """64 x spot_640_n64 in ONE engine call = 4096 polygon / recognition rows: Decoder.rows_min engages the chains with no knob lowered.  Every
+    copy's ids against the reference's and against the same image submitted alone (batch == single ACROSS the threshold), teacher-forced logits
+    of all 4096 rows through the chains within 1e-3 of the reference's (parity engine; bf16: its relative gates).  transformer.py:252-284, 430-454."""
+    _assert_all(C.check_e2e_rows_threshold('spot_640_n64', dtype, 64))
+
+
 def test_parity_engine_bf16x3_graph(C):
     _assert_all(C.check_e2e('spot_1024', 'bf16x3', graph=True))
 
