@@ -43,7 +43,7 @@ class DecLayer(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
         'sa_in_w', 'sa_bias_tab', 'sa_out_w', 'sa_out_b', 'ca_q_w', 'ca_qbias_tab', 'ca_out_w',
         'ca_out_b', 'ff1_w', 'ff1_b', 'ff2_w', 'ff2_b', 'n1_g', 'n1_b', 'n2_g', 'n2_b', 'n3_g', 'n3_b',
-        'kcache', 'vcache', 'crossK', 'crossVt', 'rows_mid', 'rows_ffn')]
+        'kcache', 'vcache', 'crossK', 'crossVt', 'rows_mid', 'rows_ffn')] + [('rows_mid_stride', c_int64), ('rows_ffn_stride', c_int64)]
 
 
 class DecRowsArgs(ctypes.Structure):
@@ -53,7 +53,7 @@ class DecRowsArgs(ctypes.Structure):
                 ('prologue', c_int32), ('tail', c_int32), ('ff1_b', c_void_p), ('ff2_b', c_void_p), ('seq', c_void_p), ('seq_ld', c_int32),
                 ('word_emb', c_void_p), ('pos_tab', c_void_p), ('emb_g', c_void_p), ('emb_b', c_void_p), ('lnt_g', c_void_p), ('lnt_b', c_void_p),
                 ('bias_tab', c_void_p), ('qkv', c_void_p), ('h0_b', c_void_p), ('h1_b', c_void_p), ('h2_b', c_void_p), ('logits', c_void_p),
-                ('vocab', c_int32), ('x3', c_int32)]
+                ('vocab', c_int32), ('x3', c_int32), ('xcd_mask', c_int32)]
 
 
 class SwinRowsArgs(ctypes.Structure):
@@ -65,8 +65,8 @@ class SwinRowsArgs(ctypes.Structure):
 
 class DecoderPlan(ctypes.Structure):
     _fields_ = ([(n, c_int32) for n in ('dtype', 'n_layers', 'd_model', 'n_heads', 'd_ff', 'vocab',
-                                        'pre_norm', 'R', 'Lmax', 'M', 'Mpad', 'n_tiles', 'q_tiles', 'n_split', 'n_prompt', 'gemm_x3', 'kv_split', 'rows_fused')]
-                + [('eps', c_float), ('rows_embed', c_void_p), ('layers', DecLayer * MAX_DEC_LAYERS)]
+                                        'pre_norm', 'R', 'Lmax', 'M', 'Mpad', 'n_tiles', 'q_tiles', 'n_split', 'n_prompt', 'gemm_x3', 'kv_split', 'rows_fused', 'rows_xcd_mask')]
+                + [('eps', c_float), ('rows_embed', c_void_p), ('rows_embed_stride', c_int64), ('layers', DecLayer * MAX_DEC_LAYERS)]
                 + [(n, c_void_p) for n in ('word_emb', 'pos_tab', 'emb_g', 'emb_b', 'fn_g', 'fn_b',
                                            'h0_w', 'h1_w', 'h2_w', 'h0_b', 'h1_b', 'h2_b')]
                 + [('kv_img_stride', c_int64)]
@@ -115,7 +115,7 @@ _SIGS = {
     'omp_kv_project_rows': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_swin_rows_block': (c_int, [ctypes.POINTER(SwinRowsArgs), c_void_p]),
     'omp_decoder_run': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_int, c_int, c_void_p]),
-    'omp_decoder_run_pair': (c_int, [ctypes.POINTER(DecoderPlan), ctypes.POINTER(DecoderPlan), c_int, c_int, c_int, c_void_p, c_void_p]),
+    'omp_decoder_run_pair': (c_int, [ctypes.POINTER(DecoderPlan), ctypes.POINTER(DecoderPlan), c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'omp_decoder_graph_reset': (c_int, [c_int]),
     'omp_decoder_step_logits': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_void_p]),
     'omp_debug_force_gemm_kernel': (c_int, [c_int]),

@@ -53,6 +53,18 @@ omp_ctx& omp_cur() {
   return t_ctx != nullptr ? *t_ctx : default_ctx();
 }
 
+int omp_device_cus() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cus[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 extern "C" int omp_ctx_create(omp_ctx** out) {
   OMP_CHECK_ARG(out != nullptr, "omp_ctx_create: null pointer");
   omp_ctx* c = new omp_ctx();

@@ -86,6 +86,7 @@ struct omp_ctx {
   OmpProfClass* prof = nullptr;   // [OMP_PROF_NCLASS], owned by the context (api.hip)
 };
 omp_ctx& omp_cur();   // the calling thread's current context
+int omp_device_cus(); // compute units of the current device (cached per device; 256 when no device answers): api.hip
 
 bool omp_prof_active(int cls);
 int omp_prof_begin(int cls, hipStream_t st, double work, double bytes = 0.0);   // -> slot; bytes = algorithmic HBM bytes of the launch

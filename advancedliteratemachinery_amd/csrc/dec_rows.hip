@@ -328,6 +328,7 @@ struct RowsP {
   const float *h0_b, *h1_b, *h2_b;
   float* logits; int vocab;        // [R, vocab] fp32
   unsigned long long* trace;       // development (omp_debug_swin_mlp_trace): [workgroup][16] cycle sums of wave 0 per phase of dec_rows_ffn_kernel
+  int xcd_mask;                    // XCDs that run the launch's tiles (rows_common.inc xcd_tile); 0 = every block is a tile
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -341,7 +342,9 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_mid_kernel(RowsP p) {
   float* red = reinterpret_cast<float*>(smem + RT * A_PITCH + TILE_SLACK);      // 2 x NW x RT
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t r0 = (int64_t)blockIdx.x * RT;
+  const int tile_id = xcd_tile(p.xcd_mask);
+  if (tile_id < 0 || (int64_t)tile_id * RT >= p.R) return;   // a block of an XCD outside the mask, or beyond the last tile
+  const int64_t r0 = (int64_t)tile_id * RT;
   Stream st = stream_of_wave(p.wstream, p.wave_stride, wave, lane);
   u32x4 ring[PF];
   sfor<PF>([&](auto U) { ws_issue<decltype(U)::value>(ring, st); });
@@ -383,7 +386,9 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_ffn_kernel(RowsP p) {
   float* b1s = red + 2 * NW * RT;                                      // d_ff floats (PRO 0)
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t r0 = (int64_t)blockIdx.x * RT;
+  const int tile_id = xcd_tile(p.xcd_mask);
+  if (tile_id < 0 || (int64_t)tile_id * RT >= p.R) return;   // a block of an XCD outside the mask, or beyond the last tile
+  const int64_t r0 = (int64_t)tile_id * RT;
   Stream st = stream_of_wave(p.wstream, p.wave_stride, wave, lane);
   u32x4 ring[PF];
   sfor<PF>([&](auto U) { ws_issue<decltype(U)::value>(ring, st); });
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_ffn_kernel(RowsP p) {
   if (tracing && lane == 0) {
     tr[0] = __builtin_amdgcn_s_memtime() - t_begin;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) p.trace[(int64_t)blockIdx.x * 16 + i] = tr[i];
+    for (int i = 0; i < 12; ++i) p.trace[(int64_t)tile_id * 16 + i] = tr[i];
   }
 }
 
@@ -609,9 +614,20 @@ constexpr int RTT_DEFAULT = 5;   // 80 rows per workgroup: the Swin chains (thou
 int rows_rtt(int R, int lo = 2) {   // lo: the smallest tile the kernel is instantiated for (the mid chain also runs 16 rows: few-row phases)
   const int forced = omp_cur().rows_rtt;
   if (forced >= 2 && forced <= 5) return forced;
+  const int half = omp_device_cus() / 2;   // 128 on MI355X
   for (int rtt = lo; rtt < 5; ++rtt)
-    if (((int64_t)R + 16 * rtt - 1) / (16 * rtt) <= 128) return rtt;
+    if (((int64_t)R + 16 * rtt - 1) / (16 * rtt) <= half) return rtt;
   return 5;
+}
+
+// grid of a chain launch of n_tiles tiles under an XCD mask (rows_common.inc xcd_tile): the mask applies when the tiles fit the masked XCDs' CUs
+// in ONE round (32 CUs per XCD), else every block is a tile.  -> blocks; *mask_out = the mask the kernel gets
+unsigned xcd_grid(int64_t n_tiles, int mask, int* mask_out) {
+  mask &= 0xFF;
+  const int n_sel = __builtin_popcount((unsigned)mask);
+  if (mask == 0 || mask == 0xFF || n_tiles > (int64_t)n_sel * (omp_device_cus() / 8)) { *mask_out = 0; return (unsigned)n_tiles; }
+  *mask_out = mask;
+  return (unsigned)((n_tiles + n_sel - 1) / n_sel * 8);
 }
 
 template <typename K>
@@ -624,7 +640,7 @@ int raise_lds(K kern, const char* what) {
 }
 
 template <int RTT, int PRO, int TAIL, int ACT>
-int launch_ffn_t(const RowsP& p, hipStream_t st) {
+int launch_ffn_t(RowsP p, hipStream_t st) {
   constexpr int RT = RTT * 16;
   const size_t smem = (size_t)RT * A_PITCH + TILE_SLACK + RT * H_PITCH + TILE_SLACK + 2 * NW * RT * 4 + 4 * D * 4;
   auto kern = dec_rows_ffn_kernel<RTT, PRO, TAIL, ACT>;
@@ -634,7 +650,8 @@ int launch_ffn_t(const RowsP& p, hipStream_t st) {
     if (rc != OMP_OK) return rc;
     done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(((int64_t)p.R + RT - 1) / RT)), dim3(NW * 64), smem, st, p);
+  const unsigned grid = xcd_grid(((int64_t)p.R + RT - 1) / RT, p.xcd_mask, &p.xcd_mask);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, p);
   OMP_CHECK_LAUNCH("omp_dec_rows_ffn");
   return OMP_OK;
 }
@@ -654,7 +671,7 @@ int launch_ffn(const RowsP& p, hipStream_t st) {
 }
 
 template <int RTT>
-int launch_mid_t(const RowsP& p, hipStream_t st) {
+int launch_mid_t(RowsP p, hipStream_t st) {
   constexpr int RT = RTT * 16;
   const size_t smem = (size_t)RT * A_PITCH + TILE_SLACK + 2 * NW * RT * 4;
   auto kern = dec_rows_mid_kernel<RTT>;
@@ -664,7 +681,8 @@ int launch_mid_t(const RowsP& p, hipStream_t st) {
     if (rc != OMP_OK) return rc;
     done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(((int64_t)p.R + RT - 1) / RT)), dim3(NW * 64), smem, st, p);
+  const unsigned grid = xcd_grid(((int64_t)p.R + RT - 1) / RT, p.xcd_mask, &p.xcd_mask);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, p);
   return OMP_OK;
 }
 
@@ -676,7 +694,8 @@ extern "C" int omp_dec_rows_mid(const omp_dec_rows_args* a, omp_stream_t s) {
   OMP_CHECK_ARG(a != nullptr, "omp_dec_rows_mid: null argument block");
   OMP_CHECK_ARG(a->R > 0 && a->d_pos && a->x && a->att && a->wstream && a->out_b && a->ln_g && a->ln_b && a->qbias_tab && a->q, "omp_dec_rows_mid: null pointer");
   const int mul = a->x3 ? 2 : 1;
-  OMP_CHECK_ARG(a->wave_stride >= mul * 128 * 1024 && a->wave_stride % 16 == 0 && ((uintptr_t)a->wstream % 16) == 0, "omp_dec_rows_mid: a wave's stream holds %d fragments of 1 KB", mul * 128);
+  OMP_CHECK_ARG(a->wave_stride == (int64_t)mul * 128 * 1024 && ((uintptr_t)a->wstream % 16) == 0,
+                "omp_dec_rows_mid: a wave's stream holds %d fragments of 1 KB (wave_stride %lld: not what model/packing.py::pack_rows_mid returns)", mul * 128, (long long)a->wave_stride);
   if (a->x3) {
     const int slot3 = omp_prof_active(OMP_PROF_ROWS) ? omp_prof_begin(OMP_PROF_ROWS, (hipStream_t)s, 3 * 4.0 * (double)a->R * D * D, (double)a->R * D * (4 + 4 + 4 + 4) + 2.0 * D * D * 4) : -1;
     const int rc3 = omp_rows_x3_mid(a, (hipStream_t)s);
@@ -687,6 +706,7 @@ extern "C" int omp_dec_rows_mid(const omp_dec_rows_args* a, omp_stream_t s) {
   p.R = a->R; p.eps = a->eps; p.d_pos = a->d_pos; p.x = a->x; p.att = reinterpret_cast<const bf16_t*>(a->att);
   p.wstream = reinterpret_cast<const char*>(a->wstream); p.wave_stride = a->wave_stride;
   p.out_b = a->out_b; p.ln_g = a->ln_g; p.ln_b = a->ln_b; p.qbias_tab = a->qbias_tab; p.q = reinterpret_cast<bf16_t*>(a->q);
+  p.xcd_mask = a->xcd_mask;
   const int slot = omp_prof_active(OMP_PROF_ROWS) ? omp_prof_begin(OMP_PROF_ROWS, (hipStream_t)s, 4.0 * (double)a->R * D * D, (double)a->R * D * (2 + 4 + 4 + 2) + 2.0 * D * D * 2) : -1;
   int rc;
   switch (rows_rtt(p.R, 1)) {
@@ -714,7 +734,8 @@ extern "C" int omp_dec_rows_ffn(const omp_dec_rows_args* a, omp_stream_t s) {
   const int vpad = (a->vocab + 127) / 128 * 128;
   const int64_t frags = (a->prologue == 0 ? 64 + 16 * 32 : 0) + (a->tail == 0 ? 192 : 128 + (vpad / 512) * 64 + ((vpad % 512) / 128) * 16);
   const int mul = a->x3 ? 2 : 1;
-  OMP_CHECK_ARG(a->wave_stride >= mul * frags * 1024 && a->wave_stride % 16 == 0 && ((uintptr_t)a->wstream % 16) == 0, "omp_dec_rows_ffn: a wave's stream holds %lld fragments of 1 KB here", (long long)(mul * frags));
+  OMP_CHECK_ARG(a->wave_stride == mul * frags * 1024 && ((uintptr_t)a->wstream % 16) == 0,
+                "omp_dec_rows_ffn: a wave's stream holds %lld fragments of 1 KB here (wave_stride %lld: not what the packer of this chain returns)", (long long)(mul * frags), (long long)a->wave_stride);
   if (a->x3) {
     const double fl3 = 3 * 2.0 * (double)a->R * D * ((a->prologue == 0 ? D + 8.0 * D : 0.0) + (a->tail == 0 ? 3.0 * D : 2.0 * D + a->vocab));
     const int slot3 = omp_prof_active(OMP_PROF_ROWS) ? omp_prof_begin(OMP_PROF_ROWS, (hipStream_t)s, fl3, (double)a->R * D * (4 + 4 + 4) + (double)a->R * (a->tail == 0 ? 3 * D * 4 : a->vocab * 4) + (double)frags * 2 * 8192) : -1;
@@ -729,6 +750,7 @@ extern "C" int omp_dec_rows_ffn(const omp_dec_rows_args* a, omp_stream_t s) {
   p.seq = a->seq; p.seq_ld = a->seq_ld; p.word_emb = a->word_emb; p.pos_tab = a->pos_tab; p.emb_g = a->emb_g; p.emb_b = a->emb_b;
   p.lnt_g = a->lnt_g; p.lnt_b = a->lnt_b; p.bias_tab = a->bias_tab; p.qkv = reinterpret_cast<bf16_t*>(a->qkv);
   p.h0_b = a->h0_b; p.h1_b = a->h1_b; p.h2_b = a->h2_b; p.logits = a->logits; p.vocab = a->vocab;
+  p.xcd_mask = a->xcd_mask;
   hipStream_t st = (hipStream_t)s;
   const double fl = 2.0 * (double)a->R * D * ((a->prologue == 0 ? D + 8.0 * D : 0.0) + (a->tail == 0 ? 3.0 * D : 2.0 * D + a->vocab));
   const int slot = omp_prof_active(OMP_PROF_ROWS) ? omp_prof_begin(OMP_PROF_ROWS, st, fl, (double)a->R * D * (2 + 4 + 4) + (double)a->R * (a->tail == 0 ? 3 * D * 2 : a->vocab * 4) + (double)frags * 8192) : -1;
@@ -770,8 +792,8 @@ extern "C" int omp_swin_rows_block(const omp_swin_rows_args* a, omp_stream_t s) 
   else OMP_CHECK_ARG(a->att && a->proj_b && a->n2_g && a->n2_b && a->fc1_b && a->fc2_b && (!tail_qkv || (a->n1_b && a->qkv_b && a->qkv)), "omp_swin_rows_block: null pointer");
   const int64_t frags = (a->mode == 1 ? 64 + 8 * 64 : 0) + (tail_qkv ? 192 : 0);
   const int mul = a->x3 ? 2 : 1;
-  OMP_CHECK_ARG(a->wave_stride >= mul * frags * 1024 && a->wave_stride % 16 == 0 && ((uintptr_t)a->wstream % 16) == 0 && ((uintptr_t)a->x % 16) == 0,
-                "omp_swin_rows_block: a wave's stream holds %lld fragments of 1 KB here; 16-byte aligned pointers", (long long)(mul * frags));
+  OMP_CHECK_ARG(a->wave_stride == mul * frags * 1024 && ((uintptr_t)a->wstream % 16) == 0 && ((uintptr_t)a->x % 16) == 0,
+                "omp_swin_rows_block: a wave's stream holds %lld fragments of 1 KB here (wave_stride %lld: not what the packer returns); 16-byte aligned pointers", (long long)(mul * frags), (long long)a->wave_stride);
   if (a->x3) {
     const double fl3 = 3 * 2.0 * (double)a->M * D * ((a->mode == 1 ? D + 8.0 * D : 0.0) + (tail_qkv ? 3.0 * D : 0.0));
     const double by3 = (double)a->M * D * (a->mode == 1 ? 4 + 4 + 4 : 4) + (tail_qkv ? (double)a->M * 3 * D * 4 : 0.0) + (double)frags * 2 * 8192;

@@ -1551,13 +1551,27 @@ extern "C" int omp_dec_cross_attn_step(const void* q, int64_t ldq, const void* K
 }
 
 namespace {
-int sample_block_max_rows() {   // up to this many rows a WORKGROUP per row samples (few-row phases: latency), beyond a wave per row with the row in registers
-  static const int v = [] {
-    const char* e = getenv("OMP355_SAMPLE_BLOCK_MAX_ROWS");
-    const long x = e ? strtol(e, nullptr, 10) : 1024;
-    return (int)(x < 0 ? 0 : (x > (1 << 30) ? (1 << 30) : x));
-  }();
+// OMP355_SAMPLE_BLOCK_MAX_ROWS (A/B knob): parsed strictly -- a value that is not a non-negative integer is an ERROR of every decoder run
+// (check_plan), not a silently different sampling kernel (strtol turned garbage into 0)
+struct SampleEnv { int rows; bool ok; };
+SampleEnv strict_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  if (e == nullptr || *e == 0) return SampleEnv{dflt, true};
+  char* end = nullptr;
+  const long x = strtol(e, &end, 10);
+  if (end == e || *end != 0 || x < 0) return SampleEnv{dflt, false};
+  return SampleEnv{(int)(x > (1 << 30) ? (1 << 30) : x), true};
+}
+const SampleEnv& sample_env() {
+  static const SampleEnv v = strict_env_int("OMP355_SAMPLE_BLOCK_MAX_ROWS", 1024);
   return v;
+}
+const SampleEnv& fused_sa_env() {
+  static const SampleEnv v = strict_env_int("OMP355_FUSED_SA_MAX_ROWS", 63);
+  return v;
+}
+int sample_block_max_rows() {   // up to this many rows a WORKGROUP per row samples (few-row phases: latency), beyond a wave per row with the row in registers
+  return sample_env().rows;
 }
 }  // namespace
 
@@ -1676,8 +1690,7 @@ int ln_gemm(const omp_decoder_plan* P, const float* g, const float* b, const voi
 // workgroup repeating LayerNorm2 + 64 x 512 weights costs 26.4 us against 16.7 + 8.5 us for the two launches, also with the
 // projection operands requested ahead of the K / V^T prefetch -- profiles/r03d_prof8_pt_step_timeline.txt.  Removed.)
 int fused_sa_max_rows() {   // beyond: the workgroups' repeated weight streams (192 KB per 4 rows) cost more than the launches
-  static const int v = [] { const char* e = getenv("OMP355_FUSED_SA_MAX_ROWS"); return e ? atoi(e) : 63; }();
-  return v;
+  return fused_sa_env().rows;
 }
 bool fused_step_ok(const omp_decoder_plan* P) {
   return omp_cur().dec_fused != 1 && P->pre_norm && P->dtype == OMP_BF16 && P->d_model == 512 && P->n_heads == 8 && P->R <= fused_sa_max_rows();
@@ -1709,20 +1722,16 @@ struct RowsStep {
   omp_dec_rows_args a{};
   CrossP cp;
   bool x3;
-  int mul;       // bytes of a stream fragment pair over a bf16 fragment: the parity engine's streams hold (hi, lo) pairs
-  int64_t vfr;   // fragments of the vocabulary projection per wave
 
   explicit RowsStep(const omp_decoder_plan* P_) : P(P_) {
     const int d = P->d_model, R = P->R;
-    const int vpad = (P->vocab + 127) / 128 * 128;
     x3 = P->gemm_x3 != 0;
-    mul = x3 ? 2 : 1;
-    vfr = (vpad / 512) * 64 + ((vpad % 512) / 128) * 16;
     a.x3 = x3 ? 1 : 0;
     a.R = R; a.eps = P->eps; a.d_pos = P->d_pos; a.x = P->x;
     a.att = x3 ? P->ffh : P->att;   // x3: attention outputs as split pairs [R, 2 d] bf16 (the FFN hidden buffer is unused on this path)
     a.seq = P->seq; a.seq_ld = P->seq_ld; a.word_emb = P->word_emb; a.pos_tab = P->pos_tab; a.emb_g = P->emb_g; a.emb_b = P->emb_b;
     a.qkv = P->qkv; a.q = P->q; a.logits = P->logits; a.vocab = P->vocab; a.h0_b = P->h0_b; a.h1_b = P->h1_b; a.h2_b = P->h2_b;
+    a.xcd_mask = P->rows_xcd_mask;
     cp.q = P->q; cp.ldq = d; cp.img_stride = P->kv_img_stride; cp.Mpad = P->Mpad;
     cp.kmask = P->key_mask; cp.groups = P->tiles; cp.partial = P->partial; cp.M = P->M; cp.nH = P->n_heads; cp.R = R; cp.kpw = 0;
     if (x3 && P->kv_split) { cp.out = P->ffh; cp.ldo = 2 * (int64_t)d; cp.lo_off = d; }   // the split-plane kernels write the chains' pair rows themselves
@@ -1730,7 +1739,7 @@ struct RowsStep {
   }
   // layer 0's q | k | v behind the embedding
   int embed(hipStream_t st) {
-    a.prologue = 1; a.tail = 0; a.wstream = P->rows_embed; a.wave_stride = (int64_t)mul * 192 * 1024;
+    a.prologue = 1; a.tail = 0; a.wstream = P->rows_embed; a.wave_stride = P->rows_embed_stride;   // the packer's own count: omp_dec_rows_* demand equality
     a.lnt_g = P->layers[0].n1_g; a.lnt_b = P->layers[0].n1_b; a.bias_tab = P->layers[0].sa_bias_tab;
     return omp_dec_rows_ffn(&a, st);
   }
@@ -1740,7 +1749,7 @@ struct RowsStep {
     const int d = P->d_model, R = P->R;
     RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, x3 ? OMP_F32 : OMP_BF16, R, P->n_heads, d, P->Lmax, st));
     if (x3) RUN(omp_split_bf16(reinterpret_cast<const float*>(P->att), d, P->ffh, 2 * d, R, d, 0, st));
-    a.wstream = L.rows_mid; a.wave_stride = (int64_t)mul * 128 * 1024;
+    a.wstream = L.rows_mid; a.wave_stride = L.rows_mid_stride;
     a.out_b = L.sa_out_b; a.ln_g = L.n2_g; a.ln_b = L.n2_b; a.qbias_tab = L.ca_qbias_tab;
     return omp_dec_rows_mid(&a, st);
   }
@@ -1756,13 +1765,13 @@ struct RowsStep {
   // out-projection + residual, norm3, FFN, and the next layer's norm1 + q k v (last layer: final norm + prediction head)
   int post_cross(int li, hipStream_t st) {
     const omp_dec_layer& L = P->layers[li];
-    a.prologue = 0; a.wstream = L.rows_ffn;
+    a.prologue = 0; a.wstream = L.rows_ffn; a.wave_stride = L.rows_ffn_stride;
     a.out_b = L.ca_out_b; a.ln_g = L.n3_g; a.ln_b = L.n3_b; a.ff1_b = L.ff1_b; a.ff2_b = L.ff2_b;
     if (li + 1 < P->n_layers) {
-      a.tail = 0; a.wave_stride = (int64_t)mul * (64 + 16 * 32 + 192) * 1024;
+      a.tail = 0;
       a.lnt_g = P->layers[li + 1].n1_g; a.lnt_b = P->layers[li + 1].n1_b; a.bias_tab = P->layers[li + 1].sa_bias_tab;
     } else {
-      a.tail = 1; a.wave_stride = (int64_t)mul * (64 + 16 * 32 + 128 + vfr) * 1024;
+      a.tail = 1;
       a.lnt_g = P->fn_g; a.lnt_b = P->fn_b;
     }
     return omp_dec_rows_ffn(&a, st);
@@ -1821,7 +1830,7 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
   bool mid_chain = !fused && omp_cur().dec_fused != 1 && T == OMP_BF16 && P->pre_norm && d == 512 && P->n_heads == 8 && !P->kv_split && R >= 16;
   for (int li = 0; li < P->n_layers && mid_chain; ++li) mid_chain = P->layers[li].rows_mid != nullptr;
   omp_dec_rows_args ma{};
-  ma.R = R; ma.eps = P->eps; ma.d_pos = P->d_pos; ma.x = P->x; ma.att = P->att; ma.q = P->q; ma.wave_stride = 128 * 1024;
+  ma.R = R; ma.eps = P->eps; ma.d_pos = P->d_pos; ma.x = P->x; ma.att = P->att; ma.q = P->q;
   for (int li = 0; li < P->n_layers; ++li) {
     const omp_dec_layer& L = P->layers[li];
     cp.K = L.crossK; cp.V = L.crossVt;
@@ -1833,7 +1842,7 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
         RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, T, R, P->n_heads, d, P->Lmax, st));
       }
       if (mid_chain) {   // out-projection + residual, norm2, cross-attention query: ONE launch (csrc/dec_rows.hip) instead of three
-        ma.wstream = L.rows_mid; ma.out_b = L.sa_out_b; ma.ln_g = L.n2_g; ma.ln_b = L.n2_b; ma.qbias_tab = L.ca_qbias_tab;
+        ma.wstream = L.rows_mid; ma.wave_stride = L.rows_mid_stride; ma.out_b = L.sa_out_b; ma.ln_g = L.n2_g; ma.ln_b = L.n2_b; ma.qbias_tab = L.ca_qbias_tab;
         RUN(omp_dec_rows_mid(&ma, st));
       } else {
         RUN(gemm(P, P->att, d, L.sa_out_w, d, d, L.sa_out_b, nullptr, 0, P->x, P->x, OMP_F32, OMP_ACT_NONE, st));
@@ -1867,6 +1876,7 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
 
 int check_plan(const omp_decoder_plan* P) {
   OMP_CHECK_ARG(P != nullptr, "omp_decoder_run: null plan");
+  OMP_CHECK_ARG(sample_env().ok && fused_sa_env().ok, "omp_decoder_run: OMP355_SAMPLE_BLOCK_MAX_ROWS / OMP355_FUSED_SA_MAX_ROWS must be non-negative integers");
   OMP_CHECK_ARG(P->dtype == OMP_F32 || P->dtype == OMP_BF16, "omp_decoder_run: bad dtype");
   OMP_CHECK_ARG(P->n_layers > 0 && P->n_layers <= OMP_MAX_DEC_LAYERS, "omp_decoder_run: bad n_layers %d", P->n_layers);
   OMP_CHECK_ARG(P->d_model == P->n_heads * DH, "omp_decoder_run: head_dim must be 64");
@@ -1973,17 +1983,20 @@ extern "C" int omp_decoder_run(const omp_decoder_plan* P, int first_pos, int n_s
   return OMP_OK;
 }
 
-// Two decoders' many-row phases (polygon || recognition: transformer.py:252-284) as ONE interleaved schedule on two streams.
+// Two decoders' many-row phases (polygon || recognition: transformer.py:252-284) as ONE interleaved schedule on three streams.
 // A step of a many-row phase alternates between two kinds of launches: the row-owner chains -- matrix-core work on at most HALF the compute
 // units (a 10 240-row launch is 128 workgroups, each holding its CU's LDS whole) -- and the cross-attention kernel, which streams K / V^T of
 // every image at the HBM rate the CUs it gets can draw (2.3 / 4.2 / 5.4 / 6.3 TB/s on 64 / 128 / 192 / 256 CUs, profiles/r02u_*).  Free-running
 // on two streams the two decoders fall into lock-step: both reach their cross-attention together (each at half rate: 438-464 us instead of
-// 230, profiles/r05m_q4_overlap_bf16.txt), then both run their chains together.  Here the cross-attention launches of the two decoders are
-// SERIALISED by events -- A.cross[l] -> B.cross[l] -> A.cross[l + 1] ... -- so that one decoder's chains (and its self-attention) always run
-// beside the OTHER decoder's cross-attention: the chain's 128 CUs compute while the remaining CUs stream.  Eager launches (a step is 19
-// launches of 20-280 us: the host stays far ahead); positions beyond the shorter decoder's last run as plain steps on its stream.
+// 230, profiles/r05m_q4_overlap_bf16.txt), then both run their chains together.  Here ALL cross-attention launches go to ONE stream sx in the
+// order A[0], B[0], A[1], B[1] ... (serialised by the stream itself), each behind an event of its decoder's chain stream, and each chain stream
+// waits for its decoder's cross-attention by an event of sx: one decoder's chains (and its self-attention) then run beside the OTHER decoder's
+// cross-attention.  sa / sb should be HIGHER-priority streams than sx: a chain workgroup needs a whole CU's LDS, so it only gets a CU at the
+// moment the previous cross-attention launch has drained -- the same moment the next one becomes ready -- and the queue priority decides who
+// is placed first (with equal priorities the 1280 cross-attention workgroups take every CU and the chains wait: measured, no gain).
+// Eager launches (a step is 19 launches of 20-280 us: the host stays far ahead); positions beyond the shorter decoder's last run alone.
 extern "C" int omp_decoder_run_pair(const omp_decoder_plan* PA, const omp_decoder_plan* PB, int first_pos, int n_steps_a, int n_steps_b,
-                                    omp_stream_t sa, omp_stream_t sb) {
+                                    omp_stream_t sa, omp_stream_t sb, omp_stream_t sx_) {
   RUN(check_plan(PA));
   RUN(check_plan(PB));
   OMP_CHECK_ARG(PA->rows_fused && PB->rows_fused && PA->n_layers == PB->n_layers, "omp_decoder_run_pair: two rows_fused plans with the same number of layers");
@@ -1992,14 +2005,15 @@ extern "C" int omp_decoder_run_pair(const omp_decoder_plan* PA, const omp_decode
   OMP_CHECK_ARG(first_pos >= 0 && n_steps_a >= 0 && n_steps_b >= 0 && first_pos + n_steps_a <= PA->Lmax && first_pos + n_steps_b <= PB->Lmax,
                 "omp_decoder_run_pair: positions exceed Lmax");
   OMP_CHECK_ARG(first_pos + n_steps_a + 1 <= PA->seq_ld && first_pos + n_steps_b + 1 <= PB->seq_ld, "omp_decoder_run_pair: seq_ld too small");
-  OMP_CHECK_ARG(sa != sb && sa != nullptr && sb != nullptr, "omp_decoder_run_pair: two distinct non-default streams");
+  OMP_CHECK_ARG(sa != sb && sa != sx_ && sb != sx_ && sa != nullptr && sb != nullptr && sx_ != nullptr, "omp_decoder_run_pair: three distinct non-default streams");
   hipStream_t st[2] = {(hipStream_t)sa, (hipStream_t)sb};
+  hipStream_t sx = (hipStream_t)sx_;
   const omp_decoder_plan* P[2] = {PA, PB};
   const int n[2] = {n_steps_a, n_steps_b};
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  for (int k = 0; k < 2; ++k)
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // [k]: decoder k's chain stream has reached its cross-attention; [2]: sx has finished a cross-attention
+  for (int k = 0; k < 3; ++k)
     if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) {
-      if (ev[0]) (void)hipEventDestroy(ev[0]);
+      for (int j = 0; j < k; ++j) (void)hipEventDestroy(ev[j]);
       omp_set_error("omp_decoder_run_pair: hipEventCreate failed");
       return OMP_ERR_LAUNCH;
     }
@@ -2010,14 +2024,19 @@ extern "C" int omp_decoder_run_pair(const omp_decoder_plan* PA, const omp_decode
     OMP_CHECK_LAUNCH("omp_decoder_run_pair(advance)");
     return OMP_OK;
   };
-  int rc = OMP_OK;
-  bool crossed = false;   // ev[1] has been recorded: A's next cross-attention waits for B's last
+  // decoder k's cross-attention of layer li on sx, between its chain stream's "ready" event and the event that releases the chain stream again
+  auto cross_on_sx = [&](int k, int li) -> int {
+    if (hipEventRecord(ev[k], st[k]) != hipSuccess || hipStreamWaitEvent(sx, ev[k], 0) != hipSuccess) { omp_set_error("omp_decoder_run_pair: event record / wait failed"); return OMP_ERR_LAUNCH; }
+    RUN(rs[k].cross(li, sx));
+    if (hipEventRecord(ev[2], sx) != hipSuccess || hipStreamWaitEvent(st[k], ev[2], 0) != hipSuccess) { omp_set_error("omp_decoder_run_pair: event record / wait failed"); return OMP_ERR_LAUNCH; }
+    return OMP_OK;
+  };
   auto body = [&]() -> int {
     const int steps = n[0] > n[1] ? n[0] : n[1];
     for (int i = 0; i < steps; ++i) {
       const int pos = first_pos + i;
       const bool on[2] = {i < n[0], i < n[1]};
-      if (on[0] != on[1]) {   // the longer decoder alone
+      if (on[0] != on[1]) {   // the longer decoder alone, on its own stream
         const int k = on[0] ? 0 : 1;
         RUN(step_launch_rows(P[k], st[k]));
         RUN(finish(k, pos));
@@ -2028,23 +2047,19 @@ extern "C" int omp_decoder_run_pair(const omp_decoder_plan* PA, const omp_decode
       for (int li = 0; li < PA->n_layers; ++li) {
         RUN(rs[0].pre_cross(li, st[0]));
         RUN(rs[1].pre_cross(li, st[1]));
-        if (crossed && hipStreamWaitEvent(st[0], ev[1], 0) != hipSuccess) { omp_set_error("omp_decoder_run_pair: stream wait failed"); return OMP_ERR_LAUNCH; }
-        RUN(rs[0].cross(li, st[0]));
-        if (hipEventRecord(ev[0], st[0]) != hipSuccess || hipStreamWaitEvent(st[1], ev[0], 0) != hipSuccess) { omp_set_error("omp_decoder_run_pair: event record / wait failed"); return OMP_ERR_LAUNCH; }
-        RUN(rs[1].cross(li, st[1]));
-        if (hipEventRecord(ev[1], st[1]) != hipSuccess) { omp_set_error("omp_decoder_run_pair: event record failed"); return OMP_ERR_LAUNCH; }
-        crossed = true;
+        RUN(cross_on_sx(0, li));
+        RUN(cross_on_sx(1, li));
         RUN(rs[0].post_cross(li, st[0]));
         RUN(rs[1].post_cross(li, st[1]));
       }
       RUN(finish(0, pos));
       RUN(finish(1, pos));
     }
+    // sx has run ahead of nothing: its last cross-attention is awaited by a chain stream; the caller joins sa and sb
     return OMP_OK;
   };
-  rc = body();
-  (void)hipEventDestroy(ev[0]);   // released once the recorded work has completed
-  (void)hipEventDestroy(ev[1]);
+  const int rc = body();
+  for (int k = 0; k < 3; ++k) (void)hipEventDestroy(ev[k]);   // released once the recorded work has completed
   return rc;
 }
 

@@ -232,7 +232,7 @@ def validate(model, dataloader, epoch, args, batch_size=1):
     pred = getattr(args, 'eos_pred_counts', None)
     kie = args.vie_categories > 0
     local_raw, local_meta = [], []
-    pend_imgs, pend_tg = [], []
+    pend_imgs, pend_tg, pend_key = [], [], []
     if pred is not None and not sharded:
         # balanced shards + homogeneous batches (plan_eos_balance): this rank's images in plan order, engine calls cut where the plan cuts;
         # every meta carries its dataset index so that rank 0 restores dataset order before formatting (the JSON is the unbalanced run's)
@@ -256,20 +256,27 @@ def validate(model, dataloader, epoch, args, batch_size=1):
             return
         raw, _ = predict_raw(model, list(pend_imgs), args, [t['orig_size'] for t in pend_tg] if args.infer_vie else None)
         local_raw.extend(raw)
-        for t in pend_tg:
+        for t, key in zip(pend_tg, pend_key):
             m = _meta(t)
-            m['_idx'] = order[len(local_meta)] if order is not None else lo + len(local_meta)
+            m['_idx'] = key
             local_meta.append(m)
-        del pend_imgs[:], pend_tg[:]
+        del pend_imgs[:], pend_tg[:], pend_key[:]
 
-    for samples, targets in items:
+    # Sort key of an image = (shard, ITEM index, image inside the item): `lo`, `order` and `cuts` count dataloader ITEMS, and an item may hold
+    # several images (counting images there let the ranks' keys overlap and cut the balanced plan in the wrong places).  A loader that
+    # is already rank-sharded has no global item index: its ranks' parts stay in rank order (shard = rank), as the gather delivers them.
+    for it, (samples, targets) in enumerate(items):
         nt = _as_nested(samples)
-        for img, t in zip(nt.unpad_tensors(), targets):
+        item = order[it] if order is not None else lo + it
+        for k, (img, t) in enumerate(zip(nt.unpad_tensors(), targets)):
             pend_imgs.append(img)
             pend_tg.append(t)
-            seen[0] += 1
-            if (cuts is not None and seen[0] in cuts) or (cuts is None and len(pend_imgs) >= max(1, int(batch_size))):
+            pend_key.append((rank if sharded else 0, item, k))
+            if cuts is None and len(pend_imgs) >= max(1, int(batch_size)):
                 flush()
+        seen[0] += 1
+        if cuts is not None and seen[0] in cuts:   # the plan cuts between ITEMS
+            flush()
     flush()
 
     folder = os.path.join(args.output_folder, 'results', 'ep%03d' % epoch) if getattr(args, 'output_folder', None) else None

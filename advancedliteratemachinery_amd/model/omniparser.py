@@ -99,7 +99,10 @@ class OmniParser(nn.Module):
         if not self.overlap_decoders:
             return None
         if self._streams is None or self._streams[0].device != dev:
-            self._streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            # high priority: in the paired schedule of the many-row phases (Decoder.decode_poly_and_rec) these carry the row-owner chains, which must be
+            # placed BEFORE the cross-attention workgroups of the caller's (normal-priority) stream when a launch drains (omp_decoder_run_pair)
+            pr = -1 if env_flag('OMP355_SIDE_PRIO', True) else 0
+            self._streams = (torch.cuda.Stream(device=dev, priority=pr), torch.cuda.Stream(device=dev, priority=pr))
         return self._streams
 
     def set_engine_dtype(self, dtype):

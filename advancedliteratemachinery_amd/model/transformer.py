@@ -199,7 +199,9 @@ class Decoder(object):
         self.rows_min = self.ROWS_MIN_ROWS
         # polygon || recognition phases on the chains: their steps interleaved with serialised cross-attention launches (omp_decoder_run_pair);
         # OMP355_PAIR=0: two free-running streams of step graphs (round 5; A/B)
-        self.pair_stagger = env_flag('OMP355_PAIR', True)
+        self.pair_stagger = env_flag('OMP355_PAIR', False)
+        # XCD placement of the many-row chains per decoder kind (omp_decoder_plan.rows_xcd_mask); OMP355_XCD_SPLIT=0: every launch on all eight
+        self.xcd_masks = {'poly': 0x0F, 'rec': 0xF0} if env_flag('OMP355_XCD_SPLIT', True) else {}
         self._x3_cache = {}   # kind -> (layers, head) with every matrix as its [w_hi | w_hi | w_lo] image (bf16x3 engine, R > 64)
 
     X3_MIN_ROWS = 65    # phases with more rows run their products as split-bf16 products (csrc/decoder.hip: step_launch_x3)
@@ -215,14 +217,16 @@ class Decoder(object):
         (embed, [(mid, ffn) per layer]); the last layer's ffn stream ends in the prediction head."""
         if kind not in self._rows_cache:
             Ls, hd = self.layers[kind], self.head[kind]
-            embed = packing.pack_rows_embed_qkv(Ls[0]['sa_in_w'])[0]
+            if tuple(hd[0][0].shape) != (self.d, self.d) or tuple(hd[1][0].shape) != (self.d, self.d) or hd[2][0].shape[1] != self.d:
+                raise ValueError('row-owner chains: the prediction head must be %d -> %d -> %d -> vocab' % (self.d, self.d, self.d))
+            embed = packing.pack_rows_embed_qkv(Ls[0]['sa_in_w'])   # every entry: (stream buffer, bytes per wave) as the packer returns them
             per = []
             for l, w in enumerate(Ls):
-                mid = packing.pack_rows_mid(w['sa_out_w'], w['ca_q_w'])[0]
+                mid = packing.pack_rows_mid(w['sa_out_w'], w['ca_q_w'])
                 if l + 1 < len(Ls):
-                    ffn = packing.pack_rows_ffn_qkv(w['ca_out_w'], w['ff1_w'], w['ff2_w'], Ls[l + 1]['sa_in_w'])[0]
+                    ffn = packing.pack_rows_ffn_qkv(w['ca_out_w'], w['ff1_w'], w['ff2_w'], Ls[l + 1]['sa_in_w'])
                 else:
-                    ffn = packing.pack_rows_ffn_head(w['ca_out_w'], w['ff1_w'], w['ff2_w'], hd[0][0], hd[1][0], hd[2][0])[0]
+                    ffn = packing.pack_rows_ffn_head(w['ca_out_w'], w['ff1_w'], w['ff2_w'], hd[0][0], hd[1][0], hd[2][0])
                 per.append((mid, ffn))
             self._rows_cache[kind] = (embed, per)
         return self._rows_cache[kind]
@@ -235,7 +239,7 @@ class Decoder(object):
             if kind in self._rows_cache:
                 self._rows_cache[key] = [m for m, _ in self._rows_cache[kind][1]]
             else:
-                self._rows_cache[key] = [packing.pack_rows_mid(w['sa_out_w'], w['ca_q_w'])[0] for w in self.layers[kind]]
+                self._rows_cache[key] = [packing.pack_rows_mid(w['sa_out_w'], w['ca_q_w']) for w in self.layers[kind]]
         return self._rows_cache[key]
 
     def _x3_weights(self, kind):
@@ -338,9 +342,12 @@ class Decoder(object):
         P.rows_fused = 1 if use_rows else 0
         if use_rows:
             r_embed, r_layers = self._rows_streams(ph.kind)
-            P.rows_embed = r_embed.data_ptr()
+            P.rows_embed, P.rows_embed_stride = r_embed[0].data_ptr(), r_embed[1]
         else:
-            P.rows_embed = None
+            P.rows_embed, P.rows_embed_stride = None, 0
+        # polygon and recognition phases run side by side: each decoder's chains on its own four XCDs, so that a weight set fills four private L2s
+        # instead of eight (include/omp355.h rows_xcd_mask; launches of more than 128 workgroups ignore it)
+        P.rows_xcd_mask = self.xcd_masks.get(ph.kind, 0) if use_rows else 0
         # in between (more rows than the fused few-row kernels take, fewer than the chains want): the mid chain alone
         use_mid = bool(not use_rows and self.dtype == torch.bfloat16 and not self.kv_split and a.tfm_pre_norm and self.MID_MIN_ROWS <= ph.R
                        and d == 512 and self.nH == 8)
@@ -361,7 +368,13 @@ class Decoder(object):
                          'ca_out_b', 'ff1_w', 'ff1_b', 'ff2_w', 'ff2_b', 'n1_g', 'n1_b', 'n2_g', 'n2_b', 'n3_g', 'n3_b'):
                 setattr(Lc, name, (x3_layers[l][name] if use_x3 and name in x3_layers[l] else w[name]).data_ptr())
             Lc.kcache, Lc.vcache = ph.kc[l].data_ptr(), ph.vc[l].data_ptr()
-            Lc.rows_mid, Lc.rows_ffn = (r_layers[l][0].data_ptr(), r_layers[l][1].data_ptr()) if use_rows else (r_mid[l].data_ptr() if use_mid else None, None)
+            if use_rows:
+                (m_, ms_), (f_, fs_) = r_layers[l]
+                Lc.rows_mid, Lc.rows_mid_stride, Lc.rows_ffn, Lc.rows_ffn_stride = m_.data_ptr(), ms_, f_.data_ptr(), fs_
+            elif use_mid:
+                Lc.rows_mid, Lc.rows_mid_stride, Lc.rows_ffn, Lc.rows_ffn_stride = r_mid[l][0].data_ptr(), r_mid[l][1], None, 0
+            else:
+                Lc.rows_mid, Lc.rows_mid_stride, Lc.rows_ffn, Lc.rows_ffn_stride = None, 0, None, 0
             off = (kidx * self.L + l) * slab * esz
             Lc.crossK = kv['K'].data_ptr() + off
             Lc.crossVt = kv['Vt'].data_ptr() + off
@@ -536,7 +549,7 @@ class Decoder(object):
         if self.pair_stagger and php.plan.rows_fused and phr.plan.rows_fused:
             # both phases on the row-owner chains: ONE interleaved schedule whose cross-attention launches are serialised by events, so that one
             # decoder's chains (half the compute units) run beside the other's HBM-bound cross-attention (csrc/decoder.hip: omp_decoder_run_pair)
-            rc = _lib.lib().omp_decoder_run_pair(ctypes.byref(php.plan), ctypes.byref(phr.plan), 0, np_, nr, sp.cuda_stream, sr.cuda_stream)
+            rc = _lib.lib().omp_decoder_run_pair(ctypes.byref(php.plan), ctypes.byref(phr.plan), 0, np_, nr, sp.cuda_stream, sr.cuda_stream, cur.cuda_stream)
             _lib.check(rc, 'omp_decoder_run_pair')
             cur.wait_stream(sp)
             cur.wait_stream(sr)

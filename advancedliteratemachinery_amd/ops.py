@@ -502,14 +502,14 @@ def kv_project_rows(rows, wstream, wave_stride, bias, out, B, M, Mpad, n_slabs, 
     return out
 
 
-def dec_rows_mid(att, x, wstream, wave_stride, out_b, ln_g, ln_b, qbias_tab, d_pos, q=None, eps=1e-5, x3=False):
+def dec_rows_mid(att, x, wstream, wave_stride, out_b, ln_g, ln_b, qbias_tab, d_pos, q=None, eps=1e-5, x3=False, xcd_mask=0):
     """x += att Wo^T + bo;  q = bf16(LayerNorm(x) Wq^T + qbias_tab[*d_pos])  -- one launch, a workgroup owns 80 rows (include/omp355.h).
     x3: the parity engine's chain -- att as split pairs bf16 [R, 1024], q fp32, split weight stream, 48 rows per workgroup."""
     R = x.shape[0]
     if q is None:
         q = torch.empty((R, 512), dtype=torch.float32 if x3 else torch.bfloat16, device=x.device)
     a = _lib.DecRowsArgs()
-    a.x3 = 1 if x3 else 0
+    a.x3, a.xcd_mask = 1 if x3 else 0, int(xcd_mask)
     a.R, a.eps, a.d_pos, a.x, a.att = R, float(eps), ptr(d_pos), ptr(_c(x, 'x')), ptr(_c(att, 'att'))
     a.wstream, a.wave_stride = ptr(wstream), int(wave_stride)
     a.out_b, a.ln_g, a.ln_b, a.qbias_tab, a.q = ptr(out_b), ptr(ln_g), ptr(ln_b), ptr(qbias_tab), ptr(q)
@@ -518,12 +518,12 @@ def dec_rows_mid(att, x, wstream, wave_stride, out_b, ln_g, ln_b, qbias_tab, d_p
 
 
 def dec_rows_ffn(x, wstream, wave_stride, d_pos, lnt_g, lnt_b, att=None, out_b=None, ln_g=None, ln_b=None, ff1_b=None, ff2_b=None,
-                 embed=None, bias_tab=None, qkv=None, head_b=None, logits=None, vocab=0, eps=1e-5, x3=False):
+                 embed=None, bias_tab=None, qkv=None, head_b=None, logits=None, vocab=0, eps=1e-5, x3=False, xcd_mask=0):
     """The chain behind the cross-attention (or, embed=(seq, word_emb, pos_tab, emb_g, emb_b), the embedding of layer 0) and its tail:
     bias_tab given -> the next layer's q | k | v (bf16 [R, 1536]); head_b=(b0, b1, b2) -> the prediction head's logits (fp32 [R, vocab])."""
     R = x.shape[0]
     a = _lib.DecRowsArgs()
-    a.x3 = 1 if x3 else 0
+    a.x3, a.xcd_mask = 1 if x3 else 0, int(xcd_mask)
     a.R, a.eps, a.d_pos, a.x = R, float(eps), ptr(d_pos), ptr(_c(x, 'x'))
     a.wstream, a.wave_stride = ptr(wstream), int(wave_stride)
     a.lnt_g, a.lnt_b = ptr(lnt_g), ptr(lnt_b)

@@ -159,14 +159,27 @@ def pmc_traffic(images_per_launch, prefix=''):
 
 def pmc_gemm_traffic(size, dtype):
     """Measured HBM bytes of the large GEMMs from the rocprofv3 PMC passes over one encoder chunk + its K / V^T projection
-    (tools/encode_pmc.py, tools/pmc_gemm_json.py -> profiles/pmc_gemm.json): (bytes per launch, measured / algorithmic)."""
+    (tools/encode_pmc.py run / summarise -> profiles/pmc_gemm.json): (bytes per launch, measured / algorithmic)."""
     if size != 1024 or dtype != 'bf16':
         return None
     try:
         with open(os.environ.get('OMP355_PMC_GEMM_JSON', os.path.join(ROOT, 'profiles', 'pmc_gemm.json'))) as f:
             s_ = json.load(f)['summary']
         return float(s_['gemm_measured_bytes_per_launch']), float(s_['gemm_measured_over_alg'])
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
+def pmc_mlp_chain_traffic(size, dtype):
+    """Measured HBM bytes of the fused MLP + Swin stage-2 chain class from the same passes (profiles/pmc_gemm.json, round 6):
+    (bytes per launch, measured / algorithmic)."""
+    if size != 1024 or dtype != 'bf16':
+        return None
+    try:
+        with open(os.environ.get('OMP355_PMC_GEMM_JSON', os.path.join(ROOT, 'profiles', 'pmc_gemm.json'))) as f:
+            s_ = json.load(f)['summary']
+        return float(s_['mlp_chain_measured_bytes_per_launch']), float(s_['mlp_chain_measured_over_alg'])
+    except (OSError, ValueError, KeyError, TypeError):
         return None
 
 
@@ -783,8 +796,7 @@ def main():
             grec['frac_of_launch_rooflines'] = r_gemm / (t_gemm / 1e3)
             if gt:
                 grec['traffic_over_algorithmic'] = gt[1]
-                grec['traffic_scope'] = ('HBM bytes per GEMM launch of one 32-image encoder chunk + its K / V^T projection (profiles/pmc_gemm.json); '
-                                         'the decoder-phase GEMMs of this class are not in that pass')
+                grec['traffic_scope'] = 'HBM bytes per tile-GEMM launch of one 80-image encoder chunk (profiles/pmc_gemm.json, tools/encode_pmc.py)'
             recs.append((t_gemm, grec))
         if n_gd:
             tf = f_gd / (t_gd / 1e3) / 1e12
@@ -804,11 +816,14 @@ def main():
                                     **(dict(traffic_over_algorithmic=rt_[1], traffic_scope=rt_[2]) if rt_ else {}))))
         if n_mlp:
             tf = f_mlp / (t_mlp / 1e3) / 1e12
+            mt_ = pmc_mlp_chain_traffic(a.size, dtype_name)
             recs.append((t_mlp, dict(bound='mfma', kernel='mlp_fused_kernel (Swin stages 0/1: LayerNorm + fc1 + GELU + fc2 + residual) + dec_rows_ffn_kernel on Swin stage 2 (round 5: a block minus its window attention as one row-owner chain)',
-                                     achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=None,
+                                     achieved=tf, peak=MFMA_PEAK_TFS, unit='TFLOP/s', frac=tf / MFMA_PEAK_TFS, traffic=mt_[0] if mt_ else None,
                                      launches=int(n_mlp), avg_us=t_mlp / n_mlp * 1e3, flops_per_launch=f_mlp / n_mlp,
                                      alg_bytes_per_launch=b_mlp / n_mlp, frac_of_launch_rooflines=r_mlp / (t_mlp / 1e3),
-                                     gpu_ms_per_image=t_mlp / (n_groups * BI))))
+                                     gpu_ms_per_image=t_mlp / (n_groups * BI),
+                                     **(dict(traffic_over_algorithmic=mt_[1], traffic_scope='HBM bytes per launch of the class over one 80-image encoder chunk '
+                                                                                            '(profiles/pmc_gemm.json, tools/encode_pmc.py)') if mt_ else {}))))
         if n_cross:
             # algorithmic bytes per launch: K + V^T of the images in the call (d = 512) + q in / o out of the
             # rows (launch-weighted: 1 row/image in the point phase, N rows/image in polygon / recognition)

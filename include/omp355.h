@@ -329,6 +329,10 @@ typedef struct {
                                   makes the launch-per-Linear step run out-projection + residual, norm2 and the cross-attention query as ONE omp_dec_rows_mid
                                   launch (16-row workgroups) instead of three; NULL: three launches */
   const void* rows_ffn;        /* ca_out_w, ff1_w / ff2_w in 16 chunks, then the NEXT layer's sa_in_w -- the last layer: h0_w, h1_w, h2_w */
+  /* bytes between the streams of consecutive waves, AS RETURNED BY THE PACKER that wrote the stream (model/packing.py::pack_rows_*: fragments per
+   * wave x 1 KB).  The kernels know how many fragments each chain consumes; omp_decoder_run refuses a plan whose strides differ (a packer or
+   * layout change must fail loudly, not mis-stream weights). */
+  int64_t rows_mid_stride, rows_ffn_stride;
 } omp_dec_layer;
 
 typedef struct {
@@ -348,8 +352,14 @@ typedef struct {
    * omp_dec_rows_mid, cross-attention, omp_dec_rows_ffn -- 18 launches per step instead of 50; layers[l].rows_mid / rows_ffn and
    * rows_embed (layer 0's sa_in_w) are the packed streams (model/packing.py::pack_rows_*). */
   int32_t rows_fused;
+  /* XCD placement of the chains' workgroups (round 6; speed only, never correctness).  Bit x set = XCD x may run them; 0 = all eight.  The
+   * dispatcher is observed to place block b on XCD b % 8: a chain launch of at most 32 x popcount(mask) workgroups is launched with the blocks of
+   * the other XCDs retiring at once, so that its weight stream fills popcount(mask) private L2s instead of eight (the polygon decoder's chains
+   * 0x0F, the recognition decoder's 0xF0: each weight set lives in four L2s).  Larger launches ignore it. */
+  int32_t rows_xcd_mask;
   float eps;
   const void* rows_embed;
+  int64_t rows_embed_stride;   /* as layers[].rows_*_stride */
   omp_dec_layer layers[OMP_MAX_DEC_LAYERS];
   const float *word_emb, *pos_tab, *emb_g, *emb_b, *fn_g, *fn_b;
   const void *h0_w, *h1_w, *h2_w;
@@ -386,15 +396,17 @@ typedef struct {
 int omp_decoder_run(const omp_decoder_plan* plan, int first_pos, int n_steps, int graph_slot,
                     omp_stream_t s);
 int omp_decoder_graph_reset(int graph_slot);
-/* Two decoders' many-row phases as ONE interleaved schedule on two streams (round 6; the polygon and recognition loops of
- * Transformer.forward, transformer.py:252-284, which depend on the points only).  Both plans must be rows_fused plans with the same number
- * of layers.  Positions first_pos .. first_pos + max(n_steps_a, n_steps_b) - 1: while both decoders have steps left their launches are
- * interleaved and their cross-attention kernels serialised by events (a.cross[l] -> b.cross[l] -> a.cross[l + 1] ...), so that one decoder's
- * row-owner chains -- matrix-core work on half the compute units -- always run beside the OTHER decoder's HBM-bound cross-attention instead
- * of beside its own kind; the longer decoder finishes alone.  Eager launches on sa / sb (two distinct non-default streams); results are the
- * same bits as two omp_decoder_run calls (the same kernels on the same operands: only WHEN they run changes). */
+/* Two decoders' many-row phases as ONE interleaved schedule (round 6; the polygon and recognition loops of Transformer.forward,
+ * transformer.py:252-284, which depend on the points only).  Both plans must be rows_fused plans with the same number of layers.
+ * Positions first_pos .. first_pos + max(n_steps_a, n_steps_b) - 1: while both decoders have steps left, every cross-attention kernel of
+ * both goes to the ONE stream sx in the order a[0], b[0], a[1], b[1] ..., chained by events to the decoders' own streams sa / sb, which
+ * carry everything else (self-attention, the row-owner chains, sampling): one decoder's chains -- matrix-core work on half the compute
+ * units -- run beside the OTHER decoder's HBM-bound cross-attention instead of beside its own kind.  sa and sb should be created with a
+ * HIGHER priority than sx (a chain workgroup needs a whole CU's LDS: the queue priority decides who is placed when a launch drains).  The
+ * longer decoder finishes alone on its stream.  Eager launches; three distinct non-default streams; the caller joins sa and sb afterwards.
+ * Results are the same bits as two omp_decoder_run calls (the same kernels on the same operands: only WHEN they run changes). */
 int omp_decoder_run_pair(const omp_decoder_plan* plan_a, const omp_decoder_plan* plan_b, int first_pos, int n_steps_a, int n_steps_b,
-                         omp_stream_t sa, omp_stream_t sb);
+                         omp_stream_t sa, omp_stream_t sb, omp_stream_t sx);
 
 /* ---- Many-row decoder phases: the Linear chain between two attention kernels as ONE launch (round 5, csrc/dec_rows.hip) -----------
  * Replaces, for phases of thousands of rows (polygon / recognition decoders of a large engine call), the per-Linear launches of
@@ -414,7 +426,9 @@ int omp_decoder_run_pair(const omp_decoder_plan* plan_a, const omp_decoder_plan*
  *   the FFN interleaves, per chunk of 256 hidden units, linear1's pass (N = 256: features 32 w + 16 t, t = 0..1, K = 512) with linear2's
  *   (N = 512, K = 256);
  *   the vocabulary projection is padded with zero rows to a multiple of 128 features (512-feature passes, then 128-feature passes).
- * The buffer carries 8 KB of slack behind the last wave's stream (the ring of 8 fragments in flight runs ahead).
+ * wave_stride must equal (fragments of the chain per wave) x 1 KB -- what the packer returns; the entry points refuse anything else.
+ * The buffer carries PF x 1 KB of slack behind the last wave's stream, PF = fragments the kernels keep in flight (the ring runs ahead of the
+ * stream's end): 8 KB for the bf16 chains, 16 KB for the x3 chains (pairs of hi / lo fragments); model/packing.py allocates 16 KB for both.
  * att: bf16 [R, 512]; x: fp32 [R, 512] in place; q: bf16 [R, 512]; qkv: bf16 [R, 1536]; logits: fp32 [R, vocab], vocab % 4 == 0. */
 typedef struct {
   int32_t R;
@@ -444,10 +458,12 @@ typedef struct {
    * wstream carries per (k-step, feature tile) the fragment of w_hi then of w_lo (twice the fragments; model/packing.py, x3=True); a
    * workgroup owns 48 rows. */
   int32_t x3;
+  int32_t xcd_mask;                /* XCDs whose CUs may run the launch's workgroups (omp_decoder_plan.rows_xcd_mask); 0 = all */
 } omp_dec_rows_args;
 int omp_dec_rows_mid(const omp_dec_rows_args* a, omp_stream_t s);
 int omp_dec_rows_ffn(const omp_dec_rows_args* a, omp_stream_t s);
-int omp_dec_rows_tile(void);   /* rows per workgroup (80) */
+int omp_dec_rows_tile(void);   /* the LARGEST tile: 80 rows per workgroup (the Swin chains always; decoder launches take 16 x {1..5} rows: the smallest
+                                  tile that keeps the launch on half the device's compute units, csrc/dec_rows.hip rows_rtt) */
 
 /* Cross-attention memory projection as a row-owner stream kernel (csrc/kv_rows.hip, round 5) -- replaces, for bf16 engines with d_model 512,
  * 8 heads and M % 64 == 0, the two omp_gemm_bias_act launches with OMP_STORE_KBLK / OMP_STORE_VBLK that computed what nn.MultiheadAttention

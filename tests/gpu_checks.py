@@ -669,14 +669,16 @@ def check_decoder_fused(with_mask=True):
     return out
 
 
-def check_dec_rows(x3=False):
+def check_dec_rows(x3=False, xcd_mask=0, results=None):
     """Row-owner chains of the decoders' many-row phases (csrc/dec_rows.hip, round 5) against a CPU restatement of the sub-layers they
     replace (transformer.py:430-454 forward_pre, :302-328 embeddings, block/mlp.py head) with bf16 rounding where the kernels round
     (LayerNorm outputs, attention outputs, hidden activations, q / k / v), fp32 elsewhere.  R = 200 rows: three workgroups of 80 rows,
     the last one ragged (40 rows).  x3: the parity engine's chains (csrc/dec_rows_x3.hip: split operands, fp32 weights / outputs, 48 rows
-    per workgroup) against plain fp32 arithmetic."""
+    per workgroup) against plain fp32 arithmetic.  xcd_mask: the launches confined to those XCDs (omp_dec_rows_args.xcd_mask); results: a list
+    that receives the device outputs (check_dec_rows_xcd compares them bit for bit across masks)."""
     from advancedliteratemachinery_amd.model import packing
     bf = torch.bfloat16
+    keep = (lambda *ts: results.extend(t.clone() for t in ts)) if results is not None else (lambda *ts: None)
     wd = torch.float32 if x3 else bf                                        # what the packers take
     rq = (lambda t: t) if x3 else (lambda t: q(t, bf))                       # where the bf16 chains round, the parity chains do not
     d, ff, V, R, P, pos = 512, 2048, 1104, 200, 12, 5
@@ -698,8 +700,9 @@ def check_dec_rows(x3=False):
     q_ref = rq(rq(ln(x1, g2, b2)) @ Wq.T + qtab[pos])
     stream, stride = packing.pack_rows_mid(dev(Wo, wd), dev(Wq, wd))
     xd = dev(x0)
-    qd = ops.dec_rows_mid(att_d, xd, stream, stride, dev(bo), dev(g2), dev(b2), dev(qtab), dpos, x3=x3)
+    qd = ops.dec_rows_mid(att_d, xd, stream, stride, dev(bo), dev(g2), dev(b2), dev(qtab), dpos, x3=x3, xcd_mask=xcd_mask)
     torch.cuda.synchronize()
+    keep(xd, qd)
     out.append(rrec(tag + '_mid x (residual stream)', maxerr(xd, x1), 2e-4 * x1.abs().max().item()))
     out.append(rrec(tag + '_mid q', maxerr(qd, q_ref), (5e-4 if x3 else 0.02) * q_ref.abs().max().item()))
     # ---- ffn: x1 = x + att Wo^T + bo; x2 = x1 + relu(LN3(x1) W1^T + b1) W2^T + b2; tails
@@ -716,17 +719,19 @@ def check_dec_rows(x3=False):
     t0 = rq(torch.relu(yt @ H0.T + hb[0]))
     t1 = rq(torch.relu(t0 @ H1.T + hb[1]))
     lg_ref = t1 @ H2.T + hb[2]
-    common = dict(att=att_d, out_b=dev(bc), ln_g=dev(g3), ln_b=dev(b3), ff1_b=dev(b1), ff2_b=dev(bb2), x3=x3)
+    common = dict(att=att_d, out_b=dev(bc), ln_g=dev(g3), ln_b=dev(b3), ff1_b=dev(b1), ff2_b=dev(bb2), x3=x3, xcd_mask=xcd_mask)
     stream, stride = packing.pack_rows_ffn_qkv(dev(Wc, wd), dev(W1, wd), dev(W2, wd), dev(Win, wd))
     xd = dev(x0)
     qkv = ops.dec_rows_ffn(xd, stream, stride, dpos, dev(gt), dev(bt), bias_tab=dev(tab), **common)
     torch.cuda.synchronize()
+    keep(xd, qkv)
     out.append(rrec(tag + '_ffn[qkv tail] x', maxerr(xd, x2), t_x * x2.abs().max().item()))
     out.append(rrec(tag + '_ffn[qkv tail] qkv', maxerr(qkv, qkv_ref), t_o * qkv_ref.abs().max().item()))
     stream, stride = packing.pack_rows_ffn_head(dev(Wc, wd), dev(W1, wd), dev(W2, wd), dev(H0, wd), dev(H1, wd), dev(H2, wd))
     xd = dev(x0)
     lg = ops.dec_rows_ffn(xd, stream, stride, dpos, dev(gt), dev(bt), head_b=tuple(dev(b) for b in hb), vocab=V, **common)
     torch.cuda.synchronize()
+    keep(xd, lg)
     out.append(rrec(tag + '_ffn[head tail] x', maxerr(xd, x2), t_x * x2.abs().max().item()))
     out.append(rrec(tag + '_ffn[head tail] logits', maxerr(lg, lg_ref), t_o * lg_ref.abs().max().item(), 'max|logit|=%.2f' % lg_ref.abs().max().item()))
     # ---- embedding prologue: x = LN(word[tok] + pos_tab[pos]); qkv = LN1(x) Win^T + tab[pos]
@@ -737,8 +742,10 @@ def check_dec_rows(x3=False):
     qkv_e = rq(rq(ln(xe, gt, bt)) @ Win.T + tab[pos])
     stream, stride = packing.pack_rows_embed_qkv(dev(Win, wd))
     xd = torch.zeros(R, d, device=DEV)
-    qkv = ops.dec_rows_ffn(xd, stream, stride, dpos, dev(gt), dev(bt), embed=(seq.to(DEV), dev(word), dev(ptab), dev(ge), dev(be)), bias_tab=dev(tab), x3=x3)
+    qkv = ops.dec_rows_ffn(xd, stream, stride, dpos, dev(gt), dev(bt), embed=(seq.to(DEV), dev(word), dev(ptab), dev(ge), dev(be)), bias_tab=dev(tab), x3=x3,
+                           xcd_mask=xcd_mask)
     torch.cuda.synchronize()
+    keep(xd, qkv)
     out.append(rrec(tag + '_ffn[embedding] x', maxerr(xd, xe), 1e-5 * max(1.0, xe.abs().max().item())))
     out.append(rrec(tag + '_ffn[embedding] qkv', maxerr(qkv, qkv_e), (5e-4 if x3 else 0.02) * qkv_e.abs().max().item()))
     return out
@@ -746,6 +753,27 @@ def check_dec_rows(x3=False):
 
 def check_dec_rows_x3():
     return check_dec_rows(x3=True)
+
+
+def check_dec_rows_xcd():
+    """omp_dec_rows_args.xcd_mask (round 6): a chain launch confined to a subset of the XCDs -- 8 blocks per group of popcount(mask) tiles, the
+    blocks of the other XCDs retire at once -- computes the same tiles: every output identical BIT FOR BIT to the unmasked launch, for the
+    decoders' masks (0x0F, 0xF0), an interleaved one (0x55), a single XCD (0x04) and at two tile sizes (R = 200: 7 tiles of 32 rows, 3 of 80)."""
+    out = []
+    try:
+        for rtt in (2, 5):
+            ops.rows_tile(rtt)
+            ref = []
+            base = check_dec_rows(results=ref)
+            out += [dict(r, name='%s @ %d rows, all XCDs' % (r['name'], 16 * rtt)) for r in base]
+            for mask in (0x0F, 0xF0, 0x55, 0x04):
+                got = []
+                check_dec_rows(xcd_mask=mask, results=got)
+                same = len(got) == len(ref) and all(torch.equal(a, b) for a, b in zip(got, ref))
+                out.append(rec('dec_rows @ %d rows per workgroup: xcd_mask 0x%02X == unmasked launch, bit for bit (%d tensors)' % (16 * rtt, mask, len(ref)), 0 if same else 1, 0))
+    finally:
+        ops.rows_tile(0)
+    return out
 
 
 def check_dec_rows_tiles():
@@ -1294,6 +1322,44 @@ def check_e2e_rows_threshold(name='spot_640_n64', dtype_name='bf16x3', copies=64
     # first and last copy under the engine's full per-image gates (stage maps, FPN, memory, logits of the 1-image phases, tokens)
     for b in (0, copies - 1):
         out += _compare_image('%s x%d,img%d' % (name, copies, b), dtype_name, args, gold, e, b, copies, res[b], dec, model)
+    return out
+
+
+def check_run_pair(dtype_name='bf16', name='spot_640_n64', copies=64):
+    """omp_decoder_run_pair (round 6: the polygon and recognition phases of a many-row call as ONE interleaved schedule, cross-attention launches
+    serialised by events) against the two free-running streams of step graphs it replaces: the same kernels on the same operands, so the packed
+    ids AND probabilities of every image must be identical bit for bit.  64 x the 64-instance fixture = 4096 rows per phase (the chains' own
+    threshold); on a side stream with graphs and side streams on, as bench.py runs."""
+    gold = golden(name)
+    case = gold['case']
+    args, sd, img, mask, seqs = G.case_inputs(case)
+    model = build_model(args, sd, case['depths'], ENGINES[dtype_name], True, case.get('swin'))
+    _, dec = model.engine()
+    imgs = img.to(DEV).expand(copies, -1, -1, -1).contiguous()
+    masks = mask.to(DEV).expand(copies, -1, -1).contiguous()
+    n_inst = gold['out']['pt'].numel() // 2
+    st = torch.cuda.Stream()
+    res = {}
+    keep = dec.pair_stagger
+    try:
+        with torch.cuda.stream(st):
+            for on in (False, True, True):
+                dec.pair_stagger = on
+                ids, probs, n = model.infer(imgs, masks, seqs, packed=n_inst)
+                res[on] = (ids.clone(), probs.clone(), n.clone())
+        st.synchronize()
+    finally:
+        dec.pair_stagger = keep
+    fused, ph = _chain_phases(dec)
+    out = [rec('run_pair[%s] the %d-row polygon and recognition phases are rows_fused plans' % (dtype_name, copies * n_inst),
+               0 if sorted((p_.kind, p_.R) for p_ in fused) == [('poly', copies * n_inst), ('rec', copies * n_inst)] else 1, 0)]
+    for i, what in enumerate(('ids', 'probabilities', 'instance counts')):
+        out.append(rec('run_pair[%s] %s identical to the two-stream schedule' % (dtype_name, what), 0 if torch.equal(res[True][i], res[False][i]) else 1, 0))
+    out.append(rec('run_pair[%s] every image has its %d instances' % (dtype_name, n_inst), 0 if bool((res[True][2] == n_inst).all()) else 1, 0))
+    if dtype_name in ('fp32', 'bf16x3'):
+        go = gold['out']
+        ref = torch.cat([go['pt'].reshape(-1, 2), go['poly'].reshape(-1, 32), go['rec'].reshape(n_inst, -1)], 1).to(DEV, torch.int32)
+        out.append(rec('run_pair[%s] ids of every copy identical to the reference\'s' % dtype_name, float((res[True][0] != ref.unsqueeze(0)).sum()), 0))
     return out
 
 

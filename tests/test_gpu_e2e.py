@@ -54,6 +54,14 @@ def test_decode_path_at_its_threshold(C, dtype):
     _assert_all(C.check_e2e_rows_threshold('spot_640_n64', dtype, 64))
 
 
+@pytest.mark.parametrize('dtype', ['bf16x3', 'bf16'])
+@pytest.mark.timeout(400, method='thread')
+def test_paired_schedule_equals_two_streams(C, dtype):
+    """round 6: polygon || recognition as one interleaved schedule with serialised cross-attention launches (omp_decoder_run_pair) == the two
+    free-running streams of step graphs, bit for bit, at 4096 rows per phase (transformer.py:252-284)."""
+    _assert_all(C.check_run_pair(dtype))
+
+
 def test_parity_engine_bf16x3_graph(C):
     _assert_all(C.check_e2e('spot_1024', 'bf16x3', graph=True))
 

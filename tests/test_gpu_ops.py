@@ -20,7 +20,7 @@ def C():
 
 @pytest.mark.parametrize('name', ['check_layernorm', 'check_gemm', 'check_mlp_fused', 'check_self_attn', 'check_gemm_small', 'check_patch_embed', 'check_window_attn',
                                   'check_patch_merge', 'check_fpn', 'check_posembed', 'check_sampling', 'check_cross_attn', 'check_split_ops', 'check_gemm_x3',
-                                  'check_window_attn_split', 'check_swin_block', 'check_cross_attn_split', 'check_gemm_4w', 'check_dec_rows', 'check_swin_rows_block', 'check_dec_rows_x3', 'check_swin_rows_block_x3', 'check_dec_rows_tiles', 'check_kv_rows'])
+                                  'check_window_attn_split', 'check_swin_block', 'check_cross_attn_split', 'check_gemm_4w', 'check_dec_rows', 'check_swin_rows_block', 'check_dec_rows_x3', 'check_swin_rows_block_x3', 'check_dec_rows_tiles', 'check_kv_rows', 'check_dec_rows_xcd'])
 def test_op(C, name):
     _assert_all(getattr(C, name)())
 

@@ -251,3 +251,57 @@ def test_validate_world2_eos_balanced_shards_give_the_same_json(tmp_path):
     for _, _, calls, planned in got:
         assert calls == planned                                  # every rank made exactly the engine calls of its plan
     _same(json.load(open(os.path.join(str(tmp_path), 'results', 'ep002', 'unit_val.json'))), exp)
+
+
+def _loader_pairs(n_items):
+    """dataloader items that hold TWO images each (validate's docstring allows it): same sizes inside an item, as a collate would give"""
+    singles = _loader(2 * n_items)
+    items = []
+    for i in range(n_items):
+        (a, ta), (b, tb) = singles[2 * i], singles[2 * i + 1]
+        h = max(a.tensors.shape[2], b.tensors.shape[2])
+        w = max(a.tensors.shape[3], b.tensors.shape[3])
+        img = torch.zeros(2, 3, h, w)
+        mask = torch.ones(2, h, w, dtype=torch.bool)
+        for k, s in enumerate((a, b)):
+            hh, ww = s.tensors.shape[2:]
+            img[k, :, :hh, :ww] = s.tensors[0]
+            mask[k, :hh, :ww] = False
+        items.append((RefStyleNested(img, mask), ta + tb))
+    return items
+
+
+def _worker_pairs(rank, world, port, folder, q, balanced):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    assert udist.init_distributed_mode(backend='gloo')
+    args = make_args(use_char_window_prompt=True, output_folder=folder)
+    loader = _loader_pairs(5)
+    if balanced:   # one predicted count per ITEM
+        args.eos_pred_counts = [sum(_key(s.tensors[k], s.mask[k]) % 4 for k in range(2)) for s, _ in loader]
+    model = StubModel()
+    got = inf.validate(model, loader, 4 + int(balanced), args, batch_size=2)
+    q.put((rank, len(got), [b for (b, _, _, _), _ in model.calls]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_validate_world2_items_with_two_images_keep_dataset_order(tmp_path):
+    """`lo`, `order` and the plan's cuts count dataloader ITEMS; with two images per item the per-image sort keys of the ranks used to
+    overlap (contiguous shards) and the balanced plan was cut after the wrong image.  Both paths must write the single-image loader's JSON."""
+    args = make_args(use_char_window_prompt=True)
+    exp = _expected(10, args)
+    for balanced in (False, True):
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        port = 35500 + (os.getpid() % 2000) + int(balanced)
+        procs = [ctx.Process(target=_worker_pairs, args=(r, 2, port, str(tmp_path), q, balanced)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=180) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+        assert got[0][1] == len(exp) and got[1][1] == 0
+        assert sum(sum(c) for _, _, c in got) == 10                                  # every image decoded exactly once
+        if balanced:
+            assert all(b % 2 == 0 for _, _, c in got for b in c)                         # engine calls are cut between items
+        _same(json.load(open(os.path.join(str(tmp_path), 'results', 'ep%03d' % (4 + int(balanced)), 'unit_val.json'))), exp)

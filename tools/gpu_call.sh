@@ -12,7 +12,9 @@
 #   q4tail           per-launch durations of the 64-row cross-attention kernel by what ran beside it (tools/rocpd_overlap.py)
 #   kbench:<what>    tools/kbench.py <what>              [KBENCH_* knobs of that tool]
 #   pmcdec           FETCH_SIZE / WRITE_SIZE passes over the decoders' many-row kernels (tools/dec_rows_pmc.py) -> profiles/pmc_dec_rows.json
+#   pmcenc           FETCH_SIZE / WRITE_SIZE passes over one 80-image encoder chunk + its K / V^T projection (tools/encode_pmc.py) -> pmc_gemm.json   [PMC_ENC_ARGS: "<images> <engine>"]
 #   pmccross         FETCH_SIZE / WRITE_SIZE passes over the cross-attention kernels at PMC_IMAGES images per launch -> pmc_cross_attn.json
+#   ab:<VAR>         the headline alone (no side legs, no CPU baseline) with VAR=0 and VAR=1 in the environment, phase times on stderr   [AB_ARGS, AB_VALUES]
 #   py:<script>      python <script> (stdout -> <script basename>.txt)
 TAG=${1:?tag}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$PWD
@@ -64,6 +66,12 @@ pmcdec) for c in FETCH_SIZE WRITE_SIZE; do
           f=$(find $OUT/pd_$c -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $OUT/pmcdec_$c.csv; rm -rf $OUT/pd_$c
         done
         python tools/dec_rows_pmc.py summarise $OUT/pmcdec_FETCH_SIZE.csv $OUT/pmcdec_WRITE_SIZE.csv > $OUT/pmc_dec_rows.json 2>> $OUT/rc.log; cat $OUT/pmc_dec_rows.json; rm -f $OUT/pmcdec_*.csv;;
+pmcenc) for c in FETCH_SIZE WRITE_SIZE; do
+          (cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$OUT/pe_$c -o pmc -- python $R/tools/encode_pmc.py run ${PMC_ENC_ARGS:-80 bf16} > $R/$OUT/pmcenc_$c.json 2> $R/$OUT/pmcenc_$c.err); echo "pmcenc $c rc=$?" >> $OUT/rc.log
+          f=$(find $OUT/pe_$c -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $OUT/pmcenc_$c.csv; rm -rf $OUT/pe_$c
+        done
+        tail -1 $OUT/pmcenc_FETCH_SIZE.json > $OUT/encode_alg.json
+        python tools/encode_pmc.py summarise $OUT/pmcenc_FETCH_SIZE.csv $OUT/pmcenc_WRITE_SIZE.csv $OUT/encode_alg.json > $OUT/pmc_gemm.json 2>> $OUT/rc.log; python -c "import json; print(json.dumps(json.load(open('$OUT/pmc_gemm.json'))['summary'], indent=1))"; rm -f $OUT/pmcenc_*.csv;;
 pmccross) PMC_STEPS=${PMC_STEPS:-20}
         PMC_ARGS="--steps $PMC_STEPS --warmup 0 --lanes 1 --graph 0 --no-cpu-baseline --no-roofline --no-parity-leg --no-config-legs --no-batch8 --no-eos-run --min-seconds 0.5"
         for c in FETCH_SIZE WRITE_SIZE; do
@@ -71,6 +79,11 @@ pmccross) PMC_STEPS=${PMC_STEPS:-20}
           f=$(find $OUT/pmc_$c -name "*counter_collection.csv" 2>/dev/null | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f $c > $OUT/pmc_$c.txt 2>> $OUT/pmc_$c.err; rm -rf $OUT/pmc_$c
         done
         python tools/pmc_cross_json.py $OUT/pmc_FETCH_SIZE.txt $OUT/pmc_WRITE_SIZE.txt $((8 * PMC_STEPS)) "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python bench.py $PMC_ARGS" profiles/pmc_cross_attn.json > $OUT/pmc_cross_attn.json 2>> $OUT/rc.log;;
+ab:*)   var=${leg#ab:}
+        for v in ${AB_VALUES:-0 1}; do
+          env $var=$v timeout 600 python bench.py --steps 20 --warmup 5 --phase-times --no-parity-leg --no-config-legs --no-batch8 --no-eos-run --no-cpu-baseline ${AB_ARGS} > $OUT/ab_${var}_$v.json 2> $OUT/ab_${var}_$v.err; echo "ab $var=$v rc=$?" >> $OUT/rc.log
+          echo "== $var=$v"; grep "phase ms" $OUT/ab_${var}_$v.err | cut -c1-400; python tools/bench_summary.py $OUT/ab_${var}_$v.json | head -12
+        done;;
 py:*)   sc=${leg#py:}; timeout 600 python $sc > $OUT/$(basename $sc .py).txt 2>&1; echo "py $sc rc=$?" >> $OUT/rc.log; tail -40 $OUT/$(basename $sc .py).txt;;
 *)      echo "unknown leg $leg" | tee -a $OUT/rc.log;;
 esac; done
