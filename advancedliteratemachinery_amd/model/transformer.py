@@ -200,8 +200,11 @@ class Decoder(object):
         # polygon || recognition phases on the chains: their steps interleaved with serialised cross-attention launches (omp_decoder_run_pair);
         # OMP355_PAIR=0: two free-running streams of step graphs (round 5; A/B)
         self.pair_stagger = env_flag('OMP355_PAIR', False)
-        # XCD placement of the many-row chains per decoder kind (omp_decoder_plan.rows_xcd_mask); OMP355_XCD_SPLIT=0: every launch on all eight
-        self.xcd_masks = {'poly': 0x0F, 'rec': 0xF0} if env_flag('OMP355_XCD_SPLIT', True) else {}
+        # XCD placement of the many-row chains per decoder kind (omp_decoder_plan.rows_xcd_mask): each decoder's weight set then fills four private L2s
+        # instead of eight -- HBM traffic of the chains 1.30x -> 1.14x algorithmic (profiles/r06d_pmc_dec_rows_xcd_split.json) -- but the OTHER
+        # decoder's cross-attention is then confined to four XCDs' share of the fabric: polygon + recognition 98 -> 109 ms per 160 images
+        # (profiles/r06d_ab_xcd_split_*).  Off by default; OMP355_XCD_SPLIT=1 is the A/B knob
+        self.xcd_masks = {'poly': 0x0F, 'rec': 0xF0} if env_flag('OMP355_XCD_SPLIT', False) else {}
         self._x3_cache = {}   # kind -> (layers, head) with every matrix as its [w_hi | w_hi | w_lo] image (bf16x3 engine, R > 64)
 
     X3_MIN_ROWS = 65    # phases with more rows run their products as split-bf16 products (csrc/decoder.hip: step_launch_x3)
@@ -345,8 +348,7 @@ class Decoder(object):
             P.rows_embed, P.rows_embed_stride = r_embed[0].data_ptr(), r_embed[1]
         else:
             P.rows_embed, P.rows_embed_stride = None, 0
-        # polygon and recognition phases run side by side: each decoder's chains on its own four XCDs, so that a weight set fills four private L2s
-        # instead of eight (include/omp355.h rows_xcd_mask; launches of more than 128 workgroups ignore it)
+        # (A/B, off by default) each decoder's chains on its own four XCDs (include/omp355.h rows_xcd_mask; launches of more than 128 workgroups ignore it)
         P.rows_xcd_mask = self.xcd_masks.get(ph.kind, 0) if use_rows else 0
         # in between (more rows than the fused few-row kernels take, fewer than the chains want): the mid chain alone
         use_mid = bool(not use_rows and self.dtype == torch.bfloat16 and not self.kv_split and a.tfm_pre_norm and self.MID_MIN_ROWS <= ph.R

@@ -13,7 +13,8 @@ error message, not a silently different engine.  Knobs that change a
   OMP355_PAIR          polygon || recognition phases on the chains as ONE interleaved schedule with serialised cross-attention launches
                        (omp_decoder_run_pair; 0 / 1, default 0: measured equal to slower, profiles/r06b_*, r06c_*)
   OMP355_SIDE_PRIO     the model's polygon / recognition side streams at high priority (0 / 1, default 1)
-  OMP355_XCD_SPLIT     each decoder's many-row chains on its own four XCDs (0 / 1, default 1)
+  OMP355_XCD_SPLIT     each decoder's many-row chains on its own four XCDs (0 / 1, default 0: chain HBM traffic 1.30x -> 1.14x algorithmic, but the
+                       phase 98 -> 109 ms: the other decoder's cross-attention is left with four XCDs' share of the fabric; profiles/r06d_*)
   OMP355_DEC_PRIORITY  pipeline lanes: decoder streams at high priority (0 / 1, default 0)
 Read in C (csrc/decoder.hip), parsed strictly there -- anything but a non-negative integer fails every omp_decoder_run:
   OMP355_SAMPLE_BLOCK_MAX_ROWS  rows up to which sampling runs a workgroup per row (default 1024)
