@@ -15,6 +15,7 @@
 #   pmcenc           FETCH_SIZE / WRITE_SIZE passes over one 80-image encoder chunk + its K / V^T projection (tools/encode_pmc.py) -> pmc_gemm.json   [PMC_ENC_ARGS: "<images> <engine>"]
 #   pmccross         FETCH_SIZE / WRITE_SIZE passes over the cross-attention kernels at PMC_IMAGES images per launch -> pmc_cross_attn.json
 #   ab:<VAR>         the headline alone (no side legs, no CPU baseline) with VAR=0 and VAR=1 in the environment, phase times on stderr   [AB_ARGS, AB_VALUES]
+#   timeline         kernel trace of the headline WITH graph replay, then tools/rocpd_timeline.py at TL_ANCHOR (kernel substring), occurrence TL_OCC, TL_COUNT dispatches   [TL_ARGS: bench arguments]
 #   py:<script>      python <script> (stdout -> <script basename>.txt)
 TAG=${1:?tag}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$PWD
@@ -84,6 +85,11 @@ ab:*)   var=${leg#ab:}
           env $var=$v timeout 600 python bench.py --steps 20 --warmup 5 --phase-times --no-parity-leg --no-config-legs --no-batch8 --no-eos-run --no-cpu-baseline ${AB_ARGS} > $OUT/ab_${var}_$v.json 2> $OUT/ab_${var}_$v.err; echo "ab $var=$v rc=$?" >> $OUT/rc.log
           echo "== $var=$v"; grep "phase ms" $OUT/ab_${var}_$v.err | cut -c1-400; python tools/bench_summary.py $OUT/ab_${var}_$v.json | head -12
         done;;
+timeline) (cd /tmp && timeout 420 rocprofv3 --kernel-trace -d $R/$OUT/p_tl -o kt -- python $R/bench.py --steps 20 --warmup 0 --min-seconds 0 --no-parity-leg --no-config-legs --no-batch8 --no-eos-run --no-cpu-baseline --no-roofline ${TL_ARGS} > $R/$OUT/tl_bench.json 2> $R/$OUT/tl.err); echo "timeline rc=$?" >> $OUT/rc.log
+        db=$(find $OUT/p_tl -name "*.db" | head -1)
+        [ -n "$db" ] && python tools/rocpd_timeline.py $db "${TL_ANCHOR:-dec_embed_ln_kernel}" ${TL_OCC:-300} ${TL_COUNT:-60} > $OUT/timeline.txt 2>> $OUT/rc.log
+        [ -n "$db" ] && python tools/rocpd_timeline.py $db "dec_rows_ffn_kernel<5, 1, 0, 0>" ${TL_OCC2:-40} 44 > $OUT/timeline_polyrec.txt 2>> $OUT/rc.log
+        rm -rf $OUT/p_tl; cat $OUT/timeline.txt | cut -c1-150;;
 py:*)   sc=${leg#py:}; timeout 600 python $sc > $OUT/$(basename $sc .py).txt 2>&1; echo "py $sc rc=$?" >> $OUT/rc.log; tail -40 $OUT/$(basename $sc .py).txt;;
 *)      echo "unknown leg $leg" | tee -a $OUT/rc.log;;
 esac; done
