@@ -99,9 +99,11 @@ class OmniParser(nn.Module):
         if not self.overlap_decoders:
             return None
         if self._streams is None or self._streams[0].device != dev:
-            # high priority: in the paired schedule of the many-row phases (Decoder.decode_poly_and_rec) these carry the row-owner chains, which must be
-            # placed BEFORE the cross-attention workgroups of the caller's (normal-priority) stream when a launch drains (omp_decoder_run_pair)
-            pr = -1 if env_flag('OMP355_SIDE_PRIO', True) else 0
+            # OMP355_SIDE_PRIO=1 (A/B of the paired schedule, Decoder.decode_poly_and_rec / omp_decoder_run_pair): the side streams at HIGH priority, so that
+            # the row-owner chains they carry are placed before the cross-attention workgroups of the caller's stream when a launch drains.  Default 0:
+            # high-priority streams take hardware queues of their own, and the four single-stream lanes of a pipelined run created afterwards then
+            # share what is left -- bench.py's batch8 leg fell from 228 to 129 img/s with them (profiles/r06g_bench.json vs r06h)
+            pr = -1 if env_flag('OMP355_SIDE_PRIO', False) else 0
             self._streams = (torch.cuda.Stream(device=dev, priority=pr), torch.cuda.Stream(device=dev, priority=pr))
         return self._streams
 

@@ -12,7 +12,7 @@ error message, not a silently different engine.  Knobs that change a
   OMP355_MLP_ROWS_MIN  tokens from which the blocks of Swin-B's stage 2 run as row-owner chains (default 32768)
   OMP355_PAIR          polygon || recognition phases on the chains as ONE interleaved schedule with serialised cross-attention launches
                        (omp_decoder_run_pair; 0 / 1, default 0: measured equal to slower, profiles/r06b_*, r06c_*)
-  OMP355_SIDE_PRIO     the model's polygon / recognition side streams at high priority (0 / 1, default 1)
+  OMP355_SIDE_PRIO     the model's polygon / recognition side streams at high priority (0 / 1, default 0: they cost the pipelined lanes their hardware queues)
   OMP355_XCD_SPLIT     each decoder's many-row chains on its own four XCDs (0 / 1, default 0: chain HBM traffic 1.30x -> 1.14x algorithmic, but the
                        phase 98 -> 109 ms: the other decoder's cross-attention is left with four XCDs' share of the fabric; profiles/r06d_*)
   OMP355_DEC_PRIORITY  pipeline lanes: decoder streams at high priority (0 / 1, default 0)
