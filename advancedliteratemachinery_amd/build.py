@@ -52,13 +52,11 @@ def _fresh(target, digest, stamp=None):
         return False
 
 
-def build(force=False, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
+def plan(force=False):
+    """-> (jobs, objects, stamps, audited): what build() would compile right now.  jobs: (command, object, digest) per STALE source -- its stamp does not hold
+    the digest of (flags, source, headers), or it is an AUDITED source with neither an audit stamp of that digest nor its device assembly on disk."""
     hipcc = _hipcc()
-    jobs = []
-    objs = []
-    stamps = []
-    audited = {}
+    jobs, objs, stamps, audited = [], [], [], {}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace('.hip', '.o'))
@@ -72,6 +70,13 @@ def build(force=False, verbose=True):
             audited[src] = dg
         if force or not _fresh(o, dg) or (src in AUDITED and not _fresh(o, dg, o + '.audit.stamp') and not os.path.exists(_asm_of(src))):
             jobs.append(([hipcc] + flags + ['-c', s, '-o', o], o, dg))
+    return jobs, objs, stamps, audited
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    jobs, objs, stamps, audited = plan(force)
 
     def run(job):
         cmd, obj, dg = job[:3]

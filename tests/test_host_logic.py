@@ -723,3 +723,39 @@ def test_qkv_tail_rows_match_the_16_byte_store_mapping():
                 for r in range(4):
                     stored_at = 32 * (ft // 2) + 8 * g + 4 * (ft % 2) + r
                     assert p[group * 64 + ft * 16 + 4 * g + r, 0].item() == float(torch.tensor(group * 64 + stored_at, dtype=torch.float32).to(torch.bfloat16))
+
+
+def test_build_plan_is_by_content_and_audited_objects_need_proof():
+    """advancedliteratemachinery_amd/build.py: an unchanged tree compiles nothing; an AUDITED source (asm-addressed kernels) whose object has
+    neither an audit stamp of the current digest nor its device assembly on disk is STALE -- the audit is never skipped silently."""
+    import shutil
+    from advancedliteratemachinery_amd import build as B
+    B.build(verbose=False)                       # the driver has built the tree already: verifies, links nothing new
+    jobs, objs, stamps, audited = B.plan()
+    assert jobs == [] and len(objs) == len(B.SOURCES) and set(audited) == set(B.AUDITED)
+    obj = os.path.join(B.OBJ, 'kv_rows.o')
+    asm, ast = B._asm_of('kv_rows.hip'), obj + '.audit.stamp'
+    assert os.path.exists(ast)
+    moved = []
+    try:
+        for f in (asm, ast):
+            if os.path.exists(f):
+                shutil.move(f, f + '.away')
+                moved.append(f)
+        stale = [os.path.basename(j[1]) for j in B.plan()[0]]
+        assert stale == ['kv_rows.o']            # no proof of an audit left: recompile (and re-audit), do not skip
+        if asm in moved:                         # the assembly alone is proof enough to run the audit again without recompiling
+            shutil.move(asm + '.away', asm)
+            moved.remove(asm)
+            assert B.plan()[0] == []
+    finally:
+        for f in moved:
+            shutil.move(f + '.away', f)
+    assert B.plan()[0] == []
+    # a changed flag set changes every digest
+    keep = list(B.FLAGS)
+    try:
+        B.FLAGS.append('-DOMP355_TEST_FLAG')
+        assert len(B.plan()[0]) == len(B.SOURCES)
+    finally:
+        B.FLAGS[:] = keep
