@@ -92,6 +92,8 @@ extern "C" int omp_ctx_destroy(omp_ctx* c) {
   for (int i = 0; i < OMP_MAX_GRAPH_SLOTS; ++i) {
     if (c->slots[i].exec) (void)hipGraphExecDestroy(c->slots[i].exec);
     if (c->slots[i].graph) (void)hipGraphDestroy(c->slots[i].graph);
+    if (c->slots[i].exec_n) (void)hipGraphExecDestroy(c->slots[i].exec_n);
+    if (c->slots[i].graph_n) (void)hipGraphDestroy(c->slots[i].graph_n);
   }
   for (int k = 0; k < OMP_PROF_NCLASS; ++k)
     for (auto& e : c->prof[k].ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

@@ -60,9 +60,12 @@ enum { OMP_PROF_CROSS = 0, OMP_PROF_GEMM = 1, OMP_PROF_MLP = 2, OMP_PROF_GEMM_DE
 // time except the thread-local error string and the thread-local "capturing" flag of omp_decoder_run.
 // ---------------------------------------------------------------------------------------------
 constexpr int OMP_MAX_GRAPH_SLOTS = 4096;   // fixed table (no reallocation): pipeline lanes drive their own slots from their own threads
+constexpr int OMP_GRAPH_RUN = 8;   // sampling steps per multi-step graph (omp_decoder_run)
 struct OmpGraphSlot {
-  hipGraph_t graph = nullptr;
+  hipGraph_t graph = nullptr;       // ONE sampling step
   hipGraphExec_t exec = nullptr;
+  hipGraph_t graph_n = nullptr;     // OMP_GRAPH_RUN consecutive sampling steps (positions come from the device counter: the steps are identical)
+  hipGraphExec_t exec_n = nullptr;
 };
 struct OmpProfClass;   // api.hip
 struct omp_ctx {

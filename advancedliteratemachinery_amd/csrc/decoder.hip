@@ -1874,6 +1874,12 @@ int step_launch(const omp_decoder_plan* P, bool do_head, hipStream_t st) {
   return OMP_OK;
 }
 
+// sampling steps per multi-step graph; OMP355_GRAPH_RUN=1 switches the runs off (A/B): parsed strictly like the other knobs of this file
+int graph_run_steps() {
+  static const SampleEnv v = strict_env_int("OMP355_GRAPH_RUN", OMP_GRAPH_RUN);
+  return v.ok && v.rows >= 1 && v.rows <= OMP_GRAPH_RUN ? (v.rows == OMP_GRAPH_RUN ? OMP_GRAPH_RUN : 1) : OMP_GRAPH_RUN;
+}
+
 int check_plan(const omp_decoder_plan* P) {
   OMP_CHECK_ARG(P != nullptr, "omp_decoder_run: null plan");
   OMP_CHECK_ARG(sample_env().ok && fused_sa_env().ok, "omp_decoder_run: OMP355_SAMPLE_BLOCK_MAX_ROWS / OMP355_FUSED_SA_MAX_ROWS must be non-negative integers");
@@ -1936,6 +1942,8 @@ extern "C" int omp_decoder_graph_reset(int slot) {
     OmpGraphSlot& gs = omp_cur().slots[slot];
     if (gs.exec) (void)hipGraphExecDestroy(gs.exec);
     if (gs.graph) (void)hipGraphDestroy(gs.graph);
+    if (gs.exec_n) (void)hipGraphExecDestroy(gs.exec_n);
+    if (gs.graph_n) (void)hipGraphDestroy(gs.graph_n);
     gs = OmpGraphSlot();
   }
   return OMP_OK;
@@ -1964,21 +1972,36 @@ extern "C" int omp_decoder_run(const omp_decoder_plan* P, int first_pos, int n_s
     }
     OMP_CHECK_ARG(graph_slot < OMP_MAX_GRAPH_SLOTS, "omp_decoder_run: graph slot %d out of range", graph_slot);
     OmpGraphSlot& gs = omp_cur().slots[graph_slot];
-    if (gs.exec == nullptr) {
-      hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-      if (e != hipSuccess) { omp_set_error("omp_decoder_run: begin capture: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
-      g_capturing = true;
-      int rc = step_launch(P, true, st);
-      if (rc == OMP_OK) rc = sample_and_advance(P, st);
-      g_capturing = false;
-      e = hipStreamEndCapture(st, &gs.graph);
-      if (rc != OMP_OK) return rc;
-      if (e != hipSuccess) { omp_set_error("omp_decoder_run: end capture: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
-      e = hipGraphInstantiate(&gs.exec, gs.graph, nullptr, nullptr, 0);
-      if (e != hipSuccess) { omp_set_error("omp_decoder_run: instantiate: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
+    // capture `steps` sampling steps of this plan into (graph, exec) once, then replay: a step reads its position from the device counter, so every
+    // step of a phase is the same launch sequence.  Consecutive graph launches are ~8.5 us apart on the GPU (profiles/r06f_pt_step_timeline_*): runs of
+    // OMP_GRAPH_RUN steps go out as ONE graph (round 6), the remainder as single-step graphs.
+    auto replay = [&](hipGraph_t& graph, hipGraphExec_t& exec, int steps) -> int {
+      if (exec == nullptr) {
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) { omp_set_error("omp_decoder_run: begin capture: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
+        g_capturing = true;
+        int rc = OMP_OK;
+        for (int k = 0; k < steps && rc == OMP_OK; ++k) {
+          rc = step_launch(P, true, st);
+          if (rc == OMP_OK) rc = sample_and_advance(P, st);
+        }
+        g_capturing = false;
+        e = hipStreamEndCapture(st, &graph);
+        if (rc != OMP_OK) return rc;
+        if (e != hipSuccess) { omp_set_error("omp_decoder_run: end capture: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { omp_set_error("omp_decoder_run: instantiate: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
+      }
+      const hipError_t e = hipGraphLaunch(exec, st);
+      if (e != hipSuccess) { omp_set_error("omp_decoder_run: graph launch: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
+      return OMP_OK;
+    };
+    if (graph_run_steps() > 1 && n_steps - i >= graph_run_steps()) {   // (every later position of this call samples too: pos only grows)
+      RUN(replay(gs.graph_n, gs.exec_n, graph_run_steps()));
+      i += graph_run_steps() - 1;
+      continue;
     }
-    hipError_t e = hipGraphLaunch(gs.exec, st);
-    if (e != hipSuccess) { omp_set_error("omp_decoder_run: graph launch: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
+    RUN(replay(gs.graph, gs.exec, 1));
   }
   return OMP_OK;
 }

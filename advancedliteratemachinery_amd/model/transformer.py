@@ -207,6 +207,7 @@ class Decoder(object):
         self.xcd_masks = {'poly': 0x0F, 'rec': 0xF0} if env_flag('OMP355_XCD_SPLIT', False) else {}
         self._x3_cache = {}   # kind -> (layers, head) with every matrix as its [w_hi | w_hi | w_lo] image (bf16x3 engine, R > 64)
 
+    GRAPH_RUN = 8       # positions per omp_decoder_run call of the two-stream polygon / recognition schedule (csrc/common.h OMP_GRAPH_RUN)
     X3_MIN_ROWS = 65    # phases with more rows run their products as split-bf16 products (csrc/decoder.hip: step_launch_x3)
     # bf16 engine: phases with at least this many rows run their Linear layers as row-owner chains (csrc/dec_rows.hip: 80 rows per
     # workgroup, weights streamed from L2): from ~50 workgroups on they beat the launch-per-Linear path (profiles/r05*_kbench_dec_rows*)
@@ -556,13 +557,18 @@ class Decoder(object):
             cur.wait_stream(sp)
             cur.wait_stream(sr)
             return self.instances_result(php), self.instances_result(phr)
-        for pos in range(max(np_, nr)):
+        # enqueue in runs of GRAPH_RUN positions, alternating between the two streams (both queues stay fed; omp_decoder_run replays a run of sampling
+        # steps as ONE graph: consecutive graph launches are ~8.5 us apart on the GPU)
+        # (few-row phases alternate step by step: their kernels are launch-bound and a stream that waits 8 steps for its turn idles --
+        # 8-image call 19.5 -> 21.1 ms with runs of 8, 160-image call 100.7 -> 99.3, KIE's 2048-row phases +1 %: profiles/r06l_*)
+        run = self.GRAPH_RUN if php.R >= 2048 else 1
+        for pos in range(0, max(np_, nr), run):
             if pos < np_:
                 with torch.cuda.stream(sp):
-                    self._run(php, pos, 1)
+                    self._run(php, pos, min(run, np_ - pos))
             if pos < nr:
                 with torch.cuda.stream(sr):
-                    self._run(phr, pos, 1)
+                    self._run(phr, pos, min(run, nr - pos))
         cur.wait_stream(sp)
         cur.wait_stream(sr)
         return self.instances_result(php), self.instances_result(phr)

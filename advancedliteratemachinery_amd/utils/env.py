@@ -18,7 +18,8 @@ error message, not a silently different engine.  Knobs that change a
   OMP355_DEC_PRIORITY  pipeline lanes: decoder streams at high priority (0 / 1, default 0)
 Read in C (csrc/decoder.hip), parsed strictly there -- anything but a non-negative integer fails every omp_decoder_run:
   OMP355_SAMPLE_BLOCK_MAX_ROWS  rows up to which sampling runs a workgroup per row (default 1024)
-  OMP355_FUSED_SA_MAX_ROWS      rows up to which the fused few-row self-attention kernel runs (default 63)"""
+  OMP355_FUSED_SA_MAX_ROWS      rows up to which the fused few-row self-attention kernel runs (default 63)
+  OMP355_GRAPH_RUN              8 (default): runs of 8 sampling steps replay as ONE hipGraph; 1: one graph launch per step (A/B)"""
 import os
 
 
