@@ -96,7 +96,7 @@ class _GraphSlots(object):
 
 # bounds of the per-decoder caches: a real evaluation has variable image sizes and instance counts, so
 # K/V slabs (100-200 MB per image size), phase buffers (KV caches, scratch) and captured graphs are LRU-evicted
-MAX_KV_ENTRIES = 3
+MAX_KV_ENTRIES = 4
 MAX_PHASES = 12
 MAX_SLOTS_PER_PHASE = 2
 
