@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16, OMP_BF16X2 = 0, 1, 2   # BF16X2: split-bf16 pair rows [hi | lo] (include/omp355.h)
 ABI_VERSION = 20
-STORE_PLAIN, STORE_KBLK, STORE_VBLK = 0, 2, 3
+STORE_PLAIN, STORE_KBLK, STORE_VBLK, STORE_ROWSTAT = 0, 2, 3, 4
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
 MAX_DEC_LAYERS = 8
@@ -131,6 +131,7 @@ _SIGS = {
     'omp_vit_patch_embed': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     'omp_vit_attn': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_a3_pool': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'omp_row_stat_merge': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'omp_row_argmax_prob': (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'omp_resize_normalize_pad': (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -408,6 +408,54 @@ __global__ __launch_bounds__(256) void gemm_dma(GemmP p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS writes only: the residual loads keep flying
   __builtin_amdgcn_s_barrier();
   stamp(3);                                      // accumulators of every wave are in LDS
+  if (p.store_mode == OMP_STORE_ROWSTAT) {
+    // greedy decoding without the logits (include/omp355.h, omp_row_stat_merge): per row and 64-column HALF of the tile the maximum of logit + bias,
+    // its column and the sum of exp(logit - maximum) over the valid columns.  A thread owns one row's half (two serial passes over 64 LDS values: no
+    // cross-lane reduction chains -- a first version reduced a row over 32 lanes with ten dependent shuffles per pass and took longer than the
+    // logits store it replaced); columns beyond N count as -inf, a half without a valid column stores {-inf, 0}.
+    if constexpr (std::is_same<TOut, float>::value && BM == 128 && BN == 128) {
+      const int row = tid & 127, half = tid >> 7;
+      const float* er = E + row * ES + half * 64;
+      const int nc0 = n0 + half * 64;
+      const bool bvec = bias != nullptr && !p.bias_m && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && nc0 + 64 <= p.N;
+      auto col = [&](int q, float (&v)[4]) {   // columns nc0 + 4 q .. + 3 of this row: logit + bias, -inf beyond N
+        const f32x4 t = *reinterpret_cast<const f32x4*>(er + 4 * q);
+        if (bvec) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + nc0 + 4 * q);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = t[u] + b4[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = nc0 + 4 * q + u;
+            v[u] = c < p.N ? t[u] + ((bias != nullptr && !p.bias_m) ? bias[c] : 0.f) : -INFINITY;
+          }
+        }
+      };
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll 4
+      for (int q = 0; q < 16; ++q) {
+        float v[4];
+        col(q, v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (v[u] > best) { best = v[u]; bi = nc0 + 4 * q + u; }   // ascending columns, strict >: the lowest index wins a tie
+      }
+      float sum = 0.f;
+      if (best > -INFINITY) {
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+          float v[4];
+          col(q, v);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sum += expf(v[u] - best);   // exp(-inf) = 0
+        }
+      }
+      if (m0 + row < p.M) reinterpret_cast<f32x4*>(p.C)[((int64_t)(m0 + row) * p.tiles_n + tn) * 2 + half] = f32x4{best, sum, __int_as_float(bi), 0.f};
+    }
+    return;
+  }
   if (n >= p.N) return;
   if (vec_path) {
     auto store_rows = [&](auto ACT) {
@@ -754,6 +802,7 @@ int launch_gemm(const GemmP& p0, hipStream_t st) {
     if (cx.gemm_choice_only) { cx.gemm_last_choice = 4; return OMP_OK; }
     return launch_small<T, TOut>(p, st);
   }
+  if (p.store_mode == OMP_STORE_ROWSTAT) which = 5;   // the row statistics live in the 128 x 128 kernel's epilogue
   if (which == 0) {
     // round 4 (profiles/r04b_kbench_dec_rows*.txt, the 10240-row polygon / recognition phases of a 160-image engine call): 64x64
     // tiles only below 256 tiles of 128x128 (they lose 10-25 % to the 128x128 kernel at 320 tiles, at K = 512 and at the bf16x3
@@ -1025,7 +1074,11 @@ extern "C" int omp_gemm_bias_act(const omp_gemm_args* a, omp_stream_t s) {
                   "omp_gemm_bias_act: C2 needs a residual, a plain 16-byte-aligned destination, M > 64 and N a multiple of the 16-byte chunk");
   }
   p.kv_B = a->kv_images; p.kv_tok = a->kv_tokens; p.kv_mpad = a->kv_mpad; p.kv_nH = a->kv_heads; p.kv_kb = a->kv_key_block;
-  if (p.store_mode != OMP_STORE_PLAIN) {
+  if (p.store_mode == OMP_STORE_ROWSTAT) {
+    OMP_CHECK_ARG(a->out_dtype == OMP_F32 && !a->trans_out && a->residual == nullptr && a->C2 == nullptr && a->ln_gamma == nullptr && !a->small_m_splitk &&
+                      a->act == OMP_ACT_NONE && !a->bias_along_m,
+                  "omp_gemm_bias_act: OMP_STORE_ROWSTAT takes an fp32 destination [M][2 ceil(N / 128)][4] and no residual / activation / C2 / trans_out / LayerNorm prologue");
+  } else if (p.store_mode != OMP_STORE_PLAIN) {
     OMP_CHECK_ARG(p.store_mode == OMP_STORE_KBLK || p.store_mode == OMP_STORE_VBLK, "omp_gemm_bias_act: bad store_mode %d", p.store_mode);
     OMP_CHECK_ARG(!a->trans_out && a->residual == nullptr && a->ln_gamma == nullptr && !a->small_m_splitk,
                   "omp_gemm_bias_act: blocked K/V stores take no residual / trans_out / LayerNorm prologue");

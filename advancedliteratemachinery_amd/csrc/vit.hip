@@ -333,7 +333,47 @@ __global__ __launch_bounds__(256) void row_argmax_prob_kernel(const float* __res
   }
 }
 
+// The tiles of a row (omp_gemm_bias_act, OMP_STORE_ROWSTAT) -> greedy id and its softmax probability.  One wave per row: the row's maximum over the
+// tiles' maxima (lowest column on ties: tiles ascend with the columns), then sum_t s_t exp(m_t - max).
+__global__ __launch_bounds__(256) void row_stat_merge_kernel(const f32x4* __restrict__ stats, int R, int nt, int32_t* __restrict__ ids,
+                                                             float* __restrict__ prob) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const f32x4* sr = stats + (int64_t)r * nt;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int t = lane; t < nt; t += 64) {
+    const f32x4 v = sr[t];
+    const int i = __float_as_int(v[2]);
+    if (v[0] > best || (v[0] == best && i < bi)) { best = v[0]; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  float sum = 0.f;
+  for (int t = lane; t < nt; t += 64) {
+    const f32x4 v = sr[t];
+    sum += v[1] * expf(v[0] - best);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) {
+    ids[r] = bi;
+    prob[r] = 1.0f / sum;
+  }
+}
+
 }  // namespace
+
+extern "C" int omp_row_stat_merge(const float* stats, int R, int n_tiles, int32_t* ids, float* prob, omp_stream_t s) {
+  OMP_CHECK_ARG(stats && ids && prob, "omp_row_stat_merge: null pointer");
+  OMP_CHECK_ARG(R > 0 && n_tiles > 0 && ((uintptr_t)stats % 16) == 0, "omp_row_stat_merge: bad shape / alignment");
+  hipLaunchKernelGGL(row_stat_merge_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)s, reinterpret_cast<const f32x4*>(stats), R, n_tiles, ids, prob);
+  OMP_CHECK_LAUNCH("omp_row_stat_merge");
+  return OMP_OK;
+}
 
 extern "C" int omp_vit_patch_embed(const float* img, const float* w, const float* bias, const float* cls,
                                    const float* pos, void* out, int out_dtype, int B, int H, int W, int E,

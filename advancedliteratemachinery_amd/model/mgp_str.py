@@ -161,6 +161,7 @@ class MGPSTR(nn.Module):
             self.register_parameter(pname, nn.Parameter(torch.zeros(*shape), requires_grad=False))
         self._engine, self._engine_key = None, None
         self.vit_attn_kernel = True    # bf16, 257 tokens: csrc/vit.hip::vit_attn_kernel; False = blocked cross-attention kernels
+        self.greedy_fused = True       # recognize(): wide heads decode from the head product's row statistics, no logits tensor (False: logits + arg-max pass; A/B, tests)
         self.eval()
 
     # reference key names in and out ----------------------------------------------------------------
@@ -248,7 +249,9 @@ class MGPSTR(nn.Module):
             ops.gemm(h, blk['w2'], blk['b2'], residual=x, out=x, a_wrap=h.shape[1])
         return x, B, T
 
-    def _a3_head(self, x, B, T, name, want_attn):
+    def _a3_head(self, x, B, T, name, want_attn, greedy=False):
+        """greedy=True (recognize): -> (attn, (ids [B, S], prob [B, S])) -- the head product keeps per-tile row statistics instead of writing the
+        logits (ops.gemm_row_argmax_prob; the BPE / WordPiece heads are 50 257 / 30 522 classes wide: 2.8 / 1.7 GB of fp32 per 512-word batch)."""
         e, c = self.engine(), self.cfg
         a, S = e.a3[name], c['max_len']
         if e.x3:
@@ -259,16 +262,24 @@ class MGPSTR(nn.Module):
             feat = ops.gemm(ys, a['wfeat'], out_dtype=f32, a_wrap=2 * E)
             pooled, attn = ops.a3_pool(sel, feat, B, T, S, want_attn)
             zs = ops.layernorm(pooled, a['n'][0], a['n'][1], out_dtype=ops.SPLIT, eps=LN_EPS_A3)
+            if greedy and self.greedy_fused and a['hw'].shape[0] >= self.GREEDY_FUSED_MIN_CLASSES:
+                i, p = ops.gemm_row_argmax_prob(zs, a['hw'], a['hb'], a_wrap=2 * E)
+                return attn, (i.view(B, S), p.view(B, S))
             logits = ops.gemm(zs, a['hw'], a['hb'], out_dtype=f32, a_wrap=2 * E)
-            return attn, logits.view(B, S, -1)
+            return attn, (ops.row_argmax_prob_2d(logits, B, S) if greedy else logits.view(B, S, -1))
         y = ops.layernorm(x, a['tn'][0], a['tn'][1], eps=LN_EPS_A3)
         t = ops.gemm(y, a['wg'])
         sel = ops.gemm(t, a['wsel'], out_dtype=torch.float32)                 # [B*T, S] fp32
         feat = ops.gemm(y, a['wfeat'])
         pooled, attn = ops.a3_pool(sel, feat, B, T, S, want_attn)
         z = ops.layernorm(pooled, a['n'][0], a['n'][1], out_dtype=self.engine_dtype, eps=LN_EPS_A3)
+        if greedy and self.greedy_fused and a['hw'].shape[0] >= self.GREEDY_FUSED_MIN_CLASSES:
+            i, p = ops.gemm_row_argmax_prob(z, a['hw'], a['hb'])
+            return attn, (i.view(B, S), p.view(B, S))
         logits = ops.gemm(z, a['hw'], a['hb'], out_dtype=torch.float32)
-        return attn, logits.view(B, S, -1)
+        return attn, (ops.row_argmax_prob_2d(logits, B, S) if greedy else logits.view(B, S, -1))
+
+    GREEDY_FUSED_MIN_CLASSES = 1024   # heads at least this wide decode greedily from the product's row statistics (the 38-class character head: one tile, nothing to save)
 
     @torch.no_grad()
     def forward(self, input, is_eval=False):
@@ -285,6 +296,18 @@ class MGPSTR(nn.Module):
                 outs.append(lg)
         return [attens] + outs if is_eval else outs
 
+    @torch.no_grad()
+    def greedy(self, input):
+        """The device part of recognition (test_final.py:145-170): -> [(ids int32 [B, S], prob fp32 [B, S])] for char / bpe / wp.  The wide heads
+        (BPE 50 257, WordPiece 30 522 classes) decode from the head product's per-tile row statistics -- no logits tensor (greedy_fused)."""
+        if self.training:
+            raise NotImplementedError('training is out of scope for the MI355X inference engine')
+        if not input.is_cuda:
+            raise RuntimeError('MGPSTR runs on MI355X only: pass device tensors; there is no CPU fallback')
+        with torch.cuda.device(input.device):
+            x, B, T = self.encode(input)
+            return [self._a3_head(x, B, T, name, False, greedy=True)[1] for name in GRANULARITIES]
+
     # result decoding (test_final.py:145-240) ---------------------------------------------------------
     @torch.no_grad()
     def recognize(self, input, bpe_vocab=None, wp_vocab=None):
@@ -293,13 +316,10 @@ class MGPSTR(nn.Module):
         GPT-2 `vocab.json` / BERT `vocab.txt` (or utils.mgp_tokens.BpeVocab / WordPieceVocab objects): the records then also
         carry `bpe_text`, `wp_text` and the fused `text` of test_final.py:196-236 (the reference fetches both tokenizers from
         the hub, utils.py:23-24; without the files the engine stops at ids + confidences)."""
-        outs = self.forward(input, is_eval=False)
-        B, S = outs[0].shape[0], outs[0].shape[1]
         ids, probs = [], []
-        for lg in outs:
-            i, p = ops.row_argmax_prob(lg.reshape(B * S, -1))
-            ids.append(i.view(B, S)[:, 1:].cpu())
-            probs.append(p.view(B, S)[:, 1:].cpu())
+        for i, p in self.greedy(input):
+            ids.append(i[:, 1:].cpu())
+            probs.append(p[:, 1:].cpu())
         res = decode_ids(ids, probs)
         if bpe_vocab is not None or wp_vocab is not None:
             from ..utils import mgp_tokens as MT

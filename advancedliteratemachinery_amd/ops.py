@@ -373,6 +373,28 @@ def row_argmax_prob(logits):
     return ids, prob
 
 
+def row_argmax_prob_2d(logits, B, S):
+    """row_argmax_prob of logits [B * S, V] as ([B, S] ids, [B, S] prob)"""
+    i, p = row_argmax_prob(logits.reshape(B * S, -1))
+    return i.view(B, S), p.view(B, S)
+
+
+def gemm_row_argmax_prob(A, W, bias=None, a_wrap=0):
+    """(ids int32 [M], prob fp32 [M]) of the rows of A W^T + bias WITHOUT materialising the [M, N] logits: the product stores per
+    (row, 128-column tile) its maximum, arg-max and sum of exponentials (omp_gemm_bias_act, OMP_STORE_ROWSTAT), omp_row_stat_merge folds
+    the tiles.  The same values as row_argmax_prob(gemm(A, W, bias, out_dtype=float32)) (identical product bits; the probability within
+    the rounding of a different summation order).  a_wrap: a split-pair A against the [hi | hi | lo] image of an fp32 weight (bf16x3)."""
+    M = A.numel() // A.shape[-1]
+    N = W.shape[0]
+    nt = 2 * ((N + 127) // 128)        # one record per 64-column half of a 128-column tile
+    stats = torch.empty((M, nt, 4), dtype=torch.float32, device=A.device)
+    gemm(A, W, bias, out=stats, out_dtype=torch.float32, store_mode=_lib.STORE_ROWSTAT, ldc=N, a_wrap=a_wrap)
+    ids = torch.empty(M, dtype=torch.int32, device=A.device)
+    prob = torch.empty(M, dtype=torch.float32, device=A.device)
+    _lib.check(_lib.lib().omp_row_stat_merge(ptr(stats), M, nt, ptr(ids), ptr(prob), stream()), 'omp_row_stat_merge')
+    return ids, prob
+
+
 class Context(object):
     """An omp_ctx: independent kernel selectors, captured decoder graphs and measurement brackets (include/omp355.h).
     `with ctx:` makes it current for the calling thread and restores the previous one; pipeline lane threads inherit the

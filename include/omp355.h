@@ -37,7 +37,7 @@ enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORT
  * bf16x3 engine: x.w ~ hi.w_hi + lo.w_hi + hi.w_lo on the bf16 matrix cores (see omp_gemm_args.a_wrap). */
 enum { OMP_F32 = 0, OMP_BF16 = 1, OMP_BF16X2 = 2 };
 enum { OMP_ACT_NONE = 0, OMP_ACT_GELU = 1, OMP_ACT_RELU = 2 };
-enum { OMP_STORE_PLAIN = 0, OMP_STORE_KBLK = 2, OMP_STORE_VBLK = 3 };
+enum { OMP_STORE_PLAIN = 0, OMP_STORE_KBLK = 2, OMP_STORE_VBLK = 3, OMP_STORE_ROWSTAT = 4 };
 /* decoder kinds (reference: model/transformer.py:26-33 pt/poly/rec decoders) */
 enum { OMP_DEC_PT = 0, OMP_DEC_POLY = 1, OMP_DEC_REC = 2 };
 
@@ -501,6 +501,14 @@ int omp_vit_patch_embed(const float* img, const float* w, const float* bias, con
 int omp_a3_pool(const float* sel, int ld_sel, const void* feat, int dtype, float* pooled, float* attn, int B, int T,
                 int S, int C, omp_stream_t s);
 
+/* Greedy decoding WITHOUT materialising the logits (round 6; MGP-STR's BPE / WordPiece heads: 13 824 rows x 50 257 / 30 522 classes are 2.8 / 1.7 GB
+ * of fp32 per forward that the head product writes and the arg-max pass reads back -- test_final.py:145-170 needs only the greedy id and its
+ * softmax probability).  omp_gemm_bias_act with store_mode = OMP_STORE_ROWSTAT (out_dtype f32; no residual / activation / second destination /
+ * transposed output) runs the product on 128 x 128 tiles and, instead of the logits, stores per (row, column tile) the tile's statistics into
+ * C = float [M][2 ceil(N / 128)][4], one record per 64-column half tile: {maximum of logit + bias, sum of exp(logit - maximum), index of the
+ * maximum (int32 bits, lowest index on ties), 0}; a half without a valid column holds {-inf, 0, .}.  omp_row_stat_merge folds a row's tiles: ids[r] = arg max, prob[r] = 1 / sum_tiles s_t exp(m_t - max) -- the values
+ * omp_row_argmax_prob computes from the full row (same product bits; the probability differs by the rounding of a different summation order). */
+int omp_row_stat_merge(const float* stats, int R, int n_records, int32_t* ids, float* prob, omp_stream_t s);   /* n_records = 2 ceil(N / 128) */
 /* Greedy id and its softmax probability for every row of logits fp32 [R, ld] (V columns used).  Replaces
  * topk(1) + softmax(...).max(dim=2) of test_final.py:145-170. */
 int omp_row_argmax_prob(const float* logits, int64_t ld, int R, int V, int32_t* ids, float* prob, omp_stream_t s);

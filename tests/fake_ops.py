@@ -89,3 +89,13 @@ def a3_pool(sel, feat, B, T, S, want_attn=True):
 def row_argmax_prob(logits):
     p, i = F.softmax(logits, dim=1).max(dim=1)
     return i.int(), p
+
+
+def row_argmax_prob_2d(logits, B, S):
+    i, p = row_argmax_prob(logits.reshape(B * S, -1))
+    return i.view(B, S), p.view(B, S)
+
+
+def gemm_row_argmax_prob(A, W, bias=None, a_wrap=0):
+    """include/omp355.h: OMP_STORE_ROWSTAT + omp_row_stat_merge == the greedy id / probability of the rows of A W^T + bias"""
+    return row_argmax_prob(gemm(A, W, bias, out_dtype=torch.float32, a_wrap=a_wrap))

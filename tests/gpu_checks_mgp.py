@@ -285,3 +285,60 @@ def check_crop_resizer():
         ref = np.asarray(Image.fromarray(imgs[bi]).crop((x0, y0, x1, y1)).resize((128, 32), Image.BICUBIC)).astype(np.float32) / np.float32(255.0)
         worst = max(worst, float((got[n] - torch.from_numpy(ref).permute(2, 0, 1)).abs().max()))
     return [rec('crop_resizer == Pillow bicubic', worst, 0.0)]
+
+
+def check_gemm_row_stats():
+    """omp_gemm_bias_act(OMP_STORE_ROWSTAT) + omp_row_stat_merge (round 6: greedy decoding without the logits tensor) against the path it replaces --
+    the same product written as fp32 logits, then omp_row_argmax_prob -- on ragged shapes: ids identical (the product bits are the same; ties go to
+    the lowest index in both), probabilities within 2e-6 relative (a different summation order of the exponentials).  Engines: bf16 operands, fp32
+    operands, and the bf16x3 form (split-pair rows against the [hi | hi | lo] weight image)."""
+    out = []
+    for (M, N, K) in ((300, 50257, 768), (129, 1104, 512), (64, 128, 256), (1000, 30522, 768)):
+        A, W, b = rnd(M, K, seed=M + 1), rnd(N, K, seed=N + 2) / K ** 0.5, rnd(N, seed=N + 3, scale=0.2)
+        b[7] += 3.0       # a clear winner somewhere, a planted exact tie elsewhere (rows 0 / 1 below)
+        for tag, mk in (('bf16', lambda t: t.to(DEV, torch.bfloat16)), ('fp32', lambda t: t.to(DEV))):
+            Ad, Wd, bd = mk(A), mk(W), b.to(DEV)
+            if M > 1 and N > 200:   # an exact tie: two identical weight rows with the same bias -> the lower index must win in both paths
+                Wd[150] = Wd[40]
+                bd[150] = bd[40] = 9.0
+            lg = ops.gemm(Ad, Wd, bd, out_dtype=torch.float32)
+            i0, p0 = ops.row_argmax_prob(lg)
+            i1, p1 = ops.gemm_row_argmax_prob(Ad, Wd, bd)
+            out.append(rec('gemm_row_stats[%s %dx%dx%d] ids identical' % (tag, M, N, K), float((i0 != i1).sum()), 0))
+            out.append(rec('gemm_row_stats[%s %dx%dx%d] probabilities (relative)' % (tag, M, N, K), ((p0 - p1).abs() / p0).max().item(), 2e-6))
+            if N > 200:
+                out.append(rec('gemm_row_stats[%s %dx%dx%d] the planted tie goes to the lower index' % (tag, M, N, K), float((i1 != 40).sum()) if tag == 'fp32' else 0.0, 0))
+        # bf16x3: split-pair activation rows against the [hi | hi | lo] image of the fp32 weight
+        As, W3, bd = ops.split_bf16(A.to(DEV)), ops.split_weight3(W.to(DEV)), b.to(DEV)
+        lg = ops.gemm(As, W3, bd, out_dtype=torch.float32, a_wrap=2 * K)
+        i0, p0 = ops.row_argmax_prob(lg)
+        i1, p1 = ops.gemm_row_argmax_prob(As, W3, bd, a_wrap=2 * K)
+        # (the logits path may take the fused three-product kernel, whose summation order differs in the last bits: ids may differ only at a near-tie)
+        lg_s = lg.sort(dim=-1, descending=True).values
+        near = (lg_s[:, 0] - lg_s[:, 1]) < 1e-4
+        out.append(rec('gemm_row_stats[bf16x3 %dx%dx%d] ids identical outside exact near-ties' % (M, N, K), float(((i0 != i1) & ~near).sum()), 0, '%d near-ties' % int(near.sum())))
+        out.append(rec('gemm_row_stats[bf16x3 %dx%dx%d] probabilities (relative)' % (M, N, K), ((p0 - p1).abs() / p0).max().item(), 1e-4))
+    return out
+
+
+def check_mgp_greedy_fused(dtype_name='bf16', B=64):
+    """MGPSTR.recognize with the wide heads decoding from the product's row statistics (greedy_fused, the default) against the logits + arg-max
+    pass it replaces: full ViT-B with the full vocabularies (BPE 50 257, WordPiece 30 522 classes), batch 64 -- ids of all three granularities,
+    the fused choice and the text identical, confidences within 1e-5."""
+    c = R.cfg()
+    sd = R.make_state_dict(c, seed=41)
+    model = build(c, sd, ENGINES[dtype_name])
+    img = rnd(B, 3, 32, 128, seed=78).clamp(-1, 1).to(DEV)
+    model.greedy_fused = False
+    ref = model.recognize(img)
+    model.greedy_fused = True
+    got = model.recognize(img)
+    bad = {k: 0 for k in ('char_ids', 'bpe_ids', 'wp_ids', 'choice', 'char_text')}
+    cerr = 0.0
+    for g, r in zip(got, ref):
+        for k in bad:
+            bad[k] += 0 if g[k] == r[k] else 1
+        cerr = max(cerr, max(abs(x - y) for x, y in zip(g['conf'], r['conf'])))
+    out = [rec('mgp_greedy_fused[%s] %s identical over %d words' % (dtype_name, k, B), v, 0) for k, v in bad.items()]
+    out.append(rec('mgp_greedy_fused[%s] confidences' % dtype_name, cerr, 1e-5))
+    return out

@@ -56,3 +56,15 @@ def test_crop_resizer_bit_exact_with_pillow(C):
 def test_two_stage_pipeline_matches_oracle_chain(C):
     """OmniParser detections -> device crops -> MGP-STR -> fused decoding."""
     _assert_all(C.check_two_stage())
+
+
+def test_gemm_row_statistics_equal_logits_then_argmax(C):
+    """round 6: OMP_STORE_ROWSTAT + omp_row_stat_merge == fp32 logits + omp_row_argmax_prob (ids identical, probabilities to rounding)"""
+    _assert_all(C.check_gemm_row_stats())
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'bf16x3', 'fp32'])
+def test_mgp_recognize_without_logits_tensor(C, dtype):
+    """MGPSTR.recognize: the BPE / WordPiece heads decode from the head product's row statistics -- same ids, choice, text, confidences as
+    logits + arg-max (test_final.py:145-240)"""
+    _assert_all(C.check_mgp_greedy_fused(dtype))

@@ -43,3 +43,39 @@ def test_bf16_flow_uses_32_key_blocks():
     # the oracle (to bf16 precision) shows the host passes the geometry the kernels document
     assert (outs[0][1] - rch).abs().max().item() < 0.3
     assert (outs[0][0] - ratt[0]).abs().max().item() < 2e-2
+
+
+def test_greedy_heads_decode_without_logits_on_the_wide_heads():
+    """MGPSTR.greedy / recognize (round 6): the BPE and WordPiece heads go through ops.gemm_row_argmax_prob (no logits tensor), the 38-class character
+    head through logits + arg-max; ids equal the oracle's arg-max either way, and with greedy_fused off."""
+    c = R.cfg(depth=1)
+    sd = R.make_state_dict(c, seed=9)
+    model = M.MGPSTR(dict(depth=1), engine_dtype='fp32')
+    eng = M._Engine(sd, model.cfg, model.engine_dtype, 'mgp_str.')
+    model.engine = lambda: eng
+    calls = []
+    real = M.ops
+    fused = fake_ops.gemm_row_argmax_prob
+
+    def spy(A, W, bias=None, a_wrap=0):
+        calls.append(W.shape[0])
+        return fused(A, W, bias, a_wrap)
+    fake_ops.gemm_row_argmax_prob = spy
+    M.ops = fake_ops
+    try:
+        img = torch.rand(2, 3, 32, 128, generator=torch.Generator().manual_seed(4)) * 2 - 1
+        x, Bn, T = model.encode(img)
+        res = {}
+        for on in (True, False):
+            model.greedy_fused = on
+            res[on] = [model._a3_head(x, Bn, T, n, False, greedy=True)[1] for n in M.GRANULARITIES]
+    finally:
+        M.ops = real
+        fake_ops.gemm_row_argmax_prob = fused
+    assert sorted(calls) == sorted([c['bpe_classes'], c['wp_classes']]) if 'bpe_classes' in c else len(calls) == 2   # the two wide heads, once (fused run only)
+    with torch.no_grad():
+        _, rch, rbp, rwp = R.forward(sd, c, img)
+    for on in (True, False):
+        for (i, p), rl in zip(res[on], (rch, rbp, rwp)):
+            assert tuple(i.shape) == tuple(rl.shape[:2]) and torch.equal(i.long(), rl.argmax(-1))
+            assert (p - rl.softmax(-1).max(-1).values).abs().max().item() < 1e-5
