@@ -559,8 +559,9 @@ class Decoder(object):
             return self.instances_result(php), self.instances_result(phr)
         # enqueue in runs of GRAPH_RUN positions, alternating between the two streams (both queues stay fed; omp_decoder_run replays a run of sampling
         # steps as ONE graph: consecutive graph launches are ~8.5 us apart on the GPU)
-        # (few-row phases alternate step by step: their kernels are launch-bound and a stream that waits 8 steps for its turn idles --
-        # 8-image call 19.5 -> 21.1 ms with runs of 8, 160-image call 100.7 -> 99.3, KIE's 2048-row phases +1 %: profiles/r06l_*)
+        # (few-row phases keep alternating step by step: runs of 8 bought them nothing -- the 8-image phase reads 19.7-21.1 ms with or without,
+        # box to box -- and a launch-bound stream that waits eight steps for its turn can only lose; 160-image call 100.7 -> 99.3 ms, KIE's
+        # 2048-row phases +1 %: profiles/r06l_*)
         run = self.GRAPH_RUN if php.R >= 2048 else 1
         for pos in range(0, max(np_, nr), run):
             if pos < np_:
