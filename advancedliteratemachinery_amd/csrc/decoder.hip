@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 2) void dec_self_attn_row_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
                                                                 T* __restrict__ out, const int32_t* __restrict__ d_pos, int R,
-                                                                int d, int Lmax) {
+                                                                int d, int Lmax, bf16_t* __restrict__ out_split = nullptr) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
@@ -263,6 +263,16 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 2) void dec_self_attn_row
   const float inv = 1.0f / l;
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] *= inv;
+  if (out_split != nullptr) {
+    // the parity engine's chains take the attention output as split pairs [R, 2 d] = [hi | lo] (hi = bf16(x), lo = bf16(x - hi): the planes
+    // omp_split_bf16 writes): written here, the fp32 tensor and the conversion launch behind it (42 MB per 10 240-row launch) do not exist
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { hi[i] = (bf16_t)o[i]; lo[i] = (bf16_t)(o[i] - (float)hi[i]); }
+    *reinterpret_cast<bf16x8*>(out_split + (int64_t)r * 2 * d + lane * 8) = hi;
+    *reinterpret_cast<bf16x8*>(out_split + (int64_t)r * 2 * d + d + lane * 8) = lo;
+    return;
+  }
   store8(out + (int64_t)r * d + lane * 8, o);
 }
 
@@ -1711,6 +1721,14 @@ int launch_fused_self_attn(const omp_decoder_plan* P, const omp_dec_layer& L, bo
   return OMP_OK;
 }
 
+// fp32 self-attention step of the many-row kernel writing SPLIT PAIRS (the parity engine's chains): omp_dec_self_attn_step + omp_split_bf16 in one launch
+int self_attn_rows_split(const omp_decoder_plan* P, const omp_dec_layer& L, void* out_split, hipStream_t st) {
+  hipLaunchKernelGGL((dec_self_attn_row_kernel<float>), dim3((P->R + 3) / 4), dim3(256), 0, st, reinterpret_cast<const float*>(P->qkv), reinterpret_cast<float*>(L.kcache),
+                     reinterpret_cast<float*>(L.vcache), reinterpret_cast<float*>(P->att), P->d_pos, P->R, P->d_model, P->Lmax, reinterpret_cast<bf16_t*>(out_split));
+  OMP_CHECK_LAUNCH("omp_decoder_run(self-attention, split pairs)");
+  return OMP_OK;
+}
+
 // Many-row phases (plan->rows_fused): the Linear layers as row-owner chains (bf16 engine: csrc/dec_rows.hip; parity engine, plan->gemm_x3:
 // csrc/dec_rows_x3.hip -- three bf16 matrix-core products per Linear over split operands, fp32 self-attention, split-plane cross-attention) --
 // embedding | q k v, then per layer self-attention, out-projection .. cross-attention query, cross-attention, out-projection .. FFN .. next
@@ -1747,8 +1765,12 @@ struct RowsStep {
   int pre_cross(int li, hipStream_t st) {
     const omp_dec_layer& L = P->layers[li];
     const int d = P->d_model, R = P->R;
-    RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, x3 ? OMP_F32 : OMP_BF16, R, P->n_heads, d, P->Lmax, st));
-    if (x3) RUN(omp_split_bf16(reinterpret_cast<const float*>(P->att), d, P->ffh, 2 * d, R, d, 0, st));
+    if (x3 && P->n_heads == 8 && omp_cur().self_attn_impl != 1) {
+      RUN(self_attn_rows_split(P, L, P->ffh, st));   // one wave per row whatever the row count (the chains' tests run 1 .. 64 rows too)
+    } else {
+      RUN(omp_dec_self_attn_step(P->qkv, L.kcache, L.vcache, P->att, P->d_pos, x3 ? OMP_F32 : OMP_BF16, R, P->n_heads, d, P->Lmax, st));
+      if (x3) RUN(omp_split_bf16(reinterpret_cast<const float*>(P->att), d, P->ffh, 2 * d, R, d, 0, st));
+    }
     a.wstream = L.rows_mid; a.wave_stride = L.rows_mid_stride;
     a.out_b = L.sa_out_b; a.ln_g = L.n2_g; a.ln_b = L.n2_b; a.qbias_tab = L.ca_qbias_tab;
     return omp_dec_rows_mid(&a, st);
