@@ -129,6 +129,7 @@ _SIGS = {
     'omp_debug_self_attn_impl': (c_int, [c_int]),
     'omp_debug_dec_fused': (c_int, [c_int]),
     'omp_vit_patch_embed': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
+    'omp_vit_attn_qkv': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_vit_attn': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_a3_pool': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'omp_row_stat_merge': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -26,7 +26,13 @@ namespace {
 //     in the order the V^T slab stores its keys, O^T = alpha O^T + V^T P^T, scaled by 1 / sum on the way out.
 // Through the blocked cross-attention kernels the same layer cost 5 row groups x (K + V^T streamed from L2) per
 // (image, head) and ran its last group for one query.
-template <int NB>   // 16-key score blocks (Mpad = 16 NB; NB even)
+// QKV (round 6): q, K and V are the three column groups of ONE token-major projection [B T, 3 nH 64] (timm's fused qkv Linear, mgp_str.py:72-73) --
+// K = q + nH 64, Vt = q + 2 nH 64, row pitch ldq.  The key rows go to LDS by the same DMA (source rows ldq apart, rows beyond T clamped: masked
+// below), and the V^T image is BUILT here: every thread loads 16-byte pieces of value rows (8 dims of a key) and scatters them as eight 2-byte LDS
+// writes into the blocked, slot-permuted layout the P V product reads (keys beyond T: zeros).  The blocked slabs cost the projections dearly: the
+// V^T slab's store path degenerates to one 2-byte store with two integer divisions per element when the tokens per image (257) are not a multiple
+// of 4 -- 540 us per block against 200 for the plain product of the same size (profiles/r06j_mgp_str_kernel_shapes.txt).
+template <int NB, bool QKV = false>   // 16-key score blocks (Mpad = 16 NB; NB even)
 __global__ __launch_bounds__(256, 2) void vit_attn_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out, int64_t ldo,
                                                           int T, int nH) {
@@ -38,7 +44,43 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(const bf16_t* __restri
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, g = lane >> 4;
   const int h = blockIdx.x, b = blockIdx.y;
   const int64_t slab = ((int64_t)b * nH + h) * MP * 64;
-  {
+  if constexpr (QKV) {
+    const int dr = lane >> 3, dc = (lane & 7) ^ dr;
+    const bf16_t* kb_ = K + (int64_t)b * T * ldq + h * 64 + dc * 8;
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+      int key = i * 32 + wave * 8 + dr;
+      if (key > T - 1) key = T - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb_ + (int64_t)key * ldq),
+                                       (__attribute__((address_space(3))) void*)(lds + (i * 32 + wave * 8) * 128), 16, 0, 0);
+    }
+    // V^T image: element (key j = 32 s + kl, dim d) -> row 32 s + d / 2, byte (d & 1) * 64 + 2 slot(kl), 16-byte chunks XOR-swizzled by the row
+    constexpr int PIECES = MP * 8, PER = (PIECES + 255) / 256;
+    const bf16_t* vb_ = Vt + (int64_t)b * T * ldq + h * 64;
+    frag vr[PER];
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      const int idx = it * 256 + (int)threadIdx.x, j = idx >> 3, c8 = idx & 7;
+      frag z;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) z[u] = (bf16_t)0.f;
+      vr[it] = (idx < PIECES && j < T) ? *reinterpret_cast<const frag*>(vb_ + (int64_t)j * ldq + c8 * 8) : z;
+    }
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      const int idx = it * 256 + (int)threadIdx.x, j = idx >> 3, c8 = idx & 7;
+      if (idx < PIECES) {
+        const int s_ = j >> 5, kl = j & 31;
+        const int slot = ((kl & 15) >> 2) * 8 + (kl >> 4) * 4 + (kl & 3);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int d = c8 * 8 + u, rw = d >> 1, byte = (d & 1) * 64 + slot * 2;
+          *reinterpret_cast<bf16_t*>(lds + KBYTES + (s_ * 32 + rw) * 128 + ((((byte >> 4) ^ (rw & 7))) << 4) + (byte & 15)) = vr[it][u];
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else {
     const int dr = lane >> 3, dc = (lane & 7) ^ dr;
     const bf16_t* ks = K + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
     const bf16_t* vs = Vt + slab + (int64_t)(wave * 8 + dr) * 64 + dc * 8;
@@ -417,6 +459,31 @@ extern "C" int omp_vit_attn(const void* q, int64_t ldq, const void* K, const voi
   hipLaunchKernelGGL(kern, dim3(nH, B), dim3(256), smem, (hipStream_t)s, (const bf16_t*)q, ldq, (const bf16_t*)K,
                      (const bf16_t*)Vt, (bf16_t*)out, ldo, T, nH);
   OMP_CHECK_LAUNCH("omp_vit_attn");
+  return OMP_OK;
+}
+
+extern "C" int omp_vit_attn_qkv(const void* qkv, int64_t ld, void* out, int64_t ldo, int dtype, int B, int T, int nH, omp_stream_t s) {
+  OMP_CHECK_ARG(qkv && out, "omp_vit_attn_qkv: null pointer");
+  OMP_CHECK_ARG(B > 0 && T > 0 && nH > 0 && ld >= 3 * (int64_t)nH * 64 && ld % 8 == 0 && ldo % 4 == 0 && ((uintptr_t)qkv % 16) == 0,
+                "omp_vit_attn_qkv: qkv is [B T, 3 nH 64] with a row pitch that is a multiple of 8 elements (B=%d T=%d nH=%d ld=%lld)", B, T, nH, (long long)ld);
+  if (dtype != OMP_BF16 || T > 288) {
+    omp_set_error("omp_vit_attn_qkv: built for bf16 and at most 288 tokens per image (MGP-STR's ViT: 257)");
+    return OMP_ERR_UNSUPPORTED;
+  }
+  constexpr int NB = 18;
+  constexpr size_t smem = 2 * (size_t)NB * 16 * 128;
+  auto kern = vit_attn_kernel<NB, true>;
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      omp_set_error("omp_vit_attn_qkv: cannot raise dynamic LDS limit");
+      return OMP_ERR_LAUNCH;
+    }
+    done = true;
+  }
+  const bf16_t* q = reinterpret_cast<const bf16_t*>(qkv);
+  hipLaunchKernelGGL(kern, dim3(nH, B), dim3(256), smem, (hipStream_t)s, q, ld, q + nH * 64, q + 2 * nH * 64, (bf16_t*)out, ldo, T, nH);
+  OMP_CHECK_LAUNCH("omp_vit_attn_qkv");
   return OMP_OK;
 }
 

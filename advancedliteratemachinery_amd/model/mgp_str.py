@@ -107,6 +107,8 @@ class _Engine(object):
                 n2=(f32(b + 'norm2.weight'), f32(b + 'norm2.bias')),
                 w1=mat(f32(b + 'mlp.fc1.weight')), b1=f32(b + 'mlp.fc1.bias'),
                 w2=mat(f32(b + 'mlp.fc2.weight')), b2=f32(b + 'mlp.fc2.bias')))
+            if not self.x3 and dtype == torch.bfloat16:   # the fused projection of the token-major attention path (ops.vit_attn_qkv)
+                self.blocks[-1].update(wqkv=mat(qkv_w), bqkv=qkv_b.contiguous())
         self.a3 = {}
         for name in GRANULARITIES:
             t = name + '_tokenLearner.'
@@ -161,6 +163,7 @@ class MGPSTR(nn.Module):
             self.register_parameter(pname, nn.Parameter(torch.zeros(*shape), requires_grad=False))
         self._engine, self._engine_key = None, None
         self.vit_attn_kernel = True    # bf16, 257 tokens: csrc/vit.hip::vit_attn_kernel; False = blocked cross-attention kernels
+        self.vit_qkv_fused = True      # bf16: q | k | v as ONE token-major product, V^T built in LDS by the attention kernel (False: blocked K / V^T slabs; A/B, tests)
         self.greedy_fused = True       # recognize(): wide heads decode from the head product's row statistics, no logits tensor (False: logits + arg-max pass; A/B, tests)
         self.eval()
 
@@ -209,15 +212,22 @@ class MGPSTR(nn.Module):
         geom = (B, T, Mpad, nH, KB)
         y = torch.empty_like(x)
         att = torch.empty_like(x)
+        fused_qkv = self.vit_attn_kernel and self.vit_qkv_fused and dt == torch.bfloat16 and T <= 288 and 'wqkv' in e.blocks[0]
+        qkv = torch.empty((B * T, 3 * E), dtype=dt, device=x.device) if fused_qkv else None
         for blk in e.blocks:
             ops.layernorm(x, blk['n1'][0], blk['n1'][1], out=y, eps=LN_EPS_BLOCK)
-            q = ops.gemm(y, blk['wq'], blk['bq'])
-            ops.gemm(y, blk['wk'], blk['bk'], out=K, store_mode=_lib.STORE_KBLK, kv=geom)
-            ops.gemm(blk['wv'], y, blk['bv'], out=Vt, store_mode=_lib.STORE_VBLK, kv=geom, bias_along_m=True, M=E, N=B * T, K=E)
-            if self.vit_attn_kernel and dt == torch.bfloat16 and Mpad == 288:
-                ops.vit_attn(q, K[0], Vt[0], att, B, T, nH, Mpad)     # one workgroup per (image, head), K / V^T in LDS
+            if fused_qkv:
+                # ONE plain product [B T, 3 E] (timm's fused qkv Linear); the attention kernel reads its three column groups and builds V^T in LDS
+                ops.gemm(y, blk['wqkv'], blk['bqkv'], out=qkv)
+                ops.vit_attn_qkv(qkv, att, B, T, nH)
             else:
-                ops.dec_cross_attn_step(q, K[0], Vt[0], nH * Mpad * 64, Mpad, None, groups, n_groups, 4, None, att, T, nH, 1)
+                q = ops.gemm(y, blk['wq'], blk['bq'])
+                ops.gemm(y, blk['wk'], blk['bk'], out=K, store_mode=_lib.STORE_KBLK, kv=geom)
+                ops.gemm(blk['wv'], y, blk['bv'], out=Vt, store_mode=_lib.STORE_VBLK, kv=geom, bias_along_m=True, M=E, N=B * T, K=E)
+                if self.vit_attn_kernel and dt == torch.bfloat16 and Mpad == 288:
+                    ops.vit_attn(q, K[0], Vt[0], att, B, T, nH, Mpad)     # one workgroup per (image, head), K / V^T in LDS
+                else:
+                    ops.dec_cross_attn_step(q, K[0], Vt[0], nH * Mpad * 64, Mpad, None, groups, n_groups, 4, None, att, T, nH, 1)
             ops.gemm(att, blk['wo'], blk['bo'], residual=x, out=x)
             ops.layernorm(x, blk['n2'][0], blk['n2'][1], out=y, eps=LN_EPS_BLOCK)
             h = ops.gemm(y, blk['w1'], blk['b1'], act=ops.ACT_GELU)

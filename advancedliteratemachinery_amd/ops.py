@@ -353,6 +353,14 @@ def vit_attn(q, K, Vt, out, B, T, nH, Mpad):
     return out
 
 
+def vit_attn_qkv(qkv, out, B, T, nH):
+    """bf16 ViT self-attention on the token-major fused projection qkv [B*T, 3*nH*64] = [q | k | v] -> out [B*T, nH*64]: one workgroup per
+    (image, head), keys by strided DMA, the blocked V^T image built in LDS by the kernel (omp_vit_attn_qkv)."""
+    rc = _lib.lib().omp_vit_attn_qkv(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), dt(qkv), B, T, nH, stream())
+    _lib.check(rc, 'omp_vit_attn_qkv')
+    return out
+
+
 def a3_pool(sel, feat, B, T, S, want_attn=True):
     """sel fp32 [B*T, >=S], feat [B*T, C] -> (pooled fp32 [B*S, C], maps fp32 [B, S, T] or None)."""
     C = feat.shape[-1]

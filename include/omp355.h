@@ -488,6 +488,10 @@ int omp_kv_project_rows(const void* rows, const void* wstream, int64_t wave_stri
  * OMP_ERR_UNSUPPORTED and are served by omp_dec_cross_attn_step on the same slabs. */
 int omp_vit_attn(const void* q, int64_t ldq, const void* K, const void* Vt, int Mpad, void* out, int64_t ldo,
                  int dtype, int B, int T, int nH, omp_stream_t s);
+/* The same attention on ONE token-major projection qkv [B T, 3 nH 64] = [q | k | v] (timm's fused qkv Linear, modules/mgp_str.py:72-73; round 6): the key
+ * rows reach LDS by strided DMA and the kernel builds the blocked V^T image itself, so the projection is one plain product of N = 3 nH 64 instead of a
+ * plain one and two with blocked-slab epilogues (the V^T slab store costs 2.7x a plain product at 257 tokens per image).  bf16, T <= 288. */
+int omp_vit_attn_qkv(const void* qkv, int64_t ld, void* out, int64_t ldo, int dtype, int B, int T, int nH, omp_stream_t s);
 
 /* Patch embedding + cls token + position embedding.  Replaces timm PatchEmbed (Conv2d(3,E,4,4) -> flatten ->
  * transpose) and modules/mgp_str.py:66-70.  img NCHW fp32 [B,3,H,W] (H, W multiples of 4); w [E,3,4,4], bias [E],

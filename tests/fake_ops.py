@@ -99,3 +99,13 @@ def row_argmax_prob_2d(logits, B, S):
 def gemm_row_argmax_prob(A, W, bias=None, a_wrap=0):
     """include/omp355.h: OMP_STORE_ROWSTAT + omp_row_stat_merge == the greedy id / probability of the rows of A W^T + bias"""
     return row_argmax_prob(gemm(A, W, bias, out_dtype=torch.float32, a_wrap=a_wrap))
+
+
+def vit_attn_qkv(qkv, out, B, T, nH):
+    """test double of omp_vit_attn_qkv: softmax(q k^T / 8) v per (image, head) on the token-major fused projection [B*T, 3*nH*64]"""
+    E = nH * 64
+    x = qkv.float().reshape(B, T, 3, nH, 64)
+    q, k, v = x[:, :, 0].permute(0, 2, 1, 3), x[:, :, 1].permute(0, 2, 1, 3), x[:, :, 2].permute(0, 2, 1, 3)
+    att = F.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v
+    out.copy_(att.permute(0, 2, 1, 3).reshape(B * T, E).to(out.dtype))
+    return out

@@ -342,3 +342,26 @@ def check_mgp_greedy_fused(dtype_name='bf16', B=64):
     out = [rec('mgp_greedy_fused[%s] %s identical over %d words' % (dtype_name, k, B), v, 0) for k, v in bad.items()]
     out.append(rec('mgp_greedy_fused[%s] confidences' % dtype_name, cerr, 1e-5))
     return out
+
+
+def check_vit_attn_qkv(B=5):
+    """omp_vit_attn_qkv (round 6: q | k | v as ONE token-major product, keys by strided DMA, the blocked V^T image built in LDS by the kernel) against
+    the blocked-slab path it replaces (three projections with OMP_STORE_KBLK / OMP_STORE_VBLK epilogues + omp_vit_attn): the products are the same
+    bits, the attention arithmetic is the same kernel body, so the encoder's token stream must be IDENTICAL bit for bit; and against the oracle's
+    encoder under the bf16 gate.  Full ViT-B width, 2 blocks, 5 images (257 tokens: the ragged last key block, the padded keys)."""
+    c = R.cfg(depth=2)
+    sd = R.make_state_dict(c, seed=51)
+    model = build(c, sd, torch.bfloat16)
+    img = rnd(B, 3, 32, 128, seed=79).clamp(-1, 1)
+    res = {}
+    for on in (False, True):
+        model.vit_qkv_fused = on
+        x, _, T = model.encode(img.to(DEV))
+        torch.cuda.synchronize()
+        res[on] = x.float().cpu().clone()
+    with torch.no_grad():
+        ref = R.encoder(sd, c, img).reshape(res[True].shape)
+    scale = ref.abs().max().item()
+    return [rec('vit_attn_qkv: encoder tokens identical to the blocked-slab path, bit for bit', 0 if torch.equal(res[True], res[False]) else (res[True] - res[False]).abs().max().item() + 1e-9, 0),
+            rec('vit_attn_qkv: encoder tokens vs oracle (relative)', (res[True] - ref).abs().max().item() / scale, 0.03),
+            rec('vit_attn_qkv: the output is not trivially zero', 0 if res[True].abs().sum().item() > 0 else 1, 0)]

@@ -68,3 +68,8 @@ def test_mgp_recognize_without_logits_tensor(C, dtype):
     """MGPSTR.recognize: the BPE / WordPiece heads decode from the head product's row statistics -- same ids, choice, text, confidences as
     logits + arg-max (test_final.py:145-240)"""
     _assert_all(C.check_mgp_greedy_fused(dtype))
+
+
+def test_vit_attention_on_the_fused_qkv_projection(C):
+    """round 6: one token-major q | k | v product + omp_vit_attn_qkv == three projections into blocked slabs + omp_vit_attn, bit for bit"""
+    _assert_all(C.check_vit_attn_qkv())

@@ -7,10 +7,11 @@ from oracle import mgp_str_ref as R
 from tests import fake_ops
 
 
-def _run(dtype, depth=2, B=2):
+def _run(dtype, depth=2, B=2, qkv_fused=True):
     c = R.cfg(depth=depth)
     sd = R.make_state_dict(c, seed=9)
     model = M.MGPSTR(dict(depth=depth), engine_dtype=dtype)
+    model.vit_qkv_fused = qkv_fused
     eng = M._Engine(sd, model.cfg, model.engine_dtype, 'mgp_str.')
     model.engine = lambda: eng
     real = M.ops
@@ -37,8 +38,15 @@ def test_fp32_flow_matches_oracle():
         assert torch.equal(i.long().reshape(rl.shape[:2]), rl.argmax(-1))
 
 
-def test_bf16_flow_uses_32_key_blocks():
+def test_bf16_flow_with_the_fused_qkv_projection():
+    """round 6: q | k | v as ONE token-major product + omp_vit_attn_qkv (no K / V^T slabs): the host passes the layout the kernel documents"""
     outs, _, (ratt, rch, rbp, rwp), _ = _run('bf16', depth=1)
+    assert (outs[0][1] - rch).abs().max().item() < 0.3
+    assert (outs[0][0] - ratt[0]).abs().max().item() < 2e-2
+
+
+def test_bf16_flow_uses_32_key_blocks():
+    outs, _, (ratt, rch, rbp, rwp), _ = _run('bf16', depth=1, qkv_fused=False)
     # bf16 slabs use 32-key blocks in matrix-core slot order: the double undoes the permutation, so agreement with
     # the oracle (to bf16 precision) shows the host passes the geometry the kernels document
     assert (outs[0][1] - rch).abs().max().item() < 0.3
