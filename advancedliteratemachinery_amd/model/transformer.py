@@ -208,7 +208,7 @@ class Decoder(object):
         self._x3_cache = {}   # kind -> (layers, head) with every matrix as its [w_hi | w_hi | w_lo] image (bf16x3 engine, R > 64)
 
     GRAPH_RUN = 8       # positions per omp_decoder_run call of the two-stream polygon / recognition schedule (csrc/common.h OMP_GRAPH_RUN)
-    X3_MIN_ROWS = 65    # phases with more rows run their products as split-bf16 products (csrc/decoder.hip: step_launch_x3)
+    X3_MIN_ROWS = env_int('OMP355_X3_MIN', 65, 65, 1 << 30)    # phases with more rows run their products as split-bf16 products (csrc/decoder.hip: step_launch_x3)
     # bf16 engine: phases with at least this many rows run their Linear layers as row-owner chains (csrc/dec_rows.hip: 80 rows per
     # workgroup, weights streamed from L2): from ~50 workgroups on they beat the launch-per-Linear path (profiles/r05*_kbench_dec_rows*)
     ROWS_MIN_ROWS = env_int('OMP355_ROWS_MIN', 4096, 1, 1 << 30)

@@ -15,6 +15,8 @@ error message, not a silently different engine.  Knobs that change a
   OMP355_SIDE_PRIO     the model's polygon / recognition side streams at high priority (0 / 1, default 0: they cost the pipelined lanes their hardware queues)
   OMP355_XCD_SPLIT     each decoder's many-row chains on its own four XCDs (0 / 1, default 0: chain HBM traffic 1.30x -> 1.14x algorithmic, but the
                        phase 98 -> 109 ms: the other decoder's cross-attention is left with four XCDs' share of the fabric; profiles/r06d_*)
+  OMP355_X3_MIN        bf16x3 engine: rows from which a decoder phase runs its products as split-bf16 GEMMs (default 65; 161 puts the 160-row point phase
+                       on the fp32 few-row kernels: measured slower, profiles/r06y_*)
   OMP355_DEC_PRIORITY  pipeline lanes: decoder streams at high priority (0 / 1, default 0)
 Read in C (csrc/decoder.hip), parsed strictly there -- anything but a non-negative integer fails every omp_decoder_run:
   OMP355_SAMPLE_BLOCK_MAX_ROWS  rows up to which sampling runs a workgroup per row (default 1024)
