@@ -1999,16 +1999,27 @@ extern "C" int omp_decoder_run(const omp_decoder_plan* P, int first_pos, int n_s
     // OMP_GRAPH_RUN steps go out as ONE graph (round 6), the remainder as single-step graphs.
     auto replay = [&](hipGraph_t& graph, hipGraphExec_t& exec, int steps) -> int {
       if (exec == nullptr) {
-        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        // Captured on a stream of this THREAD's own, never on the caller's: while a stream is capturing, HIP refuses hipEventSynchronize / Query on
+        // every event last recorded in it -- also on completion events of EARLIER work, which another host thread may be waiting on (a pipeline
+        // lane captures the graphs of its next call while the submitter waits for its previous one: tests/test_gpu_e2e.py::
+        // test_pipelined_lanes_match_direct failed with hipErrorCapturedEvent once in eight runs, more often since a capture holds eight steps).
+        // Kernel nodes are not bound to the stream they were captured from; the graph is launched on the caller's stream below.
+        static thread_local hipStream_t cap = nullptr;
+        if (cap == nullptr && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) {
+          cap = nullptr;
+          omp_set_error("omp_decoder_run: cannot create the capture stream");
+          return OMP_ERR_LAUNCH;
+        }
+        hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) { omp_set_error("omp_decoder_run: begin capture: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
         g_capturing = true;
         int rc = OMP_OK;
         for (int k = 0; k < steps && rc == OMP_OK; ++k) {
-          rc = step_launch(P, true, st);
-          if (rc == OMP_OK) rc = sample_and_advance(P, st);
+          rc = step_launch(P, true, cap);
+          if (rc == OMP_OK) rc = sample_and_advance(P, cap);
         }
         g_capturing = false;
-        e = hipStreamEndCapture(st, &graph);
+        e = hipStreamEndCapture(cap, &graph);
         if (rc != OMP_OK) return rc;
         if (e != hipSuccess) { omp_set_error("omp_decoder_run: end capture: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
