@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libomp355.so')
 
 OMP_F32, OMP_BF16, OMP_BF16X2 = 0, 1, 2   # BF16X2: split-bf16 pair rows [hi | lo] (include/omp355.h)
-ABI_VERSION = 20
+ABI_VERSION = 21
 STORE_PLAIN, STORE_KBLK, STORE_VBLK, STORE_ROWSTAT = 0, 2, 3, 4
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DEC_PT, DEC_POLY, DEC_REC = 0, 1, 2
@@ -117,6 +117,8 @@ _SIGS = {
     'omp_decoder_run': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_int, c_int, c_void_p]),
     'omp_decoder_run_pair': (c_int, [ctypes.POINTER(DecoderPlan), ctypes.POINTER(DecoderPlan), c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'omp_decoder_graph_reset': (c_int, [c_int]),
+    'omp_capture_gate_enter': (c_int, []),
+    'omp_capture_gate_leave': (c_int, []),
     'omp_decoder_step_logits': (c_int, [ctypes.POINTER(DecoderPlan), c_int, c_void_p]),
     'omp_debug_force_gemm_kernel': (c_int, [c_int]),
     'omp_debug_gemm_choice': (c_int, [c_void_p]),

@@ -13,6 +13,7 @@
 // step is position-independent on the host side and can be replayed as a hipGraph.
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -1356,6 +1357,14 @@ __global__ __launch_bounds__(64) void pack_spotting_kernel(const int32_t* __rest
 // ---------------------------------------------------------------------------------------------
 // optional hipEvent bracketing of the cross-attention kernel (bench.py's roofline measurement)
 thread_local bool g_capturing = false;   // one host thread per pipeline lane may be capturing
+// The capture gate (round 6).  omp_decoder_run captures its graphs on the CALLER's stream (a graph captured on another stream and launched on
+// the caller's was measured: the polygon || recognition graphs then serialise, 100 -> 120 ms per 160 images, profiles/r06ze_*).  While a stream
+// captures, HIP refuses -- and INVALIDATES the capture on -- hipEventSynchronize / hipEventQuery / hipStreamWaitEvent of any event last recorded
+// in that stream, completion events of EARLIER, uncaptured work included; another host thread waiting for a pipeline lane's previous call does
+// exactly that (tests/test_gpu_e2e.py::test_pipelined_lanes_match_direct: hipErrorCapturedEvent once in nine full suites).  A capture therefore
+// holds this process-wide mutex from begin to end, and host threads take it (omp_capture_gate_enter / _leave, include/omp355.h) around
+// NON-BLOCKING event operations on another thread's streams.  Graphs are captured once per slot: steady-state calls never touch the mutex.
+static std::mutex g_capture_gate;
 
 
 template <typename T, int QT, int PD, bool NT = false>
@@ -1959,6 +1968,9 @@ extern "C" int omp_debug_cross_q4(int on) {
   return OMP_OK;
 }
 
+extern "C" int omp_capture_gate_enter(void) { g_capture_gate.lock(); return OMP_OK; }
+extern "C" int omp_capture_gate_leave(void) { g_capture_gate.unlock(); return OMP_OK; }
+
 extern "C" int omp_decoder_graph_reset(int slot) {
   if (slot >= 0 && slot < OMP_MAX_GRAPH_SLOTS) {
     OmpGraphSlot& gs = omp_cur().slots[slot];
@@ -1999,27 +2011,17 @@ extern "C" int omp_decoder_run(const omp_decoder_plan* P, int first_pos, int n_s
     // OMP_GRAPH_RUN steps go out as ONE graph (round 6), the remainder as single-step graphs.
     auto replay = [&](hipGraph_t& graph, hipGraphExec_t& exec, int steps) -> int {
       if (exec == nullptr) {
-        // Captured on a stream of this THREAD's own, never on the caller's: while a stream is capturing, HIP refuses hipEventSynchronize / Query on
-        // every event last recorded in it -- also on completion events of EARLIER work, which another host thread may be waiting on (a pipeline
-        // lane captures the graphs of its next call while the submitter waits for its previous one: tests/test_gpu_e2e.py::
-        // test_pipelined_lanes_match_direct failed with hipErrorCapturedEvent once in eight runs, more often since a capture holds eight steps).
-        // Kernel nodes are not bound to the stream they were captured from; the graph is launched on the caller's stream below.
-        static thread_local hipStream_t cap = nullptr;
-        if (cap == nullptr && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) {
-          cap = nullptr;
-          omp_set_error("omp_decoder_run: cannot create the capture stream");
-          return OMP_ERR_LAUNCH;
-        }
-        hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+        std::lock_guard<std::mutex> gate(g_capture_gate);   // held until the graph is instantiated: see g_capture_gate
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) { omp_set_error("omp_decoder_run: begin capture: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
         g_capturing = true;
         int rc = OMP_OK;
         for (int k = 0; k < steps && rc == OMP_OK; ++k) {
-          rc = step_launch(P, true, cap);
-          if (rc == OMP_OK) rc = sample_and_advance(P, cap);
+          rc = step_launch(P, true, st);
+          if (rc == OMP_OK) rc = sample_and_advance(P, st);
         }
         g_capturing = false;
-        e = hipStreamEndCapture(cap, &graph);
+        e = hipStreamEndCapture(st, &graph);
         if (rc != OMP_OK) return rc;
         if (e != hipSuccess) { omp_set_error("omp_decoder_run: end capture: %s", hipGetErrorString(e)); return OMP_ERR_LAUNCH; }
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);

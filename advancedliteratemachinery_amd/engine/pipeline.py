@@ -15,6 +15,7 @@ engine/val.py:19-35 processes one image at a time, synchronously.
 import os
 import queue
 import threading
+import time
 from concurrent.futures import Future
 
 import torch
@@ -47,9 +48,42 @@ class Lane(object):
         return self._dec
 
 
+class LaneEvent(object):
+    """Completion event of a lane job, safe to wait on from ANOTHER host thread.  The event is recorded on the lane's stream, and the lane's worker
+    may already be capturing the decoder graphs of its NEXT job on that stream: while a stream is capturing, HIP refuses hipEventSynchronize /
+    hipEventQuery / hipStreamWaitEvent for every event last recorded in it -- earlier, uncaptured work included -- and invalidates the capture
+    (hipErrorCapturedEvent / hipErrorStreamCaptureIsolation; observed once in nine full GPU suites, tests/test_gpu_e2e.py::
+    test_pipelined_lanes_match_direct).  Every call below therefore runs inside the library's capture gate (ops.capture_gate: the mutex a
+    capture holds from begin to instantiate), and only NON-BLOCKING calls do: synchronize() polls.  Graphs are captured once per slot, so in
+    steady state the gate is never contended.
+    (Measured and not kept: capturing on a private stream and launching the graph on the lane's -- graphs captured off their launch stream
+    serialise against each other, polygon || recognition 100 -> 120 ms per 160 images, profiles/r06ze_*, r06zf_*; retrying the refused call
+    -- the refusal has already invalidated the lane's capture, profiles/r06zg_*.)"""
+    __slots__ = ('event',)
+
+    def __init__(self, event):
+        self.event = event
+
+    def query(self):
+        from .. import ops
+        with ops.capture_gate():
+            return self.event.query()
+
+    def synchronize(self, poll_s=0.0001):
+        while not self.query():
+            time.sleep(poll_s)
+
+    def wait(self, stream=None):
+        """make `stream` (default: the current stream) wait for the lane job"""
+        from .. import ops
+        st = stream if stream is not None else torch.cuda.current_stream()
+        with ops.capture_gate():
+            st.wait_event(self.event)
+
+
 class LanePool(object):
     """submit(fn) runs fn(lane) on the next lane (round robin) inside that lane's stream context and
-    returns a Future of (result, event); the event is recorded on the lane stream after fn's last launch."""
+    returns a Future of (result, LaneEvent); the event is recorded on the lane stream after fn's last launch."""
 
     def __init__(self, device, n_lanes, dec_priority=None, side_streams=True):
         """side_streams=False: every lane is ONE HIP stream.  The runtime multiplexes streams onto a few hardware queues
@@ -95,7 +129,7 @@ class LanePool(object):
                     res = fn(lane)
                     ev = torch.cuda.Event()
                     ev.record(lane.stream)
-                fut.set_result((res, ev))
+                fut.set_result((res, LaneEvent(ev)))
             except BaseException as e:  # noqa: BLE001 -- delivered to the submitter
                 fut.set_exception(e)
 
@@ -111,6 +145,8 @@ class LanePool(object):
         return self.submit(lambda lane: model.infer(img, mask, sequence, lane=lane, **kw))
 
     def synchronize(self):
+        """Wait for everything the lanes have been handed so far.  Call it with no job in flight on the host side (every Future resolved): a lane
+        that is still capturing would refuse the stream synchronisation (see LaneEvent)."""
         for lane in self.lanes:
             lane.stream.synchronize()
             for s in (lane.side or ()) + ((lane.dec_stream,) if lane.dec_stream is not None else ()):

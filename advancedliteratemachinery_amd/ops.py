@@ -445,6 +445,19 @@ def make_context_current(handle):
     _lib.check(_lib.lib().omp_ctx_make_current(ctypes.c_void_p(handle)), 'omp_ctx_make_current')
 
 
+class capture_gate(object):
+    """`with ops.capture_gate():` -- bracket for NON-BLOCKING event calls on a stream another host thread drives through omp_decoder_run
+    (omp_capture_gate_enter / _leave, include/omp355.h: no graph capture begins or is in progress inside the bracket)."""
+
+    def __enter__(self):
+        _lib.lib().omp_capture_gate_enter()
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().omp_capture_gate_leave()
+        return False
+
+
 def cu_mask_words(n_per_xcd, total_cus=256, n_xcd=8, complement=False):
     """CU mask with `n_per_xcd` compute units on every XCD: bit i is set iff (i mod 32) < n_per_xcd ... balanced under both
     numberings a runtime may use for the mask (XCD-major: xcd = i / 32; interleaved: xcd = i mod 8) when n_per_xcd is a

@@ -527,7 +527,7 @@ class StepLoop(object):
         futs = [pl.submit(lambda lane, f0=f0, g_=g_: self.run_group(f0, g_, lane, forced)) for f0, g_ in zip(firsts, sizes)]
         for f in futs:
             (ids, probs), ev = f.result()
-            torch.cuda.current_stream().wait_event(ev)
+            ev.wait()   # LaneEvent: inside the capture gate (engine/pipeline.py)
             out = self.exchange(ids, probs)
         return out
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define OMP_ABI_VERSION 20
+#define OMP_ABI_VERSION 21
 #define OMP_MAX_DEC_LAYERS 8
 
 enum { OMP_OK = 0, OMP_ERR_LAUNCH = -5, OMP_ERR_INVALID = -22, OMP_ERR_UNSUPPORTED = -95 };
@@ -396,6 +396,15 @@ typedef struct {
 int omp_decoder_run(const omp_decoder_plan* plan, int first_pos, int n_steps, int graph_slot,
                     omp_stream_t s);
 int omp_decoder_graph_reset(int graph_slot);
+/* The capture gate (round 6, ABI 21; no reference counterpart: engine/val.py:19-35 runs one image at a time on one thread).  omp_decoder_run
+ * captures a graph on the caller's stream the first time a graph_slot is used.  While a stream captures, HIP fails -- and invalidates the
+ * capture on -- hipEventSynchronize / hipEventQuery / hipStreamWaitEvent of every event LAST RECORDED IN THAT STREAM, events of earlier,
+ * uncaptured work included (hipErrorCapturedEvent / hipErrorStreamCaptureIsolation).  A host thread that waits on an event recorded in a
+ * stream which ANOTHER thread drives through omp_decoder_run must bracket the event call with enter / leave: a capture holds the same
+ * process-wide mutex from begin to instantiate.  Keep the bracket non-blocking (query, stream-wait; poll instead of hipEventSynchronize) and
+ * never call omp_decoder_run inside it.  Not needed for events of the calling thread's own streams.  Always OMP_OK. */
+int omp_capture_gate_enter(void);
+int omp_capture_gate_leave(void);
 /* Two decoders' many-row phases as ONE interleaved schedule (round 6; the polygon and recognition loops of Transformer.forward,
  * transformer.py:252-284, which depend on the points only).  Both plans must be rows_fused plans with the same number of layers.
  * Positions first_pos .. first_pos + max(n_steps_a, n_steps_b) - 1: while both decoders have steps left, every cross-attention kernel of

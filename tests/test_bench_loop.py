@@ -39,6 +39,9 @@ def _worker(rank, world, port, q):
         return _tokens(rank, first, g)
     loop = bench.StepLoop(run_group, world, rank, torch.device('cpu'), group=2)
     K = 5
+    loop.timed(K, forced='N')      # untimed warm-up: gloo opens its pair connections inside the first collective (0.1-0.3 s on a loaded host, which
+    del loop.local_s[:]            # made ONE repetition satisfy min_seconds and the >= 2 repetitions below fail once in ~20 CPU runs)
+    n_warm, n_warm_calls = loop.n_gathers, len(calls)
     reps, out = loop.repeat(K, min_seconds=0.12, max_reps=6, forced='N')
     ids, probs = out
     # the last engine call of a 5-step region in groups of 2 is the remainder group (1 step): every rank holds every rank's rows, rank order
@@ -47,8 +50,8 @@ def _worker(rank, world, port, q):
         ei, ep = _tokens(r, 4, 1)
         ok &= bool(torch.equal(ids[r * B:(r + 1) * B], ei)) and bool(torch.equal(probs[r * B:(r + 1) * B], ep))   # bit patterns survive the int32 payload
     per_rank = loop.per_rank_ms(K)
-    q.put(dict(rank=rank, ok=bool(ok), reps=[round(x, 6) for x in reps], n_reps=len(reps), gathers=loop.n_gathers,
-               calls=calls[:3], n_calls=len(calls), per_rank=per_rank, local=[round(x, 6) for x in loop.local_s]))
+    q.put(dict(rank=rank, ok=bool(ok), reps=[round(x, 6) for x in reps], n_reps=len(reps), gathers=loop.n_gathers - n_warm,
+               calls=calls[n_warm_calls:n_warm_calls + 3], n_calls=len(calls) - n_warm_calls, per_rank=per_rank, local=[round(x, 6) for x in loop.local_s]))
     dist.barrier()
     dist.destroy_process_group()
 

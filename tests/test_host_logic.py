@@ -330,6 +330,50 @@ def test_omp_ctx_is_per_thread_and_default_is_protected():
     assert ops.current_context_handle() == default
 
 
+def test_capture_gate_is_a_process_wide_mutex():
+    """include/omp355.h omp_capture_gate_enter / _leave (ABI 21): the bracket a host thread puts around event calls on a stream another thread
+    drives through omp_decoder_run -- the mutex a graph capture holds.  No GPU needed: while one thread is inside the gate, another thread's
+    enter blocks, and proceeds on leave; engine/pipeline.py::LaneEvent runs every event call inside it and polls instead of blocking there."""
+    import threading
+    import time
+    from advancedliteratemachinery_amd import _lib, ops
+    from advancedliteratemachinery_amd.engine.pipeline import LaneEvent
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('libomp355.so not built')
+    order = []
+    inside, release = threading.Event(), threading.Event()
+
+    def holder():                      # stands for a lane thread in the middle of a capture
+        with ops.capture_gate():
+            inside.set()
+            release.wait(10)
+            order.append('capture done')
+    t = threading.Thread(target=holder)
+    t.start()
+    assert inside.wait(10)
+
+    class FakeEvent(object):           # a torch.cuda.Event's interface; what matters is WHEN it is touched
+        def __init__(self):
+            self.polls = 0
+
+        def query(self):
+            order.append('query')
+            self.polls += 1
+            return self.polls >= 3
+    ev = FakeEvent()
+    waiter = threading.Thread(target=lambda: LaneEvent(ev).synchronize(poll_s=0.001))
+    waiter.start()
+    time.sleep(0.05)
+    assert order == []                 # the waiter is parked at the gate: the event has not been touched during the "capture"
+    release.set()
+    t.join(10)
+    waiter.join(10)
+    assert not waiter.is_alive()
+    assert order == ['capture done', 'query', 'query', 'query']    # polled (never blocked inside the gate) until complete
+    with ops.capture_gate():           # left unlocked
+        pass
+
+
 def test_cu_mask_words_are_balanced_over_xcds():
     """ops.cu_mask_words: n CUs on EVERY XCD under the mask numbering measured on the MI355X (bit i -> XCD i % 8, profiles/
     r02u_cu_mask_probe.txt) and under an XCD-major numbering; a mask and its complement partition the 256 CUs."""

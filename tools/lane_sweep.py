@@ -56,7 +56,7 @@ def main():
                 futs = [pool.submit(lambda lane: model.infer(img, mask, seqs, forced_instances=64, has_padding=False, lane=lane)) for _ in range(k)]
                 for f in futs:
                     _, e = f.result()
-                    torch.cuda.current_stream().wait_event(e)
+                    e.wait()
             with torch.cuda.stream(st):
                 run(L)
                 run(2)
