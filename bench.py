@@ -56,6 +56,9 @@ MFMA_PEAK_TFS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix-core peak
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--rccl-selftest', action='store_true',
+                   help='run the N > 1 protocol (RCCL rendezvous, device check, one all-gather per engine call, barriers, max over ranks) with however many ranks there '
+                        'are -- ONE on a 1-GPU box: launch under torch.distributed.run exactly as the driver launches N > 1')
     p.add_argument('--steps', type=int, default=192)
     p.add_argument('--warmup', type=int, default=32)
     p.add_argument('--min-seconds', type=float, default=5.0, help='repeat the K-step timed region until this much time is measured')
@@ -472,8 +475,10 @@ class StepLoop(object):
     run_group(first_step, n_steps, lane, forced) -> (ids int32 [b, N, T], probs fp32 [b, N, L]) is the engine call; on a CPU device
     (the tests) the stream / event calls are skipped, the protocol is the same."""
 
-    def __init__(self, run_group, world, rank, device, group, pools=None):
+    def __init__(self, run_group, world, rank, device, group, pools=None, collectives=None):
         self.run_group, self.world, self.rank, self.device, self.G = run_group, world, rank, device, group
+        # collectives: run the N > 1 protocol (default: world > 1; --rccl-selftest turns it on for ONE rank, the only RCCL run a 1-GPU box allows)
+        self.coll = (world > 1) if collectives is None else bool(collectives)
         self.cuda = device.type == 'cuda'
         self.pools = pools if pools is not None else {'active': None}
         self.gather_ev = []   # (start, end) events around every all-gather of the timed region (cuda)
@@ -485,11 +490,11 @@ class StepLoop(object):
             torch.cuda.synchronize()
 
     def barrier(self):
-        if self.world > 1:
+        if self.coll:
             dist.barrier()
 
     def exchange(self, ids, probs):
-        if self.world == 1:
+        if not self.coll:
             return ids, probs
         e0 = e1 = None
         if self.cuda:
@@ -541,7 +546,7 @@ class StepLoop(object):
         self.barrier()
         el = time.perf_counter() - t0
         self.local_s.append(el)
-        if self.world > 1:
+        if self.coll:
             t = torch.tensor([el], dtype=torch.float64, device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -554,7 +559,7 @@ class StepLoop(object):
             el, out = self.timed(k, group, forced)
             reps.append(el)
             stop = sum(reps) >= min_seconds or len(reps) >= max_reps
-            if self.world > 1:
+            if self.coll:
                 t = torch.tensor([1.0 if stop else 0.0], device=self.device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 stop = bool(t.item() > 0)
@@ -563,7 +568,7 @@ class StepLoop(object):
 
     def per_rank_ms(self, steps):
         """every rank's own median ms per step (before the max over ranks), gathered on all ranks"""
-        if self.world == 1:
+        if not self.coll:
             return None
         mine = torch.tensor([pct(self.local_s, 0.5) / steps * 1e3], dtype=torch.float64, device=self.device)
         allr = torch.empty(self.world, dtype=torch.float64, device=self.device)
@@ -586,7 +591,8 @@ def main():
         raise SystemExit('--gpus %d but only %d GPUs are visible' % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    if world > 1:
+    dist_on = world > 1 or a.rccl_selftest   # (--rccl-selftest: the N > 1 protocol over RCCL with ONE rank, as torch.distributed.run launches it)
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', init_method='env://', device_id=device)
         # RCCL must see exactly N ranks on N distinct devices
@@ -598,7 +604,7 @@ def main():
 
     pinned = pin_host_threads(local, world)
     rank_diag = None
-    if world > 1:
+    if dist_on:
         # what RCCL actually sees: every rank's (rank, device index, device name, pinned cores) -- the first SCALE run is self-diagnosing
         info = dict(rank=rank, local_rank=local, device=torch.cuda.current_device(), name=torch.cuda.get_device_name(local),
                     pinned_cores=len(pinned) if pinned else None)
@@ -609,7 +615,7 @@ def main():
         res = (run_mgp_str if a.workload == 'mgp_str' else run_kie)(a, device, world, rank)
         if rank == 0:
             print(json.dumps(res), flush=True)
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
     a.batch = a.batch or 8
@@ -661,7 +667,7 @@ def main():
         return out
 
     inst_log = []
-    loop = StepLoop(lambda f0, g_, lane, forced: run_group(f0, g_, lane, N if forced == 'N' else forced), world, rank, device, G, pools)
+    loop = StepLoop(lambda f0, g_, lane, forced: run_group(f0, g_, lane, N if forced == 'N' else forced), world, rank, device, G, pools, collectives=dist_on)
     # (forced: 'N' = the benchmark's forced instance count, None = EOS honoured)
     run_steps = lambda k, group=None, forced='N': loop.run_steps(k, group, forced)     # noqa: E731
     timed = lambda k, group=None, forced='N': loop.timed(k, group, forced)             # noqa: E731
@@ -684,7 +690,7 @@ def main():
         call_imgs = calls[0][2] if calls else B * G
     elapsed = pct(reps, 0.5)
     per_rank_ms = loop.per_rank_ms(a.steps)
-    gather_ms = [e0.elapsed_time(e1) for e0, e1 in gather_ev] if world > 1 else None
+    gather_ms = [e0.elapsed_time(e1) for e0, e1 in gather_ev] if dist_on else None
     total_images = world * B * a.steps
     ips = total_images / elapsed
     # sanity: the forced workload really produced N instances x rec_length chars per image
@@ -1027,8 +1033,9 @@ def main():
         rec['images_per_sec_batch8'] = extra.get('batch8', {}).get('images_per_sec') if isinstance(extra.get('batch8'), dict) else None
         # the engine that meets north_star's parity gate (logits <= 1e-3, ids identical) on the same workload, at top level beside the bf16 figure
         rec['images_per_sec_parity_engine'] = extra.get('parity_engine', {}).get('images_per_sec') if isinstance(extra.get('parity_engine'), dict) else None
-        if world > 1:
+        if dist_on:
             rec['ranks'] = rank_diag
+            rec['backend'] = dist.get_backend()
             rec['per_rank_ms_per_step'] = per_rank_ms
             rec['all_gather_ms'] = dict(calls=len(gather_ms), median=pct(gather_ms, 0.5), p90=pct(gather_ms, 0.9),
                                         note='ONE all_gather_into_tensor per engine call (ids + probability bit patterns in one int32 payload), packing included, HIP events on rank 0')
@@ -1050,7 +1057,7 @@ def main():
     for pl in (pool, pools['b8']):
         if pl is not None:
             pl.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -83,3 +83,24 @@ def test_step_loop_single_rank_needs_no_process_group():
     loop = bench.StepLoop(lambda f, g, lane, forced: _tokens(0, f, g), 1, 0, torch.device('cpu'), group=3)
     el, (ids, probs) = loop.timed(7)
     assert ids.shape[0] == B * 1 and loop.n_gathers == 0 and loop.per_rank_ms(7) is None and el > 0
+
+
+def test_step_loop_one_rank_with_collectives_on():
+    """bench.py --rccl-selftest: the N > 1 protocol with ONE rank (the only RCCL run a 1-GPU box allows; here over gloo) -- every engine call
+    still goes through the packed all-gather, the barriers and the all-reduced stop decision, and the payload comes back bit for bit."""
+    import torch.distributed as dist
+    import bench
+    port = 37600 + (os.getpid() % 2000)
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', init_method='env://')
+    try:
+        loop = bench.StepLoop(lambda f, g, lane, forced: _tokens(0, f, g), 1, 0, torch.device('cpu'), group=3, collectives=True)
+        reps, (ids, probs) = loop.repeat(7, min_seconds=0.0, max_reps=2)
+        ei, ep = _tokens(0, 6, 1)
+        assert len(reps) == 1 and loop.n_gathers == 3                  # groups of 3, 3, 1
+        assert torch.equal(ids, ei) and torch.equal(probs, ep)
+        assert len(loop.per_rank_ms(7)) == 1
+    finally:
+        dist.destroy_process_group()
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+            os.environ.pop(k, None)

@@ -16,6 +16,7 @@
 #   pmccross         FETCH_SIZE / WRITE_SIZE passes over the cross-attention kernels at PMC_IMAGES images per launch -> pmc_cross_attn.json
 #   ab:<VAR>         the headline alone (no side legs, no CPU baseline) with VAR=0 and VAR=1 in the environment, phase times on stderr   [AB_ARGS, AB_VALUES]
 #   timeline         kernel trace of the headline WITH graph replay, then tools/rocpd_timeline.py at TL_ANCHOR (kernel substring), occurrence TL_OCC, TL_COUNT dispatches   [TL_ARGS: bench arguments]
+#   rccl1            bench.py --rccl-selftest under torch.distributed.run with one rank: RCCL rendezvous, device check, the packed all-gather per engine call, barriers   [RCCL1_ARGS]
 #   lanes            tests/test_gpu_e2e.py::test_pipelined_lanes_match_direct in LANES_REPS fresh processes (graph capture under another thread's event waits)
 #   py:<script>      python <script> (stdout -> <script basename>.txt)
 TAG=${1:?tag}; shift
@@ -91,6 +92,10 @@ timeline) (cd /tmp && timeout 420 rocprofv3 --kernel-trace -d $R/$OUT/p_tl -o kt
         [ -n "$db" ] && python tools/rocpd_timeline.py $db "${TL_ANCHOR:-dec_embed_ln_kernel}" ${TL_OCC:-300} ${TL_COUNT:-60} > $OUT/timeline.txt 2>> $OUT/rc.log
         [ -n "$db" ] && python tools/rocpd_timeline.py $db "dec_rows_ffn_kernel<5, 1, 0, 0>" ${TL_OCC2:-40} 44 > $OUT/timeline_polyrec.txt 2>> $OUT/rc.log
         rm -rf $OUT/p_tl; cat $OUT/timeline.txt | cut -c1-150;;
+rccl1)  # the N > 1 protocol over RCCL with the ONE rank a 1-GPU box allows, launched exactly as the driver launches N > 1
+        timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --rccl-selftest \
+          --no-parity-leg --no-config-legs --no-batch8 --no-eos-run --no-cpu-baseline ${RCCL1_ARGS} > $OUT/rccl1_bench.json 2> $OUT/rccl1.err; echo "rccl1 rc=$?" >> $OUT/rc.log
+        tail -3 $OUT/rccl1.err | cut -c1-300; python -c "import json; d=json.loads(open('$OUT/rccl1_bench.json').read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('value','ms_per_step','n_gpus','backend','ranks','per_rank_ms_per_step','all_gather_ms')})";;
 lanes)  # the cross-thread capture race shows once in ~4-9 processes: LANES_REPS fresh processes of the pipelined-lane tests
         for i in $(seq ${LANES_REPS:-10}); do timeout 300 python -m pytest tests -m gpu -q -k "pipelined_lanes_match_direct" 2>&1 | tail -1; done > $OUT/lanes_loop.txt
         echo "lanes rc=$(grep -c failed $OUT/lanes_loop.txt) (processes with a failure, of ${LANES_REPS:-10})" >> $OUT/rc.log; cat $OUT/lanes_loop.txt;;
