@@ -83,6 +83,7 @@ def parse():
     p.add_argument('--phase-times', action='store_true', help='also print a per-phase time breakdown (stderr)')
     p.add_argument('--overlap', type=int, default=1, help='polygon || recognition decoders on two streams')
     p.add_argument('--q4-mode', type=int, default=1, help='A/B: omp_debug_cross_q4 selector (1 default, 2 = one 32-key block per step, 4 = chunks with temporal loads)')
+    p.add_argument('--rows-tile', type=int, default=0, help='A/B: omp_debug_rows_tile (0 = by row count, 2..5 = 16-row tiles per workgroup of every decoder chain launch)')
     p.add_argument('--cross-nt', type=int, default=1, help='A/B: omp_debug_cross_nt selector (1 = non-temporal K / V^T loads always (default), 2 = only from 32 images per launch, 0 = never)')
     p.add_argument('--lanes', type=int, default=int(os.environ.get('OMP355_LANES', '1')),
                    help='step groups in flight per GPU (engine/pipeline.py): they overlap on separate HIP streams')
@@ -625,6 +626,8 @@ def main():
         _lib.check(_lib.lib().omp_debug_cross_q4(a.q4_mode), 'omp_debug_cross_q4')
     if a.cross_nt != 1:
         _lib.check(_lib.lib().omp_debug_cross_nt(a.cross_nt), 'omp_debug_cross_nt')
+    if a.rows_tile != 0:
+        _lib.check(_lib.lib().omp_debug_rows_tile(a.rows_tile), 'omp_debug_rows_tile')
     model, args, sd = build_model(a.dtype, a.graph, device)
     model.overlap_decoders = bool(a.overlap)
     model.engine()   # pack the weights once, before any lane thread asks for them
