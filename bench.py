@@ -83,6 +83,7 @@ def parse():
     p.add_argument('--phase-times', action='store_true', help='also print a per-phase time breakdown (stderr)')
     p.add_argument('--overlap', type=int, default=1, help='polygon || recognition decoders on two streams')
     p.add_argument('--q4-mode', type=int, default=1, help='A/B: omp_debug_cross_q4 selector (1 default, 2 = one 32-key block per step, 4 = chunks with temporal loads)')
+    p.add_argument('--dec-fused', type=int, default=0, help='A/B: omp_debug_dec_fused (0 default: fused few-row decoder kernels where they apply, 1 = one launch per op everywhere)')
     p.add_argument('--rows-tile', type=int, default=0, help='A/B: omp_debug_rows_tile (0 = by row count, 2..5 = 16-row tiles per workgroup of every decoder chain launch)')
     p.add_argument('--cross-nt', type=int, default=1, help='A/B: omp_debug_cross_nt selector (1 = non-temporal K / V^T loads always (default), 2 = only from 32 images per launch, 0 = never)')
     p.add_argument('--lanes', type=int, default=int(os.environ.get('OMP355_LANES', '1')),
@@ -626,6 +627,8 @@ def main():
         _lib.check(_lib.lib().omp_debug_cross_q4(a.q4_mode), 'omp_debug_cross_q4')
     if a.cross_nt != 1:
         _lib.check(_lib.lib().omp_debug_cross_nt(a.cross_nt), 'omp_debug_cross_nt')
+    if a.dec_fused != 0:
+        _lib.check(_lib.lib().omp_debug_dec_fused(a.dec_fused), 'omp_debug_dec_fused')
     if a.rows_tile != 0:
         _lib.check(_lib.lib().omp_debug_rows_tile(a.rows_tile), 'omp_debug_rows_tile')
     model, args, sd = build_model(a.dtype, a.graph, device)
