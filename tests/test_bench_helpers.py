@@ -130,3 +130,32 @@ def test_gemm4w_audit_refuses_a_register_copy_in_the_stage_loop():
         finally:
             os.unlink(f.name)
         assert seen == 1 and len(bad) == n_bad, (extra, seen, bad)
+
+
+def test_rocpd_rate_bins_dispatches_per_window(tmp_path, capsys):
+    """tools/rocpd_rate.py (round 6: what bounds the 8-image calls on four lanes) on a synthetic rocpd database: two windows of 20 ms, the first
+    with 4 kernels of 5 ms on two queues side by side (concurrency 1.0), the second with one marker kernel."""
+    import sqlite3
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import rocpd_rate
+    db = str(tmp_path / 'x.db')
+    con = sqlite3.connect(db)
+    con.execute('create table rocpd_info_kernel_symbol (id integer, display_name text)')
+    con.execute('create table rocpd_kernel_dispatch (start integer, end integer, kernel_id integer, queue_id integer)')
+    con.executemany('insert into rocpd_info_kernel_symbol values (?, ?)', [(1, 'gemm_small<x>'), (2, 'dec_fused_self_attn_kernel<true, 4>')])
+    ms = 1000000
+    con.executemany('insert into rocpd_kernel_dispatch values (?, ?, ?, ?)',
+                    [(0, 5 * ms, 1, 7), (0, 5 * ms, 1, 8), (10 * ms, 15 * ms, 1, 7), (10 * ms, 15 * ms, 1, 8), (25 * ms, 26 * ms, 2, 7)])
+    con.commit()
+    con.close()
+    argv = sys.argv
+    sys.argv = ['rocpd_rate.py', db, '20']
+    try:
+        rocpd_rate.main()
+    finally:
+        sys.argv = argv
+    lines = [ln.split() for ln in capsys.readouterr().out.strip().splitlines()]
+    assert lines[0] == ['t_ms', 'dispatches', 'kernels/ms', 'concurrency', 'queues', 'marker']
+    assert lines[1] == ['0', '4', '0.2', '1.00', '2', '0']
+    assert lines[2] == ['20', '1', '0.1', '0.05', '1', '1']
